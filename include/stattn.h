@@ -1,0 +1,160 @@
+/*
+ * stattn.h -- C ABI of libstattn.so: the MI355X-native (gfx950 / CDNA4, hand-written
+ * HIP) spatial-temporal-attention LSTM caption decoder.
+ *
+ * This is the drop-in boundary for ONE path of
+ * tuyunbin/Video-Description-with-Spatial-Temporal-Attention: the decoder graph that
+ * model_attention.py builds with Theano (init_params / build_model / build_sampler ->
+ * f_init, f_next / f_grad_shared / f_update).  Each entry point names the reference
+ * interface it replaces (file:line relative to the reference repo).  The reference
+ * binds compiled `theano.function` objects from Python; the matching binding for this
+ * library is a ctypes stub (INTEGRATION.md, and stattn/_native.py in this repo).
+ *
+ * Conventions
+ *  - plain pointers and sizes only; every `const float*` / `const int64_t*` argument
+ *    is a HOST pointer to C-contiguous data unless the name ends in `_dev`;
+ *    dtypes are strict like Theano's: int64 words, float32 everything else.
+ *  - every function returns 0 on success or a negative STATTN_E* code and never
+ *    aborts; stattn_last_error() gives the message.
+ *  - one handle = one GPU + one stream; calls on a handle are serialised by the
+ *    caller; distinct handles are independent (one per rank).
+ *  - the library owns all device memory; host buffers are borrowed for the call.
+ */
+#ifndef STATTN_H
+#define STATTN_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define STATTN_OK 0
+#define STATTN_EINVAL (-1)   /* bad argument / unsupported option value        */
+#define STATTN_EHIP (-2)     /* a HIP runtime call failed                       */
+#define STATTN_ESTATE (-3)   /* call order violated (e.g. backward w/o forward) */
+#define STATTN_ENOTFOUND (-4)
+
+typedef struct stattn_handle stattn_handle;
+
+/* The option keys the hot path consumes (model_attention.py:1079-1096 `model_options`,
+ * config.py:17-48).  Unsupported-by-the-reference values are rejected exactly where
+ * the reference graph is broken: n_layers_init must be 0 (model_attention.py:546-548),
+ * use_dropout must be 1 (:479-481), encoder must be 'none' (:524-536),
+ * ctxg_dim == dim == ctxglm_dim (ff_global is commented out, :553-554). */
+typedef struct stattn_options {
+    int32_t dim;        /* LSTM units D            (multiple of 64)              */
+    int32_t dim_word;   /* word embedding E        (multiple of 64)              */
+    int32_t n_words;    /* vocabulary V            (any)                         */
+    int32_t ctxg_dim;   /* global feature dim      (must equal dim)              */
+    int32_t ctxl_dim;   /* local (RCNN) feature F  (multiple of 32)              */
+    int32_t ctxm_dim;   /* motion (C3D) feature    (multiple of 32)              */
+    int32_t selector;   /* model_attention.py:432                                */
+    int32_t use_dropout;/* must be 1                                             */
+    int32_t prev2out;   /* :689                                                  */
+    int32_t ctx2out;    /* :691                                                  */
+    int32_t lt_mode;    /* local-temporal projection CL.Wclt (:416):
+                           0 = one MFMA GEMM per step, the reference's order;
+                           1 = L.Wclt pre-projected once per batch, alpha-weighted
+                               sum per step (same maths, different summation order) */
+    int32_t reserved[5];
+} stattn_options;
+
+/* ---- lifecycle ---------------------------------------------------------------- */
+/* Replaces: Attention.init_tparams / common.init_tparams (model_attention.py:70-78,
+ * common.py:103-107): creates the device-resident parameter set (zero-filled).
+ * `stream`: a hipStream_t to run on (e.g. torch's current stream) or NULL to create one. */
+int stattn_create(const stattn_options* opt, int device, void* stream, stattn_handle** out);
+void stattn_destroy(stattn_handle* h);
+const char* stattn_last_error(const stattn_handle* h); /* h may be NULL: last create error */
+const char* stattn_version(void);
+int stattn_sync(stattn_handle* h);                     /* hipStreamSynchronize             */
+
+/* ---- parameters: theano.shared get_value/set_value, zipp/unzip (common.py:78-87) -- */
+int stattn_param_count(const stattn_handle* h);
+const char* stattn_param_name(const stattn_handle* h, int i);
+/* dims[0..1], ndim in {0,1,2}; order = init_params dict order (model_attention.py:518-581) */
+int stattn_param_shape(const stattn_handle* h, int i, int64_t dims[2], int* ndim);
+int stattn_set_param(stattn_handle* h, const char* name, const float* src, size_t n);
+int stattn_get_param(stattn_handle* h, const char* name, float* dst, size_t n);
+/* flat device buffers (padded layout, identical on every rank) for the data-parallel
+ * all-reduce and for tools: *n = number of floats. */
+int stattn_param_buffer_dev(stattn_handle* h, void** ptr_dev, size_t* n);
+int stattn_grad_buffer_dev(stattn_handle* h, void** ptr_dev, size_t* n);
+int stattn_get_grad(stattn_handle* h, const char* name, float* dst, size_t n);
+
+/* use_noise shared scalar (model_attention.py:585, 1248, 1311): 0 = eval (x0.5), 1 = Bernoulli(.5) */
+int stattn_set_use_noise(stattn_handle* h, float use_noise);
+int stattn_set_seed(stattn_handle* h, uint64_t seed);
+/* Test hook: supply the three dropout multiplier tensors instead of drawing them:
+ * dp (t,m,3D) on the i/f/o pre-activations (:444-447), d1 (t,m,D) on proj_h (:685),
+ * d2 (t,m,E) on tanh(logit) (:696).  NULL restores the internal generator. */
+int stattn_set_dropout_masks(stattn_handle* h, const float* dp, const float* d1, const float* d2,
+                             int t, int m);
+
+/* ---- sampler: build_sampler -> f_init, f_next (model_attention.py:719-850) -------- */
+/* f_init(ctxg, ctxg_mask) -> [ctxg, h0, c0]  (:791-795).  ctxg (T,D), mask (T,). */
+int stattn_f_init(stattn_handle* h, const float* ctxg, const float* ctxg_mask, int T,
+                  float* out_h0, float* out_c0);
+/* f_next(x, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask, h, c)
+ *   -> [next_probs (m,V), next_sample (m,), h' (m,D), c' (m,D)]   (:845-848)
+ * x (m,) int64 (-1 = first word), ctxl (T,K,F), ctxm (T,F).  ctxl_mask / ctxm_mask are
+ * accepted and ignored exactly like the reference (on_unused_input='ignore').
+ * The F->D projections the reference recomputes on every call (:782-785, :322-326) are
+ * cached per video: keyed by the three ctx pointers, T, K and a content fingerprint;
+ * stattn_invalidate_ctx_cache() forces a re-projection.
+ * Optional outputs (NULL to skip) for the parity bar: out_alphal (m,T,K), out_alphag/m/lt
+ * (m,T), out_logits (m,V). */
+int stattn_f_next(stattn_handle* h, const int64_t* x, int m,
+                  const float* ctxg, const float* ctxg_mask,
+                  const float* ctxl, const float* ctxl_mask,
+                  const float* ctxm, const float* ctxm_mask, int T, int K,
+                  const float* h_in, const float* c_in,
+                  float* out_probs, int64_t* out_sample, float* out_h, float* out_c,
+                  float* out_alphal, float* out_alphag, float* out_alpham, float* out_alphalt,
+                  float* out_logits);
+int stattn_invalidate_ctx_cache(stattn_handle* h);
+
+/* ---- training graph: build_model / f_log_probs / f_grad_shared (:583-717, 1126, 1207) -- */
+/* Stage one minibatch in HBM: prepare_data()'s 8-tuple (data_engine.py:258-337).
+ * x (t,m) int64, mask (t,m), ctxg (m,T,D), mask_ctxg (m,T), ctxl (m,T,K,F),
+ * mask_ctxl (m,T,K) [ignored], ctxm (m,T,F), mask_ctxm (m,T) [ignored]. */
+int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int t, int m,
+                     const float* ctxg, const float* mask_ctxg,
+                     const float* ctxl, const float* mask_ctxl,
+                     const float* ctxm, const float* mask_ctxm, int T, int K);
+/* Forward of build_model on the staged batch (asynchronous on the handle's stream):
+ * prologue (ff_local/ff_motion, attention pre-projections, init state, x projection),
+ * t decoder steps, readout, vocabulary softmax, masked NLL. */
+int stattn_forward_train(stattn_handle* h);
+/* Results of the last forward.  Any pointer may be NULL.  cost (m,) [= -f_log_probs],
+ * probs (t*m,V), alphal (t,m,T,K), alphag/alpham/alphalt (t,m,T), logits (t*m,V). */
+int stattn_get_forward(stattn_handle* h, float* cost, float* probs,
+                       float* alphal, float* alphag, float* alpham, float* alphalt, float* logits);
+/* per-step state of the last forward, for tests: hs, cs (t,m,D), ctx (t,m,D) */
+int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx);
+
+/* ---- kernel-level entry points (used by tests/ and bench.py to check and time the
+ *      building blocks in isolation; not part of the reference surface) ------------- */
+/* C[M,N] = act(alpha * op(A).op(B) + bias[n] + add[m,n]);  host pointers.
+ * transA: A given as [K,M]; transB: B given as [N,K]; act: 0 none, 1 tanh.
+ * Runs the LDS-tiled fp32 MFMA kernel (kind=0) or the register-streaming skinny
+ * kernel (kind=1).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
+int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K,
+                    float alpha, const float* A, const float* B, const float* bias,
+                    const float* add, int act, float* C);
+/* Time `iters` launches of the big GEMM on device-resident random data; returns the
+ * average milliseconds per launch measured with HIP events on the handle's stream. */
+int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K,
+                         int iters, float* ms_per_launch);
+/* Average duration (ms) of the named kernel class over the last stattn_forward_train
+ * when profiling is enabled: 0 = spatial attention, 1 = state projections, 2 = local-
+ * temporal GEMM, 3 = temporal fuse, 4 = lstm, 5 = prologue GEMMs (sum), 6 = readout GEMMs (sum). */
+int stattn_set_profiling(stattn_handle* h, int enable);
+int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* STATTN_H */

@@ -1,0 +1,283 @@
+"""GPU parity tests (run with -m gpu on a real MI355X): the HIP path, called through the C ABI,
+against the CPU oracle on identical weights and inputs.  Bar (BASELINE.json north_star):
+attention weights and logits within 1e-4 absolute, fp32."""
+import os
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4          # north-star tolerance on attention weights and logits (absolute, fp32)
+
+
+@pytest.fixture(scope="module")
+def stattn_mod():
+    import stattn
+    return stattn
+
+
+@pytest.fixture(scope="module")
+def O():
+    from oracle import stattn_oracle
+    return stattn_oracle
+
+
+def _f64(batch):
+    return {k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()}
+
+
+SMALL = dict(dim=128, dim_word=64, n_words=211, ctxg_dim=128, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=128)
+MEDIUM = dict(dim=256, dim_word=128, n_words=1000, ctxg_dim=256, ctxl_dim=512, ctxm_dim=256, ctxglm_dim=256)
+
+
+def _decoder(stattn_mod, O, dims, lt_mode, seed=3, **optkw):
+    opt = O.default_options(**{**dims, **optkw})
+    P = O.random_params(opt, seed=seed, dtype=np.float32)
+    dec = stattn_mod.Decoder(opt, lt_mode=lt_mode)
+    dec.set_params(P)
+    return opt, P, O.cast_params(P, np.float64), dec
+
+
+# ------------------------------------------------------------------ building blocks
+@pytest.mark.parametrize("M,N,K", [(128, 128, 32), (200, 64, 96), (1664, 1024, 1024), (37, 192, 64),
+                                   (13312 // 8, 256, 4096), (300, 12032 // 4, 512)])
+def test_lds_tiled_gemm_matches_float64(stattn_mod, O, M, N, K):
+    dec = _decoder(stattn_mod, O, SMALL, 1)[3]
+    rng = np.random.RandomState(M + N + K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, N)).astype(np.float32)      # asymmetric: catches transposed C writes
+    bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
+    add = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    tol = 2e-5 * np.sqrt(K)
+    np.testing.assert_allclose(dec.gemm(A, B), ref, atol=tol, rtol=1e-5)
+    out = dec.gemm(A, B, bias=bias, add=add, act=1, alpha=0.05)
+    np.testing.assert_allclose(out, np.tanh(0.05 * ref + bias + add), atol=1e-5, rtol=1e-5)
+    # transposed operand variants (used by the backward pass)
+    np.testing.assert_allclose(dec.gemm(A, np.ascontiguousarray(B.T), transB=True), ref, atol=tol, rtol=1e-5)
+    if M % 4 == 0:
+        np.testing.assert_allclose(dec.gemm(np.ascontiguousarray(A.T), B, transA=True), ref, atol=tol, rtol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(1, 64, 16), (5, 128, 1024), (64, 8192, 1024), (64, 12032, 512), (160, 256, 256), (17, 192, 48)])
+def test_skinny_gemm_matches_float64(stattn_mod, O, M, N, K):
+    dec = _decoder(stattn_mod, O, SMALL, 1)[3]
+    rng = np.random.RandomState(M * 7 + N + K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
+    add = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    np.testing.assert_allclose(dec.gemm(A, B, kind=1), ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
+    out = dec.gemm(A, B, bias=bias, add=add, act=1, kind=1)
+    np.testing.assert_allclose(out, np.tanh(ref + bias + add), atol=1e-5, rtol=1e-5)
+
+
+# ------------------------------------------------------------------ sampler: f_init / f_next
+@pytest.mark.parametrize("lt_mode", [0, 1])
+@pytest.mark.parametrize("dims,T,K", [(SMALL, 5, 4), (MEDIUM, 26, 8), (SMALL, 7, 11)])
+def test_f_init_f_next_chain_matches_oracle(stattn_mod, O, lt_mode, dims, T, K):
+    opt, P, P64, dec = _decoder(stattn_mod, O, dims, lt_mode)
+    batch = O.synthetic_batch(opt, B=1, T=T, K=K, t=4, seed=21)
+    g, l, m, gm = batch['ctxg'][0], batch['ctxl'][0], batch['ctxm'][0], batch['mask_ctxg'][0]
+    _, h0, c0 = dec.f_init(g, gm)
+    _, h0r, c0r = O.f_init(P64, opt, g.astype(np.float64), gm.astype(np.float64))
+    assert np.abs(h0 - h0r).max() < TOL and np.abs(c0 - c0r).max() < TOL
+    # three consecutive steps, m = 3 hypotheses, first word -1
+    h = np.stack([h0, 0.3 * h0, -h0]); c = np.stack([c0, c0 * 0.5, c0])
+    hr, cr = h.astype(np.float64), c.astype(np.float64)
+    x = np.array([-1, 5, 17], np.int64)
+    for step in range(3):
+        (probs, _, h, c), ex = dec.f_next(x, g, gm, l, None, m, None, h, c, extras=True)
+        (pr, _, hr, cr), r = O.f_next(P64, opt, x, g.astype(np.float64), gm, l.astype(np.float64), None,
+                                      m.astype(np.float64), None, hr, cr, extras=True)
+        for name in ('alphal', 'alphag', 'alpham', 'alphalt', 'logit'):
+            err = np.abs(ex[name] - r[name]).max()
+            assert err < TOL, (step, name, err)
+        assert np.abs(probs - pr).max() < TOL
+        assert np.abs(h - hr).max() < TOL and np.abs(c - cr).max() < TOL
+        np.testing.assert_allclose(probs.sum(1), 1.0, atol=1e-5)
+        x = np.array([3 + step, 9, 2], np.int64)
+        hr, cr = h.astype(np.float64), c.astype(np.float64)     # re-sync so errors do not compound in the check
+
+
+def test_f_next_context_cache_tracks_the_video(stattn_mod, O):
+    opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1)
+    b = O.synthetic_batch(opt, B=2, T=5, K=4, t=3, seed=4)
+    x = np.array([4], np.int64)
+    h = np.zeros((1, 128), np.float32); c = np.zeros((1, 128), np.float32)
+    outs = []
+    for v in (0, 1, 0):
+        g, l, m = b['ctxg'][v].copy(), b['ctxl'][v].copy(), b['ctxm'][v].copy()
+        p1 = dec.f_next(x, g, None if False else b['mask_ctxg'][v], l, None, m, None, h, c)[0]
+        p2 = dec.f_next(x, g, b['mask_ctxg'][v], l, None, m, None, h, c)[0]     # cache hit: identical
+        np.testing.assert_array_equal(p1, p2)
+        outs.append(p1)
+        l[0, 0, 0] += 1.0        # in-place edit of the first element must be noticed (fingerprint)
+        p3 = dec.f_next(x, g, b['mask_ctxg'][v], l, None, m, None, h, c)[0]
+        ref = O.f_next(P64, opt, x, g.astype(np.float64), None, l.astype(np.float64), None, m.astype(np.float64), None,
+                       h.astype(np.float64), c.astype(np.float64))[0]
+        assert np.abs(p3 - ref).max() < TOL
+    np.testing.assert_array_equal(outs[0], outs[2])
+    assert np.abs(outs[0] - outs[1]).max() > 1e-6
+
+
+def test_zero_weights_known_answers_on_gpu(stattn_mod, O):
+    """Analytic KAT independent of any restatement: zero weights => uniform attention, 1/V probs,
+    c' = .5 c, h' = .5 tanh(.5 c)."""
+    opt, P, _, dec = _decoder(stattn_mod, O, SMALL, 1)
+    dec.set_params(OrderedDict((k, np.zeros_like(v)) for k, v in P.items()))
+    b = O.synthetic_batch(opt, B=1, T=6, K=5, t=3, seed=8)
+    rng = np.random.RandomState(0)
+    h = rng.standard_normal((2, 128)).astype(np.float32); c = rng.standard_normal((2, 128)).astype(np.float32)
+    (probs, _, h1, c1), ex = dec.f_next(np.array([3, -1], np.int64), b['ctxg'][0], b['mask_ctxg'][0], b['ctxl'][0], None,
+                                        b['ctxm'][0], None, h, c, extras=True)
+    np.testing.assert_allclose(ex['alphal'], 1 / 5.0, atol=1e-6)
+    for a in ('alphag', 'alpham', 'alphalt'):
+        np.testing.assert_allclose(ex[a], 1 / 6.0, atol=1e-6)
+    np.testing.assert_allclose(probs, 1 / 211.0, atol=1e-7)
+    np.testing.assert_allclose(c1, 0.5 * c, atol=1e-6)
+    np.testing.assert_allclose(h1, 0.5 * np.tanh(0.5 * c), atol=1e-6)
+
+
+# ------------------------------------------------------------------ training graph forward
+@pytest.mark.parametrize("lt_mode", [0, 1])
+@pytest.mark.parametrize("dims,B,T,K,t", [(SMALL, 5, 5, 4, 6), (MEDIUM, 9, 26, 8, 7), (SMALL, 70, 3, 2, 4)])
+def test_build_model_forward_matches_oracle(stattn_mod, O, lt_mode, dims, B, T, K, t):
+    opt, P, P64, dec = _decoder(stattn_mod, O, dims, lt_mode, seed=6)
+    batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=31)        # ragged mask
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    st = dec.get_states()
+    ref = O.build_model_forward(P64, opt, **_f64(batch))
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name] - ref[name]).max() < TOL, name
+    assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL
+    assert np.abs(out['probs'] - ref['probs']).max() < TOL
+    assert np.abs(st['h'] - ref['h']).max() < TOL and np.abs(st['c'] - ref['c']).max() < TOL
+    assert np.abs(st['ctx'] - ref['ctx']).max() < TOL
+    np.testing.assert_allclose(out['cost'], ref['cost'], rtol=1e-4, atol=1e-4)
+
+
+def test_forward_with_supplied_dropout_masks(stattn_mod, O):
+    opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1, seed=9)
+    B, T, K, t = 4, 5, 3, 5
+    batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=32)
+    rng = np.random.RandomState(1)
+    dp = rng.binomial(1, 0.5, (t, B, 3 * 128)).astype(np.float32)
+    d1 = rng.binomial(1, 0.5, (t, B, 128)).astype(np.float32)
+    d2 = rng.binomial(1, 0.5, (t, B, 64)).astype(np.float32)
+    dec.set_use_noise(1.0)
+    dec.set_dropout_masks(dp, d1, d2)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    ref = O.build_model_forward(P64, opt, **_f64(batch), dp_mask=dp.astype(np.float64), d1=d1.astype(np.float64),
+                                d2=d2.astype(np.float64))
+    assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL
+    assert np.abs(out['alphalt'] - ref['alphalt']).max() < TOL
+    # internal generator: Bernoulli(0.5) draws change the result and differ call to call
+    dec.set_dropout_masks(None, None, None)
+    dec.forward_train(); a = dec.get_forward()['cost']
+    dec.forward_train(); b = dec.get_forward()['cost']
+    assert np.abs(a - b).max() > 1e-6
+    dec.set_use_noise(0.0)
+    dec.forward_train(); c0 = dec.get_forward()['cost']
+    ref0 = O.build_model_forward(P64, opt, **_f64(batch))
+    np.testing.assert_allclose(c0, ref0['cost'], rtol=1e-4, atol=1e-4)
+
+
+def test_options_variants(stattn_mod, O):
+    for kw in (dict(selector=False), dict(ctx2out=False), dict(prev2out=False), dict(selector=False, ctx2out=False, prev2out=False)):
+        opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1, seed=12, **kw)
+        batch = O.synthetic_batch(opt, B=3, T=4, K=3, t=4, seed=33)
+        dec.set_batch(**batch)
+        dec.forward_train()
+        out = dec.get_forward(logits=True)
+        ref = O.build_model_forward(P64, opt, **_f64(batch))
+        assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL, kw
+        g, l, m, gm = batch['ctxg'][0], batch['ctxl'][0], batch['ctxm'][0], batch['mask_ctxg'][0]
+        h = np.zeros((1, 128), np.float32) + 0.1
+        (pr, _, _, _), ex = dec.f_next(np.array([5], np.int64), g, gm, l, None, m, None, h, h, extras=True)
+        (prr, _, _, _), r = O.f_next(P64, opt, np.array([5]), g.astype(np.float64), gm, l.astype(np.float64), None,
+                                     m.astype(np.float64), None, h.astype(np.float64), h.astype(np.float64), extras=True)
+        assert np.abs(ex['logit'] - r['logit']).max() < TOL, kw
+
+
+# ------------------------------------------------------------------ reference surface
+def test_attention_surface_gen_sample_matches_oracle_driver(stattn_mod, O):
+    """init_params -> init_tparams -> build_sampler -> gen_sample (greedy and beam 5) against the
+    oracle's gen_sample driven by the oracle's f_next."""
+    opt = O.default_options(**SMALL)
+    model = stattn_mod.Attention()
+    stattn_mod.common.reset_rngs(1234)
+    params = model.init_params(opt)
+    assert list(params) == list(O.param_shapes(opt))
+    for k, shp in O.param_shapes(opt).items():
+        assert np.shape(params[k]) == shp and np.asarray(params[k]).dtype == np.float32
+    # reference init gives near-uniform attention; perturb so the search is non-trivial
+    rng = np.random.RandomState(5)
+    for k in params:
+        if k.endswith('_att') or k.startswith('ff_logit'):
+            params[k] = (np.asarray(params[k]) + 0.3 * rng.standard_normal(np.shape(params[k]))).astype(np.float32)
+    tparams = model.init_tparams(params)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    P64 = O.cast_params(params, np.float64)
+    b = O.synthetic_batch(opt, B=1, T=5, K=4, t=3, seed=40)
+    args = (b['ctxg'][0], b['mask_ctxg'][0], b['ctxl'][0], b['mask_ctxl'][0], b['ctxm'][0], b['mask_ctxm'][0])
+    args64 = tuple(a.astype(np.float64) for a in args)
+    fi = lambda g, m: O.f_init(P64, opt, g, m)
+    fn = lambda *a: O.f_next(P64, opt, *a)
+    for k in (1, 5):
+        s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=8)
+        sr, scr, _, _ = O.gen_sample(fi, fn, *args64, k=k, maxlen=8)
+        assert len(s) == len(sr)
+        np.testing.assert_allclose(sorted(np.asarray(sc, np.float64)), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=1e-4)
+        assert s[int(np.argmin(sc))] == sr[int(np.argmin(scr))]
+    # unzip / zipp round trip through the device
+    pulled = stattn_mod.common.unzip(tparams)
+    for k in params:
+        np.testing.assert_array_equal(pulled[k], np.asarray(params[k], np.float32))
+
+
+def test_f_log_probs_and_strict_dtypes(stattn_mod, O):
+    opt = O.default_options(**SMALL)
+    model = stattn_mod.Attention()
+    P = O.random_params(opt, seed=2, dtype=np.float32)
+    tparams = model.init_tparams(P)
+    (trng, use_noise, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm,
+     alphals, alphags, alphams, alphalts, cost, extra) = model.build_model(tparams, opt)
+    inps = [x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm]
+    f_log_probs = model.function(inps, -cost)
+    f_alphal = model.function(inps, [alphals, 0.0])
+    b = O.synthetic_batch(opt, B=4, T=5, K=3, t=5, seed=41)
+    a = (b['x'], b['mask'], b['ctxg'], b['mask_ctxg'], b['ctxl'], b['mask_ctxl'], b['ctxm'], b['mask_ctxm'])
+    ref = O.build_model_forward(O.cast_params(P, np.float64), opt, **_f64(b))
+    np.testing.assert_allclose(f_log_probs(*a), -ref['cost'], rtol=1e-4, atol=1e-4)
+    al, z = f_alphal(*a)
+    assert z == 0.0 and np.abs(al - ref['alphal']).max() < TOL
+    nll, perp = model.pred_probs([a], f_log_probs)
+    np.testing.assert_allclose(nll, ref['cost'].mean(), rtol=1e-4)
+    with pytest.raises(TypeError):
+        f_log_probs(b['x'].astype(np.int32), *a[1:])
+    with pytest.raises(TypeError):
+        f_log_probs(a[0], a[1].astype(np.float64), *a[2:])
+
+
+def test_c1_msvd_tiny_config_logits_and_alphas(stattn_mod, O):
+    """BASELINE.json configs[0] shapes: batch 4, T=26, K=8, feat 4096, hidden 512 (V reduced to 2000 to
+    keep the float64 oracle quick); init_params-scale weights."""
+    dims = dict(dim=512, dim_word=512, n_words=2000, ctxg_dim=512, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=512)
+    for lt in (0, 1):
+        opt, P, P64, dec = _decoder(stattn_mod, O, dims, lt, seed=17)
+        batch = O.synthetic_batch(opt, B=4, T=26, K=8, t=5, seed=50)
+        dec.set_batch(**batch)
+        dec.forward_train()
+        out = dec.get_forward(logits=True)
+        ref = O.build_model_forward(P64, opt, **_f64(batch))
+        for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+            assert np.abs(out[name] - ref[name]).max() < TOL, (lt, name)
+        assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL, lt

@@ -1,0 +1,344 @@
+"""ctypes binding of libstattn.so (C ABI: include/stattn.h).
+
+This is the stub a maintainer of the reference would add where model_attention.py calls
+`theano.function(...)`: every method below forwards to exactly one C entry point.  The
+library is loaded lazily and LOUDLY: a missing .so or a box without a HIP device raises
+NativeError -- there is no CPU fallback anywhere in the product path."""
+import ctypes as C
+import os
+from collections import OrderedDict
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class NativeError(RuntimeError):
+    pass
+
+
+def library_path():
+    return os.path.join(_HERE, "libstattn.so")
+
+
+class _Options(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in
+                ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim",
+                 "selector", "use_dropout", "prev2out", "ctx2out", "lt_mode")] + [("reserved", C.c_int32 * 5)]
+
+
+_F = C.POINTER(C.c_float)
+_I64 = C.POINTER(C.c_int64)
+_H = C.c_void_p
+
+_SIGNATURES = {
+    # name: (restype, argtypes)
+    "stattn_create": (C.c_int, [C.POINTER(_Options), C.c_int, C.c_void_p, C.POINTER(_H)]),
+    "stattn_destroy": (None, [_H]),
+    "stattn_last_error": (C.c_char_p, [_H]),
+    "stattn_version": (C.c_char_p, []),
+    "stattn_sync": (C.c_int, [_H]),
+    "stattn_param_count": (C.c_int, [_H]),
+    "stattn_param_name": (C.c_char_p, [_H, C.c_int]),
+    "stattn_param_shape": (C.c_int, [_H, C.c_int, C.POINTER(C.c_int64 * 2), C.POINTER(C.c_int)]),
+    "stattn_set_param": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
+    "stattn_get_param": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
+    "stattn_get_grad": (C.c_int, [_H, C.c_char_p, _F, C.c_size_t]),
+    "stattn_param_buffer_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "stattn_grad_buffer_dev": (C.c_int, [_H, C.POINTER(C.c_void_p), C.POINTER(C.c_size_t)]),
+    "stattn_set_use_noise": (C.c_int, [_H, C.c_float]),
+    "stattn_set_seed": (C.c_int, [_H, C.c_uint64]),
+    "stattn_set_dropout_masks": (C.c_int, [_H, _F, _F, _F, C.c_int, C.c_int]),
+    "stattn_f_init": (C.c_int, [_H, _F, _F, C.c_int, _F, _F]),
+    "stattn_f_next": (C.c_int, [_H, _I64, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _F, _F,
+                                _F, _I64, _F, _F, _F, _F, _F, _F, _F]),
+    "stattn_invalidate_ctx_cache": (C.c_int, [_H]),
+    "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
+    "stattn_forward_train": (C.c_int, [_H]),
+    "stattn_get_forward": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F]),
+    "stattn_get_states": (C.c_int, [_H, _F, _F, _F]),
+    "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
+                                  _F, _F, _F, _F, C.c_int, _F]),
+    "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "stattn_set_profiling": (C.c_int, [_H, C.c_int]),
+    "stattn_get_kernel_ms": (C.c_int, [_H, C.c_int, _F, C.POINTER(C.c_int)]),
+}
+
+EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+
+
+def load_library():
+    """dlopen libstattn.so and declare every prototype.  Loading needs no GPU."""
+    global _LIB
+    if _LIB is not None:
+        return _LIB
+    path = library_path()
+    if not os.path.exists(path):
+        raise NativeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                          "(or `make -C %s/csrc`).  stattn has no CPU fallback." % (path, _HERE))
+    lib = C.CDLL(path)
+    for name, (res, args) in _SIGNATURES.items():
+        fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
+        fn.restype = res
+        fn.argtypes = args
+    _LIB = lib
+    return lib
+
+
+def _fp(a):
+    return None if a is None else a.ctypes.data_as(_F)
+
+
+def _f32(a, name, shape=None):
+    """Theano-strict input check: float32, C-contiguous (TypeError otherwise, like theano.function)."""
+    if not isinstance(a, np.ndarray) or a.dtype != np.float32:
+        raise TypeError("%s must be a float32 numpy array (got %s)" % (name, getattr(a, "dtype", type(a))))
+    if shape is not None and tuple(a.shape) != tuple(shape):
+        raise ValueError("%s has shape %s, expected %s" % (name, a.shape, tuple(shape)))
+    return np.ascontiguousarray(a)
+
+
+def _i64(a, name):
+    if not isinstance(a, np.ndarray) or a.dtype != np.int64:
+        raise TypeError("%s must be an int64 numpy array (got %s)" % (name, getattr(a, "dtype", type(a))))
+    return np.ascontiguousarray(a)
+
+
+OPTION_KEYS = ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim",
+               "selector", "use_dropout", "prev2out", "ctx2out")
+
+KERNEL_CLASSES = ("spatial", "hproj", "lt_gemm", "temporal", "lstm", "prologue", "readout")
+
+
+class Decoder(object):
+    """One native decoder instance = one GPU + one stream (stattn_handle)."""
+
+    def __init__(self, options, device=0, stream=None, lt_mode=None):
+        lib = load_library()
+        self._lib = lib
+        self._h = _H()
+        o = _Options()
+        for k in OPTION_KEYS:
+            if k not in options:
+                raise ValueError("options lacks '%s'" % k)
+            setattr(o, k, int(options[k]))
+        # reference graph limits: reject what the reference itself cannot run
+        if options.get("n_layers_init", 0) != 0:
+            raise ValueError("n_layers_init must be 0 (model_attention.py:546-548 references undefined names)")
+        if options.get("n_layers_out", 1) != 1:
+            raise ValueError("only n_layers_out == 1 is supported (config.py:23)")
+        if options.get("encoder", "none") not in ("none", None):
+            raise ValueError("encoder must be 'none' (the lstm encoder branches are broken: model_attention.py:626-634)")
+        if lt_mode is None:
+            lt_mode = int(os.environ.get("STATTN_LT_MODE", options.get("lt_mode", 1)))
+        o.lt_mode = int(lt_mode)
+        self.lt_mode = int(lt_mode)
+        self.options = dict(options)
+        rc = lib.stattn_create(C.byref(o), int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
+        if rc != 0:
+            msg = lib.stattn_last_error(None).decode()
+            self._h = _H()
+            if rc == -1:
+                raise ValueError(msg)
+            raise NativeError("stattn_create failed (%d): %s" % (rc, msg))
+        self.D, self.E, self.V = o.dim, o.dim_word, o.n_words
+        self.Fl, self.Fm = o.ctxl_dim, o.ctxm_dim
+        self._shapes = OrderedDict()
+        for i in range(lib.stattn_param_count(self._h)):
+            dims = (C.c_int64 * 2)()
+            nd = C.c_int()
+            self._chk(lib.stattn_param_shape(self._h, i, C.byref(dims), C.byref(nd)))
+            self._shapes[lib.stattn_param_name(self._h, i).decode()] = tuple(dims[j] for j in range(nd.value))
+        self._batch = None
+
+    # -- plumbing
+    def _chk(self, rc):
+        if rc == 0:
+            return
+        msg = self._lib.stattn_last_error(self._h).decode()
+        if rc == -1:
+            raise ValueError(msg)
+        raise NativeError("libstattn error %d: %s" % (rc, msg))
+
+    def close(self):
+        if getattr(self, "_h", None) and self._h.value:
+            self._lib.stattn_destroy(self._h)
+            self._h = _H()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def sync(self):
+        self._chk(self._lib.stattn_sync(self._h))
+
+    # -- parameters
+    def param_shapes(self):
+        return OrderedDict(self._shapes)
+
+    def set_param(self, name, value):
+        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+        if name not in self._shapes:
+            raise KeyError(name)
+        if tuple(v.shape) != self._shapes[name]:
+            raise ValueError("%s: shape %s, expected %s" % (name, v.shape, self._shapes[name]))
+        self._chk(self._lib.stattn_set_param(self._h, name.encode(), _fp(v), v.size))
+
+    def get_param(self, name):
+        out = np.empty(self._shapes[name], np.float32)
+        self._chk(self._lib.stattn_get_param(self._h, name.encode(), _fp(out), out.size))
+        return out
+
+    def get_grad(self, name):
+        out = np.empty(self._shapes[name], np.float32)
+        self._chk(self._lib.stattn_get_grad(self._h, name.encode(), _fp(out), out.size))
+        return out
+
+    def set_params(self, params):
+        for k in self._shapes:
+            if k not in params:
+                raise KeyError("parameter '%s' missing" % k)
+            self.set_param(k, params[k])
+
+    def get_params(self):
+        return OrderedDict((k, self.get_param(k)) for k in self._shapes)
+
+    def _dev_buffer(self, fn):
+        p = C.c_void_p()
+        n = C.c_size_t()
+        self._chk(fn(self._h, C.byref(p), C.byref(n)))
+        return p.value, n.value
+
+    def param_buffer_dev(self):
+        return self._dev_buffer(self._lib.stattn_param_buffer_dev)
+
+    def grad_buffer_dev(self):
+        return self._dev_buffer(self._lib.stattn_grad_buffer_dev)
+
+    def set_use_noise(self, v):
+        self._chk(self._lib.stattn_set_use_noise(self._h, float(v)))
+
+    def set_seed(self, seed):
+        self._chk(self._lib.stattn_set_seed(self._h, int(seed)))
+
+    def set_dropout_masks(self, dp, d1, d2):
+        if dp is None:
+            self._chk(self._lib.stattn_set_dropout_masks(self._h, None, None, None, 0, 0))
+            return
+        t, m = dp.shape[0], dp.shape[1]
+        dp = _f32(dp, "dp", (t, m, 3 * self.D)); d1 = _f32(d1, "d1", (t, m, self.D)); d2 = _f32(d2, "d2", (t, m, self.E))
+        self._chk(self._lib.stattn_set_dropout_masks(self._h, _fp(dp), _fp(d1), _fp(d2), t, m))
+
+    # -- sampler (model_attention.py:791-795, 845-848)
+    def f_init(self, ctxg, ctxg_mask):
+        ctxg = _f32(ctxg, "ctxg")
+        if ctxg.ndim != 2 or ctxg.shape[1] != self.D:
+            raise ValueError("ctxg must be (T, %d)" % self.D)
+        T = ctxg.shape[0]
+        ctxg_mask = _f32(ctxg_mask, "ctxg_mask", (T,))
+        h0 = np.empty((self.D,), np.float32); c0 = np.empty((self.D,), np.float32)
+        self._chk(self._lib.stattn_f_init(self._h, _fp(ctxg), _fp(ctxg_mask), T, _fp(h0), _fp(c0)))
+        return [ctxg, h0, c0]
+
+    def f_next(self, x, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask, h, c, extras=False):
+        x = _i64(x, "x")
+        if x.ndim != 1:
+            raise ValueError("x must be a vector")
+        m = x.shape[0]
+        ctxg = _f32(ctxg, "ctxg"); ctxl = _f32(ctxl, "ctxl"); ctxm = _f32(ctxm, "ctxm")
+        if ctxl.ndim != 3 or ctxl.shape[2] != self.Fl:
+            raise ValueError("ctxl must be (T, K, %d)" % self.Fl)
+        T, K = ctxl.shape[0], ctxl.shape[1]
+        if ctxg.shape != (T, self.D) or ctxm.shape != (T, self.Fm):
+            raise ValueError("ctxg/ctxm shapes do not match ctxl's T")
+        h = _f32(h, "init_state", (m, self.D)); c = _f32(c, "init_memory", (m, self.D))
+        probs = np.empty((m, self.V), np.float32); sample = np.empty((m,), np.int64)
+        ho = np.empty((m, self.D), np.float32); co = np.empty((m, self.D), np.float32)
+        al = ag = am = alt = lg = None
+        if extras:
+            al = np.empty((m, T, K), np.float32); ag = np.empty((m, T), np.float32)
+            am = np.empty((m, T), np.float32); alt = np.empty((m, T), np.float32)
+            lg = np.empty((m, self.V), np.float32)
+        self._chk(self._lib.stattn_f_next(
+            self._h, x.ctypes.data_as(_I64), m, _fp(ctxg), None, _fp(ctxl), None, _fp(ctxm), None, T, K,
+            _fp(h), _fp(c), _fp(probs), sample.ctypes.data_as(_I64), _fp(ho), _fp(co),
+            _fp(al), _fp(ag), _fp(am), _fp(alt), _fp(lg)))
+        out = [probs, sample, ho, co]
+        if extras:
+            return out, dict(alphal=al, alphag=ag, alpham=am, alphalt=alt, logit=lg)
+        return out
+
+    def invalidate_ctx_cache(self):
+        self._chk(self._lib.stattn_invalidate_ctx_cache(self._h))
+
+    # -- training graph
+    def set_batch(self, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
+        x = _i64(x, "x")
+        if x.ndim != 2:
+            raise ValueError("x must be (t, m)")
+        t, m = x.shape
+        mask = _f32(mask, "mask", (t, m))
+        ctxl = _f32(ctxl, "ctxl")
+        if ctxl.ndim != 4 or ctxl.shape[0] != m or ctxl.shape[3] != self.Fl:
+            raise ValueError("ctxl must be (m, T, K, %d)" % self.Fl)
+        T, K = ctxl.shape[1], ctxl.shape[2]
+        ctxg = _f32(ctxg, "ctxg", (m, T, self.D)); mask_ctxg = _f32(mask_ctxg, "mask_ctxg", (m, T))
+        ctxm = _f32(ctxm, "ctxm", (m, T, self.Fm))
+        self._chk(self._lib.stattn_set_batch(self._h, x.ctypes.data_as(_I64), _fp(mask), t, m, _fp(ctxg), _fp(mask_ctxg),
+                                             _fp(ctxl), None, _fp(ctxm), None, T, K))
+        self._batch = (t, m, T, K)
+
+    def forward_train(self):
+        self._chk(self._lib.stattn_forward_train(self._h))
+
+    def get_forward(self, probs=True, alphas=True, logits=False):
+        t, m, T, K = self._batch
+        cost = np.empty((m,), np.float32)
+        pr = np.empty((t * m, self.V), np.float32) if probs else None
+        lg = np.empty((t * m, self.V), np.float32) if logits else None
+        al = np.empty((t, m, T, K), np.float32) if alphas else None
+        ag = np.empty((t, m, T), np.float32) if alphas else None
+        am = np.empty((t, m, T), np.float32) if alphas else None
+        alt = np.empty((t, m, T), np.float32) if alphas else None
+        self._chk(self._lib.stattn_get_forward(self._h, _fp(cost), _fp(pr), _fp(al), _fp(ag), _fp(am), _fp(alt), _fp(lg)))
+        return dict(cost=cost, probs=pr, alphal=al, alphag=ag, alpham=am, alphalt=alt, logit=lg)
+
+    def get_states(self):
+        t, m, T, K = self._batch
+        hs = np.empty((t, m, self.D), np.float32); cs = np.empty((t, m, self.D), np.float32)
+        ctx = np.empty((t, m, self.D), np.float32)
+        self._chk(self._lib.stattn_get_states(self._h, _fp(hs), _fp(cs), _fp(ctx)))
+        return dict(h=hs, c=cs, ctx=ctx)
+
+    # -- kernel-level entry points
+    def gemm(self, A, B, bias=None, add=None, act=0, alpha=1.0, kind=0, transA=False, transB=False):
+        A = _f32(A, "A"); B = _f32(B, "B")
+        K, M = (A.shape if transA else A.shape[::-1])
+        N = B.shape[0] if transB else B.shape[1]
+        if (B.shape[1] if transB else B.shape[0]) != K:
+            raise ValueError("inner dimensions differ")
+        out = np.empty((M, N), np.float32)
+        bias = None if bias is None else _f32(bias, "bias", (N,))
+        add = None if add is None else _f32(add, "add", (M, N))
+        self._chk(self._lib.stattn_dbg_gemm(self._h, int(kind), int(transA), int(transB), M, N, K, float(alpha),
+                                            _fp(A), _fp(B), _fp(bias), _fp(add), int(act), _fp(out)))
+        return out
+
+    def time_gemm(self, M, N, K, iters=20, transA=False, transB=False):
+        ms = C.c_float()
+        self._chk(self._lib.stattn_dbg_time_gemm(self._h, int(transA), int(transB), M, N, K, iters, C.byref(ms)))
+        return ms.value
+
+    def set_profiling(self, on):
+        self._chk(self._lib.stattn_set_profiling(self._h, int(bool(on))))
+
+    def kernel_ms(self):
+        out = OrderedDict()
+        for i, name in enumerate(KERNEL_CLASSES):
+            ms = C.c_float(); n = C.c_int()
+            self._chk(self._lib.stattn_get_kernel_ms(self._h, i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
+        return out

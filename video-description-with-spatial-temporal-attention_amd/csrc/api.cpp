@@ -1,0 +1,1006 @@
+// C ABI of libstattn.so (see include/stattn.h).  Host-side orchestration only: parameter
+// store, batch staging, the per-timestep launch sequence, and result copies.  All arithmetic
+// lives in the hand-written gfx950 kernels (gemm.hip, skinny.hip, attn.hip, misc.hip).
+#include "../../include/stattn.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace stattn;
+
+namespace {
+
+std::string g_create_error;
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int64_t dims[2];
+    size_t off;     // offset in the flat buffer (floats)
+    int ld;         // leading dimension (floats) of the device layout
+    size_t count;   // logical element count
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_COUNT };
+
+struct Weights {   // device pointers into the flat parameter buffer
+    float *Wemb, *ff_state_W, *ff_state_b, *ff_memory_W, *ff_memory_b, *ff_local_W, *ff_local_b,
+          *ff_motion_W, *ff_motion_b, *W, *U, *b, *Wc, *Wcg, *Wcm, *Wclt, *Wdg, *Wdm, *Wdlt, *bg, *bm, *blt,
+          *Wcl, *Wdl, *bl, *Ug, *cg, *Um, *cm, *Ult, *clt, *Ul, *cl, *W_sel, *b_sel,
+          *Wl1, *bl1, *Wl2, *bl2, *Wo, *bo;
+};
+
+}  // namespace
+
+struct stattn_handle {
+    stattn_options opt{};
+    int D = 0, E = 0, V = 0, Vp = 0, Fl = 0, Fm = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> pindex;
+    float* d_params = nullptr;
+    float* d_grads = nullptr;
+    size_t nflat = 0;
+    Weights w{};
+
+    float use_noise = 0.f;
+    uint64_t seed = 1234, draw = 0;
+
+    std::map<std::string, DevBuf> bufs;
+
+    // training batch
+    int t = 0, m = 0, T = 0, K = 0;
+    bool have_batch = false, have_fwd = false;
+    bool masks_user = false;
+    int masks_t = 0, masks_m = 0;        // shape the mask buffers currently hold
+    int masks_state = 0;                 // 0 invalid, 1 holds eval (0.5), 2 holds a random draw
+
+    // sampler: cached projected video
+    const void *ck_g = nullptr, *ck_l = nullptr, *ck_m = nullptr;
+    int ck_T = 0, ck_K = 0;
+    double ck_fp = 0.0;
+    bool ck_valid = false;
+    uint64_t host_rng = 0x853c49e6748fea9bull;
+
+    // profiling
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int cls; };
+    std::vector<EvPair> ev_used;
+    std::vector<hipEvent_t> ev_pool;
+    double k_ms[KC_COUNT] = {0};
+    int k_n[KC_COUNT] = {0};
+};
+
+namespace {
+
+int fail(stattn_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(h, STATTN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define CHK(expr) do { int rc_ = (expr); if (rc_ != STATTN_OK) return rc_; } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+void add_param(stattn_handle* h, const char* name, int ndim, int64_t d0, int64_t d1, int ld = 0) {
+    ParamInfo p;
+    p.name = name; p.ndim = ndim; p.dims[0] = d0; p.dims[1] = d1;
+    p.count = ndim == 0 ? 1 : (ndim == 1 ? (size_t)d0 : (size_t)d0 * d1);
+    p.ld = (ndim == 2) ? (ld ? ld : (int)d1) : (ld ? ld : (ndim == 1 ? (int)d0 : 1));
+    const size_t padded = ndim == 2 ? (size_t)d0 * p.ld : (size_t)p.ld;
+    p.off = h->nflat;
+    h->nflat += align_up(padded, 64);   // every array starts 256-byte aligned
+    h->pindex[name] = (int)h->params.size();
+    h->params.push_back(p);
+}
+
+float* pptr(stattn_handle* h, const char* name) {
+    auto it = h->pindex.find(name);
+    return it == h->pindex.end() ? nullptr : h->d_params + h->params[it->second].off;
+}
+
+// dict order = init_params order (model_attention.py:518-581, 180-282)
+void build_param_table(stattn_handle* h) {
+    const int D = h->D, E = h->E, V = h->V, Vp = h->Vp;
+    add_param(h, "Wemb", 2, V, E);
+    add_param(h, "ff_state_W", 2, D, D);  add_param(h, "ff_state_b", 1, D, 0);
+    add_param(h, "ff_memory_W", 2, D, D); add_param(h, "ff_memory_b", 1, D, 0);
+    add_param(h, "ff_local_W", 2, h->Fl, D);  add_param(h, "ff_local_b", 1, D, 0);
+    add_param(h, "ff_motion_W", 2, h->Fm, D); add_param(h, "ff_motion_b", 1, D, 0);
+    add_param(h, "decoder_W", 2, E, 4 * D);
+    add_param(h, "decoder_U", 2, D, 4 * D);
+    add_param(h, "decoder_b", 1, 4 * D, 0);
+    add_param(h, "decoder_Wc", 2, D, 4 * D);
+    add_param(h, "decoder_Wcg_att", 2, D, D);
+    add_param(h, "decoder_Wcm_att", 2, D, D);
+    add_param(h, "decoder_Wclt_att", 2, D, D);
+    add_param(h, "decoder_Wdg_att", 2, D, D);
+    add_param(h, "decoder_Wdm_att", 2, D, D);
+    add_param(h, "decoder_Wdlt_att", 2, D, D);
+    add_param(h, "decoder_bg_att", 1, D, 0);
+    add_param(h, "decoder_bm_att", 1, D, 0);
+    add_param(h, "decoder_blt_att", 1, D, 0);
+    add_param(h, "decoder_Wcl_att", 2, D, D);
+    add_param(h, "decoder_Wdl_att", 2, D, D);
+    add_param(h, "decoder_bl_att", 1, D, 0);
+    add_param(h, "decoder_Ug_att", 2, D, 1);  add_param(h, "decoder_cg_att", 1, 1, 0);
+    add_param(h, "decoder_Um_att", 2, D, 1);  add_param(h, "decoder_cm_att", 1, 1, 0);
+    add_param(h, "decoder_Ult_att", 2, D, 1); add_param(h, "decoder_clt_att", 1, 1, 0);
+    add_param(h, "decoder_Ul_att", 2, D, 1);  add_param(h, "decoder_cl_att", 1, 1, 0);
+    if (h->opt.selector) {
+        add_param(h, "decoder_W_sel", 2, D, 1);
+        add_param(h, "decoder_b_sel", 0, 0, 0);
+    }
+    add_param(h, "ff_logit_lstm_W", 2, D, E); add_param(h, "ff_logit_lstm_b", 1, E, 0);
+    if (h->opt.ctx2out) {
+        add_param(h, "ff_logit_ctxglm_W", 2, D, E); add_param(h, "ff_logit_ctxglm_b", 1, E, 0);
+    }
+    // vocabulary projection: device layout padded to Vp = roundup(V, 128) columns (zeros)
+    add_param(h, "ff_logit_W", 2, E, V, Vp);
+    add_param(h, "ff_logit_b", 1, V, 0, Vp);
+}
+
+void bind_weights(stattn_handle* h) {
+    Weights& w = h->w;
+    w.Wemb = pptr(h, "Wemb");
+    w.ff_state_W = pptr(h, "ff_state_W"); w.ff_state_b = pptr(h, "ff_state_b");
+    w.ff_memory_W = pptr(h, "ff_memory_W"); w.ff_memory_b = pptr(h, "ff_memory_b");
+    w.ff_local_W = pptr(h, "ff_local_W"); w.ff_local_b = pptr(h, "ff_local_b");
+    w.ff_motion_W = pptr(h, "ff_motion_W"); w.ff_motion_b = pptr(h, "ff_motion_b");
+    w.W = pptr(h, "decoder_W"); w.U = pptr(h, "decoder_U"); w.b = pptr(h, "decoder_b"); w.Wc = pptr(h, "decoder_Wc");
+    w.Wcg = pptr(h, "decoder_Wcg_att"); w.Wcm = pptr(h, "decoder_Wcm_att"); w.Wclt = pptr(h, "decoder_Wclt_att");
+    w.Wdg = pptr(h, "decoder_Wdg_att"); w.Wdm = pptr(h, "decoder_Wdm_att"); w.Wdlt = pptr(h, "decoder_Wdlt_att");
+    w.bg = pptr(h, "decoder_bg_att"); w.bm = pptr(h, "decoder_bm_att"); w.blt = pptr(h, "decoder_blt_att");
+    w.Wcl = pptr(h, "decoder_Wcl_att"); w.Wdl = pptr(h, "decoder_Wdl_att"); w.bl = pptr(h, "decoder_bl_att");
+    w.Ug = pptr(h, "decoder_Ug_att"); w.cg = pptr(h, "decoder_cg_att");
+    w.Um = pptr(h, "decoder_Um_att"); w.cm = pptr(h, "decoder_cm_att");
+    w.Ult = pptr(h, "decoder_Ult_att"); w.clt = pptr(h, "decoder_clt_att");
+    w.Ul = pptr(h, "decoder_Ul_att"); w.cl = pptr(h, "decoder_cl_att");
+    w.W_sel = pptr(h, "decoder_W_sel"); w.b_sel = pptr(h, "decoder_b_sel");
+    w.Wl1 = pptr(h, "ff_logit_lstm_W"); w.bl1 = pptr(h, "ff_logit_lstm_b");
+    w.Wl2 = pptr(h, "ff_logit_ctxglm_W"); w.bl2 = pptr(h, "ff_logit_ctxglm_b");
+    w.Wo = pptr(h, "ff_logit_W"); w.bo = pptr(h, "ff_logit_b");
+}
+
+int getbuf(stattn_handle* h, const char* name, size_t nbytes, void** out) {
+    DevBuf& b = h->bufs[name];
+    HIPCHK(h, b.ensure(nbytes ? nbytes : 4));
+    *out = b.p;
+    return STATTN_OK;
+}
+template <class T>
+int getbuf_t(stattn_handle* h, const char* name, size_t n, T** out) {
+    void* p = nullptr;
+    CHK(getbuf(h, name, n * sizeof(T), &p));
+    *out = static_cast<T*>(p);
+    return STATTN_OK;
+}
+float* findbuf(stattn_handle* h, const char* name) {
+    auto it = h->bufs.find(name);
+    return it == h->bufs.end() ? nullptr : static_cast<float*>(it->second.p);
+}
+
+// ---- profiling helpers -------------------------------------------------------------
+struct Prof {
+    stattn_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr; bool on;
+    Prof(stattn_handle* h_, int c) : h(h_), cls(c), on(h_->profiling) {
+        if (!on) return;
+        auto get = [&]() { hipEvent_t e; if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
+        a = get(); b = get();
+        (void)hipEventRecord(a, h->stream);
+    }
+    ~Prof() {
+        if (!on) return;
+        (void)hipEventRecord(b, h->stream);
+        h->ev_used.push_back({a, b, cls});
+    }
+};
+
+void prof_collect(stattn_handle* h) {
+    if (h->ev_used.empty()) return;
+    (void)hipStreamSynchronize(h->stream);
+    for (auto& e : h->ev_used) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, e.a, e.b) == hipSuccess) { h->k_ms[e.cls] += ms; h->k_n[e.cls] += 1; }
+        h->ev_pool.push_back(e.a); h->ev_pool.push_back(e.b);
+    }
+    h->ev_used.clear();
+}
+
+// ---- shared building blocks ---------------------------------------------------------
+// Project raw features of `nv` videos to the decoder's context tensors (the part f_next
+// recomputes on every call in the reference, model_attention.py:782-785 + 322-326).
+struct CtxPtrs { float *G, *L, *Mo, *PG, *PL, *PM, *LW; };
+
+int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
+                    const CtxPtrs& c) {
+    const int D = h->D;
+    const Weights& w = h->w;
+    Prof pr(h, KC_PROLOGUE);
+    GemmArgs g;
+    // L = tanh(ctxl . ff_local_W + b)  (:664-665 / :782-783)
+    gemm_defaults(g);
+    g.A = ctxl; g.lda = h->Fl; g.B = w.ff_local_W; g.ldb = D; g.C = c.L; g.ldc = D;
+    g.M = nv * T * K; g.N = D; g.K = h->Fl; g.bias = w.ff_local_b; g.act = 1;
+    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    // M = tanh(ctxm . ff_motion_W + b) (:666-667 / :784-785)
+    gemm_defaults(g);
+    g.A = ctxm; g.lda = h->Fm; g.B = w.ff_motion_W; g.ldb = D; g.C = c.Mo; g.ldc = D;
+    g.M = nv * T; g.N = D; g.K = h->Fm; g.bias = w.ff_motion_b; g.act = 1;
+    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    // pctxg_, pctxl_, pctxm_ (:322-326)
+    gemm_defaults(g);
+    g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
+    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    gemm_defaults(g);
+    g.A = c.L; g.lda = D; g.B = w.Wcl; g.ldb = D; g.C = c.PL; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D; g.bias = w.bl;
+    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    gemm_defaults(g);
+    g.A = c.Mo; g.lda = D; g.B = w.Wcm; g.ldb = D; g.C = c.PM; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bm;
+    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    if (h->opt.lt_mode == 1) {   // LW = L . Wclt  (the :416 projection hoisted out of the time loop)
+        gemm_defaults(g);
+        g.A = c.L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = c.LW; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D;
+        HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    }
+    return STATTN_OK;
+}
+
+// mean of the global features + tanh(ff_state), tanh(ff_memory)  (:649, 657-660 / :766, 776-779)
+int init_state(stattn_handle* h, int nv, int T, const float* G, const float* maskG, float* mean, float* h0, float* c0) {
+    const int D = h->D;
+    HIPCHK(h, launch_ctx_mean(h->stream, G, maskG, mean, nv, T, D));
+    SkArgs a{};
+    a.M = nv; a.nseg = 2;
+    for (int i = 0; i < 2; ++i) {
+        SkSeg& s = a.seg[i];
+        skinny_seg_defaults(s);
+        s.npairs = 1;
+        s.p[0] = SkPair{mean, i == 0 ? h->w.ff_state_W : h->w.ff_memory_W, D, D, D};
+        s.C = i == 0 ? h0 : c0; s.ldc = D; s.N = D;
+        s.bias = i == 0 ? h->w.ff_state_b : h->w.ff_memory_b;
+        s.act = 1;
+    }
+    HIPCHK(h, launch_skinny(h->stream, a));
+    return STATTN_OK;
+}
+
+struct StepIO {
+    int M, T, K;
+    CtxPtrs c; const int* vid;
+    const float* h_prev; const float* c_prev;
+    float *sproj, *preh;             // [M,4D] each
+    const float* xproj;              // [M,4D] (training: emb.W + b) or null
+    const float* emb;                // [M,E]  (sampling: third LSTM pair) or null
+    const float* dp; const float* mask; const float* d1;
+    float *alphal, *CL, *eg, *em, *elt, *plt, *alphag, *alpham, *alphalt, *csum, *sel, *ctx;
+    float *h_out, *c_out, *gates, *hd;
+};
+
+// one decoder timestep: _step, model_attention.py:366-459
+int run_step(stattn_handle* h, const StepIO& io) {
+    const int D = h->D, E = h->E;
+    const Weights& w = h->w;
+    {   // state projections: h.[Wdl | Wdg | Wdm | Wdlt] -> sproj, h.U (+ x_) -> preh   (:371, 389, 402, 415, 437-438)
+        Prof pr(h, KC_HPROJ);
+        SkArgs a{};
+        a.M = io.M; a.nseg = 5;
+        const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
+        for (int i = 0; i < 4; ++i) {
+            SkSeg& s = a.seg[i];
+            skinny_seg_defaults(s);
+            s.npairs = 1; s.p[0] = SkPair{io.h_prev, Wd[i], D, D, D};
+            s.C = io.sproj + (size_t)i * D; s.ldc = 4 * D; s.N = D;
+        }
+        SkSeg& s = a.seg[4];
+        skinny_seg_defaults(s);
+        s.npairs = 1; s.p[0] = SkPair{io.h_prev, w.U, D, 4 * D, D};
+        s.C = io.preh; s.ldc = 4 * D; s.N = 4 * D;
+        if (io.xproj) { s.add = io.xproj; s.ldadd = 4 * D; }
+        HIPCHK(h, launch_skinny(h->stream, a));
+    }
+    {   // spatial attention + frame scores (:371-383, 389-397, 402-410, and 415-424 in lt_mode 1)
+        Prof pr(h, KC_SPATIAL);
+        SpatialArgs a{};
+        a.PL = io.c.PL; a.L = io.c.L; a.LW = h->opt.lt_mode == 1 ? io.c.LW : nullptr;
+        a.PG = io.c.PG; a.PM = io.c.PM; a.vid = io.vid;
+        a.sproj = io.sproj; a.ldsp = 4 * D;
+        a.Ul = w.Ul; a.cl = w.cl; a.Ug = w.Ug; a.cg = w.cg; a.Um = w.Um; a.cm = w.cm;
+        a.Ult = w.Ult; a.clt = w.clt; a.blt = w.blt;
+        a.alphal = io.alphal; a.CL = io.CL; a.eg = io.eg; a.em = io.em; a.elt = io.elt;
+        a.M = io.M; a.T = io.T; a.K = io.K; a.D = D;
+        HIPCHK(h, launch_spatial(h->stream, a));
+    }
+    if (h->opt.lt_mode == 0) {   // pctxlt = CL.Wclt + blt + pstatelt, tanh, . Ult  (:416-422) as one MFMA GEMM
+        Prof pr(h, KC_LTGEMM);
+        GemmArgs g;
+        gemm_defaults(g);
+        g.A = io.CL; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = io.plt; g.ldc = D;
+        g.M = io.M * io.T; g.N = D; g.K = D; g.bias = w.blt;
+        g.rowadd = io.sproj + 3 * (size_t)D; g.ldrow = 4 * D; g.rowgroup = io.T; g.act = 1;
+        HIPCHK(h, launch_gemm(h->stream, g, false, false));
+        HIPCHK(h, launch_rowdot(h->stream, io.plt, D, w.Ult, w.clt, io.elt, io.M * io.T, D));
+    }
+    {   // three temporal softmaxes, weighted sums, sum-fusion, selector gate (:398-399, 411-412, 425-435)
+        Prof pr(h, KC_TEMPORAL);
+        TemporalArgs a{};
+        a.eg = io.eg; a.em = io.em; a.elt = io.elt; a.G = io.c.G; a.Mo = io.c.Mo; a.vid = io.vid; a.CL = io.CL;
+        a.h_prev = io.h_prev; a.W_sel = h->opt.selector ? w.W_sel : nullptr; a.b_sel = w.b_sel;
+        a.alphag = io.alphag; a.alpham = io.alpham; a.alphalt = io.alphalt;
+        a.csum = io.csum; a.sel = io.sel; a.ctx = io.ctx;
+        a.M = io.M; a.T = io.T; a.D = D;
+        HIPCHK(h, launch_temporal(h->stream, a));
+    }
+    {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457)
+        Prof pr(h, KC_LSTM);
+        LstmArgs a{};
+        a.npairs = 1; a.p[0] = SkPair{io.ctx, w.Wc, D, 4 * D, D};
+        if (io.emb) { a.p[1] = SkPair{io.emb, w.W, E, 4 * D, E}; a.npairs = 2; a.bias = w.b; }
+        a.pre_add = io.preh; a.ldpre = 4 * D;
+        a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
+        a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
+        a.d1 = io.d1; a.ldd1 = D; a.d1_scalar = 0.5f; a.hd_out = io.hd;
+        a.M = io.M; a.D = D;
+        HIPCHK(h, launch_lstm(h->stream, a));
+    }
+    return STATTN_OK;
+}
+
+// dropout multiplier tensors dp (t,m,3D), d1 (t,m,D), d2 (t,m,E)
+int prepare_masks(stattn_handle* h, int t, int m, float** dp, float** d1, float** d2) {
+    const size_t n_dp = (size_t)t * m * 3 * h->D, n_d1 = (size_t)t * m * h->D, n_d2 = (size_t)t * m * h->E;
+    CHK(getbuf_t(h, "dp", n_dp, dp));
+    CHK(getbuf_t(h, "d1", n_d1, d1));
+    CHK(getbuf_t(h, "d2", n_d2, d2));
+    if (h->masks_user) {
+        if (h->masks_t != t || h->masks_m != m)
+            return fail(h, STATTN_ESTATE, "dropout masks were supplied for (t=%d,m=%d) but the batch is (t=%d,m=%d)",
+                        h->masks_t, h->masks_m, t, m);
+        return STATTN_OK;
+    }
+    if (h->use_noise != 0.f) {   // trng.binomial(p=0.5) (:474-477, common.py:94-99); own counter-based generator
+        HIPCHK(h, launch_bernoulli(h->stream, *dp, n_dp, h->seed, 3 * h->draw + 0));
+        HIPCHK(h, launch_bernoulli(h->stream, *d1, n_d1, h->seed, 3 * h->draw + 1));
+        HIPCHK(h, launch_bernoulli(h->stream, *d2, n_d2, h->seed, 3 * h->draw + 2));
+        h->draw++;
+        h->masks_state = 2; h->masks_t = t; h->masks_m = m;
+    } else if (!(h->masks_state == 1 && h->masks_t >= t && h->masks_m >= m && h->masks_t * h->masks_m >= t * m)) {
+        HIPCHK(h, launch_fill(h->stream, *dp, 0.5f, n_dp));   // use_noise = 0: the constant 0.5 (:472, :477)
+        HIPCHK(h, launch_fill(h->stream, *d1, 0.5f, n_d1));
+        HIPCHK(h, launch_fill(h->stream, *d2, 0.5f, n_d2));
+        h->masks_state = 1; h->masks_t = t; h->masks_m = m;
+    }
+    return STATTN_OK;
+}
+
+double fingerprint(const float* p, size_t n) {   // cheap content fingerprint: <= 4096 strided samples
+    if (!p || !n) return 0.0;
+    const size_t step = n > 4096 ? n / 4096 : 1;
+    double s = 0.0;
+    for (size_t i = 0; i < n; i += step) s = s * 1.0000001 + (double)p[i] * (double)((i % 251) + 1);
+    return s + (double)p[n - 1];
+}
+
+}  // namespace
+
+// =====================================================================================
+extern "C" {
+
+const char* stattn_version(void) { return "stattn 0.1 (gfx950)"; }
+
+const char* stattn_last_error(const stattn_handle* h) { return h ? h->err.c_str() : g_create_error.c_str(); }
+
+int stattn_create(const stattn_options* o, int device, void* stream, stattn_handle** out) {
+    if (!o || !out) return fail(nullptr, STATTN_EINVAL, "null argument");
+    *out = nullptr;
+    if (o->dim <= 0 || o->dim % 64) return fail(nullptr, STATTN_EINVAL, "dim must be a positive multiple of 64 (got %d)", o->dim);
+    if (o->dim_word <= 0 || o->dim_word % 64) return fail(nullptr, STATTN_EINVAL, "dim_word must be a positive multiple of 64 (got %d)", o->dim_word);
+    if (o->n_words < 2) return fail(nullptr, STATTN_EINVAL, "n_words must be >= 2");
+    if (o->ctxg_dim != o->dim)
+        return fail(nullptr, STATTN_EINVAL, "ctxg_dim (%d) must equal dim (%d): the reference graph has no ff_global layer "
+                    "(model_attention.py:553-554, 661-662)", o->ctxg_dim, o->dim);
+    if (o->ctxl_dim <= 0 || o->ctxl_dim % 32 || o->ctxm_dim <= 0 || o->ctxm_dim % 32)
+        return fail(nullptr, STATTN_EINVAL, "ctxl_dim and ctxm_dim must be positive multiples of 32");
+    if (!o->use_dropout)
+        return fail(nullptr, STATTN_EINVAL, "use_dropout must be true: the reference's False branch is broken (model_attention.py:479-481)");
+    if (o->lt_mode != 0 && o->lt_mode != 1) return fail(nullptr, STATTN_EINVAL, "lt_mode must be 0 or 1");
+
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, STATTN_EHIP, "no HIP device available (%s): libstattn has no CPU fallback",
+                    e == hipSuccess ? "device count 0" : hipGetErrorString(e));
+    if (device < 0 || device >= ndev) return fail(nullptr, STATTN_EINVAL, "device %d out of range (0..%d)", device, ndev - 1);
+    e = hipSetDevice(device);
+    if (e != hipSuccess) return fail(nullptr, STATTN_EHIP, "hipSetDevice: %s", hipGetErrorString(e));
+
+    stattn_handle* h = new stattn_handle();
+    h->opt = *o;
+    h->D = o->dim; h->E = o->dim_word; h->V = o->n_words; h->Vp = (int)align_up((size_t)o->n_words, 128);
+    h->Fl = o->ctxl_dim; h->Fm = o->ctxm_dim; h->device = device;
+    if (stream) { h->stream = static_cast<hipStream_t>(stream); h->own_stream = false; }
+    else {
+        e = hipStreamCreateWithFlags(&h->stream, hipStreamNonBlocking);
+        if (e != hipSuccess) { delete h; return fail(nullptr, STATTN_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+        h->own_stream = true;
+    }
+    build_param_table(h);
+    e = hipMalloc((void**)&h->d_params, h->nflat * sizeof(float));
+    if (e == hipSuccess) e = hipMalloc((void**)&h->d_grads, h->nflat * sizeof(float));
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_params, 0, h->nflat * sizeof(float), h->stream);
+    if (e == hipSuccess) e = hipMemsetAsync(h->d_grads, 0, h->nflat * sizeof(float), h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    if (e != hipSuccess) {
+        int rc = fail(nullptr, STATTN_EHIP, "parameter allocation (%zu floats): %s", h->nflat, hipGetErrorString(e));
+        stattn_destroy(h);
+        return rc;
+    }
+    bind_weights(h);
+    *out = h;
+    return STATTN_OK;
+}
+
+void stattn_destroy(stattn_handle* h) {
+    if (!h) return;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    for (auto& kv : h->bufs) kv.second.release();
+    for (auto& e : h->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->d_params) (void)hipFree(h->d_params);
+    if (h->d_grads) (void)hipFree(h->d_grads);
+    if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+}
+
+int stattn_sync(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return STATTN_OK;
+}
+
+int stattn_param_count(const stattn_handle* h) { return h ? (int)h->params.size() : 0; }
+const char* stattn_param_name(const stattn_handle* h, int i) {
+    return (h && i >= 0 && i < (int)h->params.size()) ? h->params[i].name.c_str() : nullptr;
+}
+int stattn_param_shape(const stattn_handle* h, int i, int64_t dims[2], int* ndim) {
+    if (!h || i < 0 || i >= (int)h->params.size() || !dims || !ndim) return STATTN_EINVAL;
+    dims[0] = h->params[i].dims[0]; dims[1] = h->params[i].dims[1]; *ndim = h->params[i].ndim;
+    return STATTN_OK;
+}
+
+static int param_copy(stattn_handle* h, float* base, const char* name, float* host_dst, const float* host_src, size_t n) {
+    if (!h || !name) return STATTN_EINVAL;
+    auto it = h->pindex.find(name);
+    if (it == h->pindex.end()) return fail(h, STATTN_ENOTFOUND, "unknown parameter '%s'", name);
+    const ParamInfo& p = h->params[it->second];
+    if (n != p.count) return fail(h, STATTN_EINVAL, "parameter '%s' has %zu elements, got %zu", name, p.count, n);
+    HIPCHK(h, hipSetDevice(h->device));
+    float* dev = base + p.off;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    if (p.ndim == 2 && p.ld != (int)p.dims[1]) {   // padded rows (ff_logit_W)
+        const size_t wbytes = (size_t)p.dims[1] * sizeof(float);
+        if (host_src) HIPCHK(h, hipMemcpy2D(dev, (size_t)p.ld * sizeof(float), host_src, wbytes, wbytes, (size_t)p.dims[0], hipMemcpyHostToDevice));
+        else HIPCHK(h, hipMemcpy2D(host_dst, wbytes, dev, (size_t)p.ld * sizeof(float), wbytes, (size_t)p.dims[0], hipMemcpyDeviceToHost));
+    } else {
+        if (host_src) HIPCHK(h, hipMemcpy(dev, host_src, n * sizeof(float), hipMemcpyHostToDevice));
+        else HIPCHK(h, hipMemcpy(host_dst, dev, n * sizeof(float), hipMemcpyDeviceToHost));
+    }
+    return STATTN_OK;
+}
+
+int stattn_set_param(stattn_handle* h, const char* name, const float* src, size_t n) {
+    if (!src) return STATTN_EINVAL;
+    int rc = param_copy(h, h ? h->d_params : nullptr, name, nullptr, src, n);
+    if (rc == STATTN_OK) { h->ck_valid = false; h->have_fwd = false; }
+    return rc;
+}
+int stattn_get_param(stattn_handle* h, const char* name, float* dst, size_t n) {
+    if (!dst) return STATTN_EINVAL;
+    return param_copy(h, h ? h->d_params : nullptr, name, dst, nullptr, n);
+}
+int stattn_get_grad(stattn_handle* h, const char* name, float* dst, size_t n) {
+    if (!dst) return STATTN_EINVAL;
+    return param_copy(h, h ? h->d_grads : nullptr, name, dst, nullptr, n);
+}
+int stattn_param_buffer_dev(stattn_handle* h, void** p, size_t* n) {
+    if (!h || !p || !n) return STATTN_EINVAL;
+    *p = h->d_params; *n = h->nflat;
+    return STATTN_OK;
+}
+int stattn_grad_buffer_dev(stattn_handle* h, void** p, size_t* n) {
+    if (!h || !p || !n) return STATTN_EINVAL;
+    *p = h->d_grads; *n = h->nflat;
+    return STATTN_OK;
+}
+
+int stattn_set_use_noise(stattn_handle* h, float v) {
+    if (!h) return STATTN_EINVAL;
+    if ((v != 0.f) != (h->use_noise != 0.f)) h->masks_state = 0;
+    h->use_noise = v;
+    return STATTN_OK;
+}
+int stattn_set_seed(stattn_handle* h, uint64_t seed) {
+    if (!h) return STATTN_EINVAL;
+    h->seed = seed; h->draw = 0; h->host_rng = seed * 0x9E3779B97F4A7C15ull + 0x853c49e6748fea9bull;
+    return STATTN_OK;
+}
+
+int stattn_set_dropout_masks(stattn_handle* h, const float* dp, const float* d1, const float* d2, int t, int m) {
+    if (!h) return STATTN_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!dp || !d1 || !d2) { h->masks_user = false; h->masks_state = 0; return STATTN_OK; }
+    if (t <= 0 || m <= 0) return fail(h, STATTN_EINVAL, "bad mask shape");
+    float *b_dp, *b_d1, *b_d2;
+    const size_t n_dp = (size_t)t * m * 3 * h->D, n_d1 = (size_t)t * m * h->D, n_d2 = (size_t)t * m * h->E;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(getbuf_t(h, "dp", n_dp, &b_dp));
+    CHK(getbuf_t(h, "d1", n_d1, &b_d1));
+    CHK(getbuf_t(h, "d2", n_d2, &b_d2));
+    HIPCHK(h, hipMemcpy(b_dp, dp, n_dp * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(b_d1, d1, n_d1 * sizeof(float), hipMemcpyHostToDevice));
+    HIPCHK(h, hipMemcpy(b_d2, d2, n_d2 * sizeof(float), hipMemcpyHostToDevice));
+    h->masks_user = true; h->masks_t = t; h->masks_m = m; h->masks_state = 0;
+    return STATTN_OK;
+}
+
+// ---- sampler ------------------------------------------------------------------------
+int stattn_f_init(stattn_handle* h, const float* ctxg, const float* ctxg_mask, int T, float* out_h0, float* out_c0) {
+    if (!h || !ctxg || !ctxg_mask || T <= 0 || !out_h0 || !out_c0) return fail(h, STATTN_EINVAL, "f_init: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int D = h->D;
+    float *G, *mk, *mean, *h0, *c0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(getbuf_t(h, "fi_G", (size_t)T * D, &G));
+    CHK(getbuf_t(h, "fi_mask", (size_t)T, &mk));
+    CHK(getbuf_t(h, "fi_mean", (size_t)D, &mean));
+    CHK(getbuf_t(h, "fi_h0", (size_t)D, &h0));
+    CHK(getbuf_t(h, "fi_c0", (size_t)D, &c0));
+    HIPCHK(h, hipMemcpyAsync(G, ctxg, (size_t)T * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(mk, ctxg_mask, (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    CHK(init_state(h, 1, T, G, mk, mean, h0, c0));
+    HIPCHK(h, hipMemcpyAsync(out_h0, h0, D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_c0, c0, D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return STATTN_OK;
+}
+
+int stattn_invalidate_ctx_cache(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    h->ck_valid = false;
+    return STATTN_OK;
+}
+
+int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, const float* ctxg_mask,
+                  const float* ctxl, const float* ctxl_mask, const float* ctxm, const float* ctxm_mask, int T, int K,
+                  const float* h_in, const float* c_in, float* out_probs, int64_t* out_sample, float* out_h, float* out_c,
+                  float* out_alphal, float* out_alphag, float* out_alpham, float* out_alphalt, float* out_logits) {
+    (void)ctxg_mask; (void)ctxl_mask; (void)ctxm_mask;   // unused by the reference graph too (:848)
+    if (!h || !x || m <= 0 || !ctxg || !ctxl || !ctxm || T <= 0 || K <= 0 || !h_in || !c_in)
+        return fail(h, STATTN_EINVAL, "f_next: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int D = h->D, E = h->E, V = h->V, Vp = h->Vp;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    // --- per-video context: project once, reuse while the same arrays come back
+    const size_t nG = (size_t)T * D, nL = (size_t)T * K * h->Fl, nM = (size_t)T * h->Fm;
+    const double fp = fingerprint(ctxg, nG) + 3.0 * fingerprint(ctxl, nL) + 7.0 * fingerprint(ctxm, nM);
+    CtxPtrs c{};
+    float *rawl, *rawm;
+    CHK(getbuf_t(h, "sv_G", nG, &c.G));
+    CHK(getbuf_t(h, "sv_rawl", nL, &rawl));
+    CHK(getbuf_t(h, "sv_rawm", nM, &rawm));
+    CHK(getbuf_t(h, "sv_L", (size_t)T * K * D, &c.L));
+    CHK(getbuf_t(h, "sv_Mo", (size_t)T * D, &c.Mo));
+    CHK(getbuf_t(h, "sv_PG", (size_t)T * D, &c.PG));
+    CHK(getbuf_t(h, "sv_PL", (size_t)T * K * D, &c.PL));
+    CHK(getbuf_t(h, "sv_PM", (size_t)T * D, &c.PM));
+    CHK(getbuf_t(h, "sv_LW", h->opt.lt_mode == 1 ? (size_t)T * K * D : 1, &c.LW));
+    const bool hit = h->ck_valid && h->ck_g == ctxg && h->ck_l == ctxl && h->ck_m == ctxm && h->ck_T == T &&
+                     h->ck_K == K && h->ck_fp == fp;
+    if (!hit) {
+        HIPCHK(h, hipMemcpyAsync(c.G, ctxg, nG * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(rawl, ctxl, nL * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(rawm, ctxm, nM * sizeof(float), hipMemcpyHostToDevice, s));
+        CHK(project_context(h, 1, T, K, c.G, rawl, rawm, c));
+        h->ck_g = ctxg; h->ck_l = ctxl; h->ck_m = ctxm; h->ck_T = T; h->ck_K = K; h->ck_fp = fp; h->ck_valid = true;
+    }
+
+    // --- step buffers
+    int64_t *dx, *dargmax; int* vid;
+    float *hp, *cp, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *ho, *co, *hd, *a1, *lg, *pr;
+    CHK(getbuf_t(h, "sn_x", (size_t)m, &dx));
+    CHK(getbuf_t(h, "sn_argmax", (size_t)m, &dargmax));
+    CHK(getbuf_t(h, "sn_vid", (size_t)m, &vid));
+    CHK(getbuf_t(h, "sn_hp", (size_t)m * D, &hp));
+    CHK(getbuf_t(h, "sn_cp", (size_t)m * D, &cp));
+    CHK(getbuf_t(h, "sn_emb", (size_t)m * E, &emb));
+    CHK(getbuf_t(h, "sn_sproj", (size_t)m * 4 * D, &sproj));
+    CHK(getbuf_t(h, "sn_preh", (size_t)m * 4 * D, &preh));
+    CHK(getbuf_t(h, "sn_dp", (size_t)m * 3 * D, &dp));
+    CHK(getbuf_t(h, "sn_al", (size_t)m * T * K, &al));
+    CHK(getbuf_t(h, "sn_CL", (size_t)m * T * D, &CL));
+    CHK(getbuf_t(h, "sn_eg", (size_t)m * T, &eg));
+    CHK(getbuf_t(h, "sn_em", (size_t)m * T, &em));
+    CHK(getbuf_t(h, "sn_elt", (size_t)m * T, &elt));
+    CHK(getbuf_t(h, "sn_plt", h->opt.lt_mode == 0 ? (size_t)m * T * D : 1, &plt));
+    CHK(getbuf_t(h, "sn_ag", (size_t)m * T, &ag));
+    CHK(getbuf_t(h, "sn_am", (size_t)m * T, &am));
+    CHK(getbuf_t(h, "sn_alt", (size_t)m * T, &alt));
+    CHK(getbuf_t(h, "sn_ctx", (size_t)m * D, &ctx));
+    CHK(getbuf_t(h, "sn_ho", (size_t)m * D, &ho));
+    CHK(getbuf_t(h, "sn_co", (size_t)m * D, &co));
+    CHK(getbuf_t(h, "sn_hd", (size_t)m * D, &hd));
+    CHK(getbuf_t(h, "sn_a1", (size_t)m * E, &a1));
+    CHK(getbuf_t(h, "sn_lg", (size_t)m * Vp, &lg));
+    CHK(getbuf_t(h, "sn_pr", (size_t)m * Vp, &pr));
+
+    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(hp, h_in, (size_t)m * D * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(cp, c_in, (size_t)m * D * sizeof(float), hipMemcpyHostToDevice, s));
+    HIPCHK(h, launch_iota(s, vid, m, 0));                       // every hypothesis attends to video 0 (:786-788)
+    HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)m * 3 * D));     // sampler runs with use_noise = 0 (:469-472)
+    HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, m, E, V, 0));    // :803-804
+
+    StepIO io{};
+    io.M = m; io.T = T; io.K = K; io.c = c; io.vid = vid;
+    io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
+    io.dp = dp; io.mask = nullptr; io.d1 = nullptr;
+    io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
+    io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
+    io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+    CHK(run_step(h, io));
+
+    {   // readout (:817-838): a = 0.5 * tanh(0.5h.Wl1 + bl1 [+ emb] [+ ctx.Wl2 + bl2]); logit = a.Wo + bo
+        SkArgs a{};
+        a.M = m; a.nseg = 1;
+        SkSeg& sg = a.seg[0];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{hd, w.Wl1, D, E, D};
+        if (h->opt.ctx2out) { sg.p[1] = SkPair{ctx, w.Wl2, D, E, D}; sg.npairs = 2; sg.bias2 = w.bl2; }
+        sg.bias = w.bl1;
+        if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+        sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+        HIPCHK(h, launch_skinny(s, a));
+        SkArgs b{};
+        b.M = m; b.nseg = 1;
+        SkSeg& so = b.seg[0];
+        skinny_seg_defaults(so);
+        so.npairs = 1; so.p[0] = SkPair{a1, w.Wo, E, Vp, E};
+        so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+        HIPCHK(h, launch_skinny(s, b));
+        HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, dargmax, m, V));   // :840
+    }
+
+    if (out_probs) HIPCHK(h, hipMemcpy2DAsync(out_probs, (size_t)V * 4, pr, (size_t)Vp * 4, (size_t)V * 4, m, hipMemcpyDeviceToHost, s));
+    if (out_logits) HIPCHK(h, hipMemcpy2DAsync(out_logits, (size_t)V * 4, lg, (size_t)Vp * 4, (size_t)V * 4, m, hipMemcpyDeviceToHost, s));
+    if (out_h) HIPCHK(h, hipMemcpyAsync(out_h, ho, (size_t)m * D * 4, hipMemcpyDeviceToHost, s));
+    if (out_c) HIPCHK(h, hipMemcpyAsync(out_c, co, (size_t)m * D * 4, hipMemcpyDeviceToHost, s));
+    if (out_alphal) HIPCHK(h, hipMemcpyAsync(out_alphal, al, (size_t)m * T * K * 4, hipMemcpyDeviceToHost, s));
+    if (out_alphag) HIPCHK(h, hipMemcpyAsync(out_alphag, ag, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    if (out_alpham) HIPCHK(h, hipMemcpyAsync(out_alpham, am, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    if (out_alphalt) HIPCHK(h, hipMemcpyAsync(out_alphalt, alt, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+
+    if (out_sample) {
+        // next_sample = multinomial(next_probs).argmax(1) (:841): inverse-CDF draw with the library's own
+        // generator (bit-parity with Theano's MRG stream is not a goal).  Without probs: arg-max.
+        if (out_probs) {
+            for (int r = 0; r < m; ++r) {
+                h->host_rng ^= h->host_rng << 13; h->host_rng ^= h->host_rng >> 7; h->host_rng ^= h->host_rng << 17;
+                const double u = (double)(h->host_rng >> 11) * (1.0 / 9007199254740992.0);
+                double acc = 0.0; int64_t pick = V - 1;
+                const float* p = out_probs + (size_t)r * V;
+                for (int j = 0; j < V; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
+                out_sample[r] = pick;
+            }
+        } else {
+            HIPCHK(h, hipMemcpy(out_sample, dargmax, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
+    }
+    return STATTN_OK;
+}
+
+// ---- training graph -----------------------------------------------------------------
+int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int t, int m,
+                     const float* ctxg, const float* mask_ctxg, const float* ctxl, const float* mask_ctxl,
+                     const float* ctxm, const float* mask_ctxm, int T, int K) {
+    (void)mask_ctxl; (void)mask_ctxm;   // unused by the reference graph (on_unused_input='ignore', :1127)
+    if (!h || !x || !mask || !ctxg || !mask_ctxg || !ctxl || !ctxm || t <= 0 || m <= 0 || T <= 0 || K <= 0)
+        return fail(h, STATTN_EINVAL, "set_batch: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    const int D = h->D;
+    int64_t* dx; float *dmask, *G, *mG, *rl, *rm;
+    CHK(getbuf_t(h, "x", (size_t)t * m, &dx));
+    CHK(getbuf_t(h, "mask", (size_t)t * m, &dmask));
+    CHK(getbuf_t(h, "G", (size_t)m * T * D, &G));
+    CHK(getbuf_t(h, "mG", (size_t)m * T, &mG));
+    CHK(getbuf_t(h, "rawl", (size_t)m * T * K * h->Fl, &rl));
+    CHK(getbuf_t(h, "rawm", (size_t)m * T * h->Fm, &rm));
+    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)t * m * sizeof(int64_t), hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dmask, mask, (size_t)t * m * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(G, ctxg, (size_t)m * T * D * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(mG, mask_ctxg, (size_t)m * T * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(rl, ctxl, (size_t)m * T * K * h->Fl * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(rm, ctxm, (size_t)m * T * h->Fm * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->t = t; h->m = m; h->T = T; h->K = K;
+    h->have_batch = true; h->have_fwd = false;
+    return STATTN_OK;
+}
+
+int stattn_forward_train(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_batch) return fail(h, STATTN_ESTATE, "forward_train: no batch staged (call stattn_set_batch)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)t * m;
+
+    int64_t* dx = (int64_t*)h->bufs["x"].p;
+    float* dmask = findbuf(h, "mask");
+    float* mG = findbuf(h, "mG");
+    float* rawl = findbuf(h, "rawl");
+    float* rawm = findbuf(h, "rawm");
+    CtxPtrs c{};
+    c.G = findbuf(h, "G");
+    float *mean, *emb, *xproj, *hs, *cs, *hd, *ctx, *csum, *sel, *al, *ag, *am, *alt, *CL, *gates, *sproj, *preh,
+          *eg, *em, *elt, *plt, *z1, *a1, *lg, *pr, *nll, *cost, *dp, *d1, *d2;
+    CHK(getbuf_t(h, "L", (size_t)m * T * K * D, &c.L));
+    CHK(getbuf_t(h, "Mo", (size_t)m * T * D, &c.Mo));
+    CHK(getbuf_t(h, "PG", (size_t)m * T * D, &c.PG));
+    CHK(getbuf_t(h, "PL", (size_t)m * T * K * D, &c.PL));
+    CHK(getbuf_t(h, "PM", (size_t)m * T * D, &c.PM));
+    CHK(getbuf_t(h, "LW", h->opt.lt_mode == 1 ? (size_t)m * T * K * D : 1, &c.LW));
+    CHK(getbuf_t(h, "mean", (size_t)m * D, &mean));
+    CHK(getbuf_t(h, "emb", R * E, &emb));
+    CHK(getbuf_t(h, "xproj", R * 4 * D, &xproj));
+    CHK(getbuf_t(h, "hs", (R + m) * D, &hs));          // hs[0] = h0, hs[s+1] = state after step s
+    CHK(getbuf_t(h, "cs", (R + m) * D, &cs));
+    CHK(getbuf_t(h, "hd", R * D, &hd));
+    CHK(getbuf_t(h, "ctx", R * D, &ctx));
+    CHK(getbuf_t(h, "csum", R * D, &csum));
+    CHK(getbuf_t(h, "sel", R, &sel));
+    CHK(getbuf_t(h, "alphal", R * T * K, &al));
+    CHK(getbuf_t(h, "alphag", R * T, &ag));
+    CHK(getbuf_t(h, "alpham", R * T, &am));
+    CHK(getbuf_t(h, "alphalt", R * T, &alt));
+    CHK(getbuf_t(h, "CL", R * T * D, &CL));
+    CHK(getbuf_t(h, "gates", R * 4 * D, &gates));
+    CHK(getbuf_t(h, "sproj", R * 4 * D, &sproj));
+    CHK(getbuf_t(h, "preh", R * 4 * D, &preh));
+    CHK(getbuf_t(h, "eg", R * T, &eg));
+    CHK(getbuf_t(h, "em", R * T, &em));
+    CHK(getbuf_t(h, "elt", R * T, &elt));
+    CHK(getbuf_t(h, "plt", h->opt.lt_mode == 0 ? R * T * D : 1, &plt));
+    CHK(getbuf_t(h, "z1", R * E, &z1));
+    CHK(getbuf_t(h, "a1", R * E, &a1));
+    CHK(getbuf_t(h, "logits", R * Vp, &lg));
+    CHK(getbuf_t(h, "probs", R * Vp, &pr));
+    CHK(getbuf_t(h, "nll", R, &nll));
+    CHK(getbuf_t(h, "cost", (size_t)m, &cost));
+    CHK(prepare_masks(h, t, m, &dp, &d1, &d2));
+
+    // ---- prologue, once per batch
+    CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
+    {
+        Prof pp(h, KC_PROLOGUE);
+        CHK(init_state(h, m, T, c.G, mG, mean, hs, cs));
+        HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, (int)R, E, V, m));      // emb shifted one step (:613-617)
+        GemmArgs g;
+        gemm_defaults(g);                                                   // x_ = emb.W + b (:334-335)
+        g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
+        g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
+        HIPCHK(h, launch_gemm(s, g, false, false));
+    }
+
+    // ---- the scan over caption positions (:495-512)
+    for (int st = 0; st < t; ++st) {
+        const size_t r0 = (size_t)st * m;
+        StepIO io{};
+        io.M = m; io.T = T; io.K = K; io.c = c; io.vid = nullptr;
+        io.h_prev = hs + r0 * D; io.c_prev = cs + r0 * D;
+        io.sproj = sproj + r0 * 4 * D; io.preh = preh + r0 * 4 * D;
+        io.xproj = xproj + r0 * 4 * D; io.emb = nullptr;
+        io.dp = dp + r0 * 3 * D; io.mask = dmask + r0; io.d1 = d1 + r0 * D;
+        io.alphal = al + r0 * T * K; io.CL = CL + r0 * T * D;
+        io.eg = eg + r0 * T; io.em = em + r0 * T; io.elt = elt + r0 * T; io.plt = plt + (h->opt.lt_mode == 0 ? r0 * T * D : 0);
+        io.alphag = ag + r0 * T; io.alpham = am + r0 * T; io.alphalt = alt + r0 * T;
+        io.csum = csum + r0 * D; io.sel = sel + r0; io.ctx = ctx + r0 * D;
+        io.h_out = hs + (r0 + m) * D; io.c_out = cs + (r0 + m) * D; io.gates = gates + r0 * 4 * D; io.hd = hd + r0 * D;
+        CHK(run_step(h, io));
+    }
+
+    // ---- readout over all (t*m) rows at once (:684-705), softmax and masked NLL (:708-715)
+    {
+        Prof pr_(h, KC_READOUT);
+        GemmArgs g;
+        gemm_defaults(g);      // z1 = (h*d1).Wl1 + bl1 [+ emb]
+        g.A = hd; g.lda = D; g.B = w.Wl1; g.ldb = E; g.C = h->opt.ctx2out ? z1 : a1; g.ldc = E;
+        g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl1;
+        if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
+        if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; }
+        HIPCHK(h, launch_gemm(s, g, false, false));
+        if (h->opt.ctx2out) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
+            gemm_defaults(g);
+            g.A = ctx; g.lda = D; g.B = w.Wl2; g.ldb = E; g.C = a1; g.ldc = E;
+            g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E;
+            HIPCHK(h, launch_gemm(s, g, false, false));
+        }
+        gemm_defaults(g);      // logit = a.Wo + bo
+        g.A = a1; g.lda = E; g.B = w.Wo; g.ldb = Vp; g.C = lg; g.ldc = Vp;
+        g.M = (int)R; g.N = Vp; g.K = E; g.bias = w.bo;
+        HIPCHK(h, launch_gemm(s, g, false, false));
+    }
+    HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, dx, nll, nullptr, (int)R, V));
+    HIPCHK(h, launch_cost(s, nll, dmask, cost, t, m));
+    h->have_fwd = true;
+    return STATTN_OK;
+}
+
+int stattn_get_forward(stattn_handle* h, float* cost, float* probs, float* alphal, float* alphag, float* alpham,
+                       float* alphalt, float* logits) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_fwd) return fail(h, STATTN_ESTATE, "get_forward: no forward pass has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)h->t * h->m;
+    const int T = h->T, K = h->K, V = h->V, Vp = h->Vp;
+    if (cost) HIPCHK(h, hipMemcpyAsync(cost, findbuf(h, "cost"), (size_t)h->m * 4, hipMemcpyDeviceToHost, s));
+    if (probs) HIPCHK(h, hipMemcpy2DAsync(probs, (size_t)V * 4, findbuf(h, "probs"), (size_t)Vp * 4, (size_t)V * 4, R, hipMemcpyDeviceToHost, s));
+    if (logits) HIPCHK(h, hipMemcpy2DAsync(logits, (size_t)V * 4, findbuf(h, "logits"), (size_t)Vp * 4, (size_t)V * 4, R, hipMemcpyDeviceToHost, s));
+    if (alphal) HIPCHK(h, hipMemcpyAsync(alphal, findbuf(h, "alphal"), R * T * K * 4, hipMemcpyDeviceToHost, s));
+    if (alphag) HIPCHK(h, hipMemcpyAsync(alphag, findbuf(h, "alphag"), R * T * 4, hipMemcpyDeviceToHost, s));
+    if (alpham) HIPCHK(h, hipMemcpyAsync(alpham, findbuf(h, "alpham"), R * T * 4, hipMemcpyDeviceToHost, s));
+    if (alphalt) HIPCHK(h, hipMemcpyAsync(alphalt, findbuf(h, "alphalt"), R * T * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return STATTN_OK;
+}
+
+int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_fwd) return fail(h, STATTN_ESTATE, "get_states: no forward pass has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)h->t * h->m, D = h->D, m = h->m;
+    if (hs) HIPCHK(h, hipMemcpyAsync(hs, findbuf(h, "hs") + m * D, R * D * 4, hipMemcpyDeviceToHost, s));
+    if (cs) HIPCHK(h, hipMemcpyAsync(cs, findbuf(h, "cs") + m * D, R * D * 4, hipMemcpyDeviceToHost, s));
+    if (ctx) HIPCHK(h, hipMemcpyAsync(ctx, findbuf(h, "ctx"), R * D * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return STATTN_OK;
+}
+
+// ---- kernel-level entry points ------------------------------------------------------
+int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, const float* B, const float* bias, const float* add, int act, float* C) {
+    if (!h || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(h, STATTN_EINVAL, "dbg_gemm: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    float *dA, *dB, *dC, *dbias, *dadd;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N, &dC));
+    CHK(getbuf_t(h, "dbg_bias", (size_t)N, &dbias));
+    CHK(getbuf_t(h, "dbg_add", (size_t)M * N, &dadd));
+    HIPCHK(h, hipMemcpyAsync(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dB, B, (size_t)K * N * 4, hipMemcpyHostToDevice, s));
+    if (bias) HIPCHK(h, hipMemcpyAsync(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    if (add) HIPCHK(h, hipMemcpyAsync(dadd, add, (size_t)M * N * 4, hipMemcpyHostToDevice, s));
+    if (kind == 0) {
+        GemmArgs g;
+        gemm_defaults(g);
+        g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
+        g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias ? dbias : nullptr;
+        if (add) { g.add = dadd; g.ldadd = N; }
+        g.act = act;
+        hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else {
+        if (transA || transB) return fail(h, STATTN_EINVAL, "skinny kernel has no transposed variants");
+        SkArgs a{};
+        a.M = M; a.nseg = 1;
+        SkSeg& sg = a.seg[0];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{dA, dB, K, N, K};
+        sg.C = dC; sg.ldc = N; sg.N = N; sg.bias = bias ? dbias : nullptr;
+        if (add) { sg.add = dadd; sg.ldadd = N; }
+        sg.act = act; sg.scale = 1.f;
+        if (alpha != 1.f) return fail(h, STATTN_EINVAL, "skinny kernel: alpha must be 1");
+        hipError_t e = launch_skinny(s, a);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    }
+    HIPCHK(h, hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return STATTN_OK;
+}
+
+int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(h, STATTN_EINVAL, "dbg_time_gemm: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB, *dC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N, &dC));
+    // uniform [-1,1) operands: full-range signs (never time a GEMM on zeros -- DVFS inflates the clock)
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N, 11, 2));
+    GemmArgs g;
+    gemm_defaults(g);
+    g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
+    g.M = M; g.N = N; g.K = K;
+    for (int i = 0; i < 2; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+    HIPCHK(h, hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+    HIPCHK(h, hipEventRecord(b, s));
+    HIPCHK(h, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+int stattn_set_profiling(stattn_handle* h, int enable) {
+    if (!h) return STATTN_EINVAL;
+    prof_collect(h);
+    h->profiling = enable != 0;
+    for (int i = 0; i < KC_COUNT; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
+    return STATTN_OK;
+}
+int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches) {
+    if (!h || which < 0 || which >= KC_COUNT || !ms_avg) return STATTN_EINVAL;
+    prof_collect(h);
+    *ms_avg = h->k_n[which] ? (float)(h->k_ms[which] / h->k_n[which]) : 0.f;
+    if (launches) *launches = h->k_n[which];
+    return STATTN_OK;
+}
+
+}  // extern "C"

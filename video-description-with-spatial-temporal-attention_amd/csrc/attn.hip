@@ -1,0 +1,241 @@
+// Attention kernels of the decoder step for gfx950 -- the HBM-bound part of the path.
+//
+// spatial_kernel  (model_attention.py:371-383, plus the score halves of :389-398, :402-411 and,
+//                  in lt_mode 1, :415-425):   one workgroup per (row b, frame t)
+//     e_k   = Ul . tanh(PL[v,t,k,:] + sl[b,:]) + cl          k = 0..K-1
+//     alpha = softmax_k(e)
+//     CL[b,t,:] = sum_k alpha_k L[v,t,k,:]
+//     eg[b,t] = Ug . tanh(PG[v,t,:] + sg[b,:]) + cg           (same for motion)
+//     lt_mode 1:  elt[b,t] = Ult . tanh(sum_k alpha_k LW[v,t,k,:] + blt + slt[b,:]) + clt
+//   Every byte of PL / L / LW is read exactly once per step with 16-byte coalesced loads
+//   (a K x D slab is contiguous), D is striped over the 256 lanes of the workgroup, the K+2
+//   dot products are reduced with wave shuffles + one LDS hop, the K-wide softmax lives in LDS.
+//
+// temporal_kernel (:398-399, :411-412, :425-435): one workgroup per (row b, 256-wide slice of D)
+//     three softmaxes over T (unmasked, Appendix C.5), selector gate, and
+//     ctx[b,:] = sel_b * sum_t (ag_t G[v,t,:] + am_t M[v,t,:] + alt_t CL[b,t,:])
+#include "kernels.h"
+#include "devmath.h"
+
+namespace stattn {
+
+namespace {
+
+constexpr int KMAX = 64;     // regions per frame supported by the LDS softmax
+constexpr int TMAX = 256;    // frames supported by the temporal kernel
+
+__device__ __forceinline__ float dot4_tanh(float4 x, float4 s, float4 u) {
+    return fast_tanh(x.x + s.x) * u.x + fast_tanh(x.y + s.y) * u.y +
+           fast_tanh(x.z + s.z) * u.z + fast_tanh(x.w + s.w) * u.w;
+}
+
+// sum `n` per-thread values over the 256-thread workgroup; result broadcast through out[]
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* s_red /*[4][N]*/, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float r = wave_sum(v[i]);
+        if (lane == 0) s_red[w * N + i] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) v[i] = s_red[i] + s_red[N + i] + s_red[2 * N + i] + s_red[3 * N + i];
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
+    __shared__ float s_red[4 * 10];
+    __shared__ float s_e[KMAX];
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int v = a.vid ? a.vid[b] : b;
+    const int tid = threadIdx.x;
+    const size_t slab = ((size_t)v * T + t) * K * D;
+    const float* __restrict__ PL = a.PL + slab;
+    const float* __restrict__ L = a.L + slab;
+    const float* __restrict__ sl = a.sproj + (size_t)b * a.ldsp;
+    const int nd4 = D >> 2;
+
+    // ---- scores: K region scores (+ the two frame scores with the first group of 8)
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float p[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) p[i] = 0.f;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const float4 s4 = ld4(sl + 4 * d4), u4 = ld4(a.Ul + 4 * d4);
+            float4 x[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)   // clamp keeps the 8 loads unconditional and in flight together
+                x[kk] = ld4(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) p[kk] += dot4_tanh(x[kk], s4, u4);
+            if (k0 == 0) {
+                const size_t fo = ((size_t)v * T + t) * D + 4 * d4;
+                p[8] += dot4_tanh(ld4(a.PG + fo), ld4(sl + D + 4 * d4), ld4(a.Ug + 4 * d4));
+                p[9] += dot4_tanh(ld4(a.PM + fo), ld4(sl + 2 * D + 4 * d4), ld4(a.Um + 4 * d4));
+            }
+        }
+        block_sum<10>(p, s_red, tid);
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+    }
+    __syncthreads();
+
+    // ---- softmax over the K regions (every thread redundantly; K <= 64, LDS broadcast reads)
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_e[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += __expf(s_e[k] - mx);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    if (tid < K) {
+        const float al = __expf(s_e[tid] - mx) * inv;
+        a.alphal[(size_t)bt * K + tid] = al;
+        s_e[tid] = al;
+    }
+    __syncthreads();
+
+    // ---- attended local feature (and, lt_mode 1, the local-temporal score)
+    float pe[1] = {0.f};
+    const float* __restrict__ LW = a.LW ? a.LW + slab : nullptr;
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+            const float al = s_e[k];
+            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
+            c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
+            if (LW) {
+                const float4 q4 = ld4(LW + (size_t)k * D + 4 * d4);
+                w4.x += al * q4.x; w4.y += al * q4.y; w4.z += al * q4.z; w4.w += al * q4.w;
+            }
+        }
+        st4(a.CL + (size_t)bt * D + 4 * d4, c4);
+        if (LW) {
+            const float4 bl = ld4(a.blt + 4 * d4);
+            w4.x += bl.x; w4.y += bl.y; w4.z += bl.z; w4.w += bl.w;
+            pe[0] += dot4_tanh(w4, ld4(sl + 3 * D + 4 * d4), ld4(a.Ult + 4 * d4));
+        }
+    }
+    if (LW) {
+        block_sum<1>(pe, s_red, tid);
+        if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+    }
+}
+
+// one wave per row: out[r] = dot(P[r,:], U) + c
+__global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P, int ldp,
+                                                     const float* __restrict__ U, const float* __restrict__ c,
+                                                     float* __restrict__ out, int rows, int D) {
+    const int r = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (r >= rows) return;
+    float s = 0.f;
+    for (int d4 = lane; d4 < (D >> 2); d4 += 64) {
+        const float4 p = ld4(P + (size_t)r * ldp + 4 * d4), u = ld4(U + 4 * d4);
+        s += p.x * u.x + p.y * u.y + p.z * u.z + p.w * u.w;
+    }
+    s = wave_sum(s);
+    if (lane == 0) out[r] = s + c[0];
+}
+
+__global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
+    __shared__ float s_al[3][TMAX];
+    __shared__ float s_sel;
+    __shared__ __attribute__((aligned(16))) float s_part[4][256];
+    const int T = a.T, D = a.D;
+    const int b = blockIdx.x, chunk = blockIdx.y;
+    const int v = a.vid ? a.vid[b] : b;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+
+    if (w < 3) {          // three softmaxes over T, one wave each
+        const float* e = (w == 0 ? a.eg : (w == 1 ? a.em : a.elt)) + (size_t)b * T;
+        float mx = -INFINITY;
+        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, e[t]);
+        mx = wave_max(mx);
+        float sum = 0.f;
+        for (int t = lane; t < T; t += 64) sum += __expf(e[t] - mx);
+        sum = wave_sum(sum);
+        const float inv = 1.0f / sum;
+        float* out = (w == 0 ? a.alphag : (w == 1 ? a.alpham : a.alphalt)) + (size_t)b * T;
+        for (int t = lane; t < T; t += 64) {
+            const float al = __expf(e[t] - mx) * inv;
+            s_al[w][t] = al;
+            if (chunk == 0) out[t] = al;
+        }
+    } else {              // selector gate sigma(h_prev . W_sel + b_sel)   (:433)
+        float sel = 1.f;
+        if (a.W_sel) {
+            float s = 0.f;
+            for (int d4 = lane; d4 < (D >> 2); d4 += 64) {
+                const float4 h4 = ld4(a.h_prev + (size_t)b * D + 4 * d4), w4 = ld4(a.W_sel + 4 * d4);
+                s += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
+            }
+            s = wave_sum(s);
+            sel = fast_sigmoid(s + a.b_sel[0]);
+        }
+        if (lane == 0) {
+            s_sel = sel;
+            if (chunk == 0 && a.sel) a.sel[b] = sel;
+        }
+    }
+    __syncthreads();
+
+    // weighted sums over frames: wave w takes t = w, w+4, ...; lane owns 4 consecutive d
+    const int d = chunk * 256 + 4 * lane;
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (d < D) {
+        const float* __restrict__ G = a.G + (size_t)v * T * D + d;
+        const float* __restrict__ Mo = a.Mo + (size_t)v * T * D + d;
+        const float* __restrict__ CL = a.CL + (size_t)b * T * D + d;
+#pragma unroll 2
+        for (int t = w; t < T; t += 4) {
+            const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
+            const float4 g4 = ld4(G + (size_t)t * D), m4 = ld4(Mo + (size_t)t * D), c4 = ld4(CL + (size_t)t * D);
+            acc.x += ag * g4.x + am * m4.x + alt * c4.x;
+            acc.y += ag * g4.y + am * m4.y + alt * c4.y;
+            acc.z += ag * g4.z + am * m4.z + alt * c4.z;
+            acc.w += ag * g4.w + am * m4.w + alt * c4.w;
+        }
+    }
+    st4(&s_part[w][4 * lane], acc);
+    __syncthreads();
+    if (w == 0 && d < D) {
+        float4 r = ld4(&s_part[0][4 * lane]);
+#pragma unroll
+        for (int i = 1; i < 4; ++i) {
+            const float4 q = ld4(&s_part[i][4 * lane]);
+            r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        }
+        if (a.csum) st4(a.csum + (size_t)b * D + d, r);
+        const float sel = s_sel;
+        r.x *= sel; r.y *= sel; r.z *= sel; r.w *= sel;
+        st4(a.ctx + (size_t)b * D + d, r);
+    }
+}
+
+}  // namespace
+
+hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.K > KMAX || a.K < 1 || a.D % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+hipError_t launch_rowdot(hipStream_t s, const float* P, int ldp, const float* U, const float* c,
+                         float* out, int rows, int D) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(rowdot_kernel, dim3((rows + 3) / 4), dim3(256), 0, s, P, ldp, U, c, out, rows, D);
+    return hipGetLastError();
+}
+
+hipError_t launch_temporal(hipStream_t s, const TemporalArgs& a) {
+    if (a.M <= 0) return hipSuccess;
+    if (a.T > TMAX || a.T < 1 || a.D % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(temporal_kernel, dim3(a.M, (a.D + 255) / 256), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace stattn

@@ -1,0 +1,209 @@
+// LDS-tiled fp32 MFMA GEMM for gfx950 (v_mfma_f32_32x32x2_f32: exact fp32, 157 TFLOP/s peak).
+//
+// Used for the once-per-batch prologue of the decoder (ff_local / ff_motion F->D projections,
+// model_attention.py:664-667; attention pre-projections :322-326; x projection :334-335), the
+// per-step local-temporal projection CL.Wclt (:416, lt_mode 0), the batched readout (:687-705)
+// and -- transposed variants -- the weight/input gradients of all of them.
+//
+// Tiling: block = 4 waves (2x2), block tile (64*TM) x (64*TN), BK = 32, two LDS stages.
+// Each wave owns a (32*TM) x (32*TN) sub-tile = TM x TN accumulators of 32x32 (16 VGPR each).
+//
+// Operand trick: v_mfma_f32_32x32x2 contracts k over the two half-waves (lane>>5).  A lane
+// reads FOUR consecutive k of its A row with one ds_read_b128 and feeds them to four MFMAs;
+// half-wave 0 therefore covers k = 8kk+{0..3}, half-wave 1 k = 8kk+{4..7}.  The B operand uses
+// the same k assignment, so the only effect is a permutation of the summation order inside a
+// k-block of 8.  The LDS row stride of a k-contiguous tile is BK+4 dwords: ds_read_b128 is
+// serviced in 16-lane groups and (36*i) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
+#include "kernels.h"
+#include "devmath.h"
+
+namespace stattn {
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KPAD = BK + 4;
+constexpr int NXCD = 8;
+
+// KC: operand stored k-contiguous in memory ([rows][K]); RC: row-contiguous ([K][rows]).
+template <int BR, bool KC>
+struct Tile {
+    static constexpr int ELEMS = KC ? BR * KPAD : BK * BR;
+    static constexpr int NF4 = BR * BK / 4 / 256;
+
+    // rows_total: extent of the "rows" dimension (M or N); K: extent of k.
+    __device__ static __forceinline__ void gload(float4 (&r)[NF4], const float* __restrict__ X, int ld,
+                                                 int r0, int rows_total, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int idx = tid + i * 256;
+            if constexpr (KC) {
+                const int rr = idx >> 3, kc = idx & 7;
+                int row = r0 + rr;
+                row = row < rows_total ? row : rows_total - 1;   // clamp: edge rows are never stored
+                const int k = k0 + 4 * kc;
+                r[i] = (k < K) ? ld4(X + (size_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                constexpr int RCW = BR / 4;
+                const int k = idx / RCW, rc = idx % RCW;
+                const int gk = k0 + k, gr = r0 + 4 * rc;
+                r[i] = (gk < K && gr < rows_total) ? ld4(X + (size_t)gk * ld + gr)
+                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    }
+    __device__ static __forceinline__ void sstore(const float4 (&r)[NF4], float* s, int tid) {
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            const int idx = tid + i * 256;
+            if constexpr (KC) {
+                const int rr = idx >> 3, kc = idx & 7;
+                st4(s + rr * KPAD + 4 * kc, r[i]);
+            } else {
+                constexpr int RCW = BR / 4;
+                const int k = idx / RCW, rc = idx % RCW;
+                st4(s + k * BR + 4 * rc, r[i]);
+            }
+        }
+    }
+    // fragment for row `row` (0..BR) of k-block kk (8 k's): 4 values k = 8kk + 4kh + q
+    __device__ static __forceinline__ void frag(float (&f)[4], const float* s, int row, int kk, int kh) {
+        if constexpr (KC) {
+            const float4 v = ld4(s + row * KPAD + kk * 8 + 4 * kh);
+            f[0] = v.x; f[1] = v.y; f[2] = v.z; f[3] = v.w;
+        } else {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) f[q] = s[(kk * 8 + 4 * kh + q) * BR + row];
+        }
+    }
+};
+
+template <int TM, int TN, bool AT, bool BT>
+__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    using TA = Tile<BM, !AT>;
+    using TB = Tile<BN, BT>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::ELEMS + TB::ELEMS)];
+    float* sA = smem;
+    float* sB = smem + 2 * TA::ELEMS;
+
+    // XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
+    // (consecutive tiles share the A row-panel -> L2 hits).  Bijective for any grid size.
+    const int tiles_n = g.N / BN;
+    const int nblk = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
+    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD;
+    const int m0 = (lin / tiles_n) * BM;
+    const int n0 = (lin % tiles_n) * BN;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[TA::NF4], rb[TB::NF4];
+    const int nk = (g.K + BK - 1) / BK;
+
+    TA::gload(ra, g.A, g.lda, m0, g.M, 0, g.K, tid);
+    TB::gload(rb, g.B, g.ldb, n0, g.N, 0, g.K, tid);
+    TA::sstore(ra, sA, tid);
+    TB::sstore(rb, sB, tid);
+    __syncthreads();
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const int st = kt & 1;
+        const bool more = (kt + 1 < nk);
+        if (more) {   // next tile's global loads fly while this tile is multiplied
+            TA::gload(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, tid);
+            TB::gload(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, tid);
+        }
+        const float* cA = sA + st * TA::ELEMS;
+        const float* cB = sB + st * TB::ELEMS;
+#pragma unroll
+        for (int kk = 0; kk < BK / 8; ++kk) {
+            float a[TM][4], b[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) TA::frag(a[i], cA, wm * 32 * TM + i * 32 + l31, kk, kh);
+#pragma unroll
+            for (int j = 0; j < TN; ++j) TB::frag(b[j], cB, wn * 32 * TN + j * 32 + l31, kk, kh);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+        }
+        if (more) {   // the other stage was last read before the previous barrier
+            TA::sstore(ra, sA + (st ^ 1) * TA::ELEMS, tid);
+            TB::sstore(rb, sB + (st ^ 1) * TB::ELEMS, tid);
+        }
+        __syncthreads();
+    }
+
+    // epilogue.  32x32 C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + j * 32 + l31;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < g.M) {
+                    float v = g.alpha * acc[i][j][r] + bias;
+                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
+                    if (g.act == 1) v = fast_tanh(v);
+                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
+                    float* c = g.C + (size_t)row * g.ldc + col;
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
+template <int TM, int TN>
+hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
+    const int BM = 64 * TM, BN = 64 * TN;
+    const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
+    dim3 grid(tiles), block(256);
+    if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
+    else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
+    else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, g);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
+}  // namespace
+
+void gemm_defaults(GemmArgs& g) {
+    g = GemmArgs{};
+    g.alpha = 1.f;
+    g.rowgroup = 1;
+}
+
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
+    if (g.N % 64 != 0 || g.K % 4 != 0) return hipErrorInvalidValue;
+    if (tA && (g.M % 4 != 0)) return hipErrorInvalidValue;
+    // tile choice: the largest tile that still yields >= ~0.8 blocks per CU (256 CUs)
+    auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
+    const bool n128 = (g.N % 128 == 0);
+    if (n128 && g.M > 64 && blocks(128, 128) >= 200) return launch_cfg<2, 2>(s, g, tA, tB);
+    if (g.M > 64 && blocks(128, 64) >= 200) return launch_cfg<2, 1>(s, g, tA, tB);
+    return launch_cfg<1, 1>(s, g, tA, tB);
+}
+
+}  // namespace stattn

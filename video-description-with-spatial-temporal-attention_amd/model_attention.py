@@ -1,0 +1,315 @@
+"""Host-side mirror of the reference's `model_attention.Attention` for the decoder path.
+
+Same method names, positional orders and return orders as the reference
+(model_attention.py:42-994), so its callers -- Attention.train (:1034), metrics.py:28-40,126 --
+keep working against this class:
+
+    model   = Attention()
+    params  = model.init_params(options)                 # :518-581
+    tparams = model.init_tparams(params)                 # :70-78
+    trng, use_noise, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm, \
+        alphals, alphags, alphams, alphalts, cost, extra = model.build_model(tparams, options)   # :583-717
+    f_init, f_next = model.build_sampler(tparams, options, use_noise, trng)                      # :719-850
+    sample, score, h, c = model.gen_sample(tparams, f_init, f_next, ctxg, ctxg_mask, ctxl, ctxl_mask,
+                                           ctxm, ctxm_mask, options, None, k, maxlen)            # :852-994
+
+The Theano graph is replaced by libstattn.so (hand-written gfx950 kernels behind a C ABI);
+the symbolic variables build_model returns are inert name tags that `function()` below
+recognises when it stands in for `theano.function` (f_log_probs, :1126; f_alpha*, :1167-1188)."""
+import copy
+import warnings
+from collections import OrderedDict
+
+import numpy
+
+try:                                    # package import (stattn.model_attention)
+    from . import common
+    from ._native import Decoder
+except ImportError:                     # top-level import with the package dir on sys.path
+    import common
+    from _native import Decoder
+
+from_common = ('zipp', 'unzip', 'itemlist', 'norm_weight', 'ortho_weight', 'load_params')
+zipp, unzip, itemlist = common.zipp, common.unzip, common.itemlist
+norm_weight, ortho_weight, load_params = common.norm_weight, common.ortho_weight, common.load_params
+
+
+def _p(pp, name):
+    return '%s_%s' % (pp, name)
+
+
+def validate_options(options):
+    """model_attention.py:35-40"""
+    if options['ctx2out']:
+        warnings.warn('Feeding context to output directly seems to hurt.')
+    if options['dim_word'] > options['dim']:
+        warnings.warn('dim_word should only be as large as dim.')
+    return options
+
+
+class Sym(object):
+    """Inert stand-in for a Theano symbolic variable returned by build_model."""
+
+    def __init__(self, name, neg=False):
+        self.name, self.neg = name, neg
+
+    def __neg__(self):
+        return Sym(self.name, not self.neg)
+
+    def __repr__(self):
+        return ('-' if self.neg else '') + self.name
+
+
+class TParams(OrderedDict):
+    """OrderedDict name -> SharedVar plus the native decoder they live in once bound."""
+    decoder = None
+
+
+class Attention(object):
+    def __init__(self, channel=None):
+        self.channel = channel
+        self.layers = {'ff': ('param_init_fflayer', 'fflayer'),
+                       'lstm_cond': ('param_init_lstm_cond', 'lstm_cond_layer')}
+        self._options = None
+        self.device = 0
+        self.stream = None
+
+    # ---------------------------------------------------------------- parameters
+    def load_params(self, path, params):
+        return common.load_params(path, params)
+
+    def param_init_fflayer(self, options, params, prefix='ff', nin=None, nout=None):
+        """model_attention.py:80-87"""
+        params[_p(prefix, 'W')] = norm_weight(nin, nout, scale=0.01)
+        params[_p(prefix, 'b')] = numpy.zeros((nout,)).astype('float32')
+        return params
+
+    def param_init_lstm_cond(self, options, params, prefix='lstm_cond', nin=None, dim=None, dimctxglm=None,
+                             dimctxg=None, dimctxl=None, dimctxm=None):
+        """model_attention.py:180-282: same arrays, same order, same draws from common.rng_numpy."""
+        nin = options['dim'] if nin is None else nin
+        dim = options['dim'] if dim is None else dim
+        dimctxglm = options['dim'] if dimctxglm is None else dimctxglm
+        params[_p(prefix, 'W')] = numpy.concatenate([norm_weight(nin, dim) for _ in range(4)], axis=1)   # :189-193
+        params[_p(prefix, 'U')] = numpy.concatenate([ortho_weight(dim) for _ in range(4)], axis=1)       # :196-200
+        params[_p(prefix, 'b')] = numpy.zeros((4 * dim,)).astype('float32')                              # :203
+        params[_p(prefix, 'Wc')] = norm_weight(dimctxglm, dim * 4)                                       # :206
+        params[_p(prefix, 'Wcg_att')] = norm_weight(dimctxg, ortho=False)                                # :210
+        params[_p(prefix, 'Wcm_att')] = norm_weight(dimctxm, ortho=False)                                # :214
+        params[_p(prefix, 'Wclt_att')] = norm_weight(dimctxl, ortho=False)                               # :218
+        params[_p(prefix, 'Wdg_att')] = norm_weight(dim, dimctxg)                                        # :222
+        params[_p(prefix, 'Wdm_att')] = norm_weight(dim, dimctxm)                                        # :225
+        params[_p(prefix, 'Wdlt_att')] = norm_weight(dim, dimctxl)                                       # :228
+        params[_p(prefix, 'bg_att')] = numpy.zeros((dimctxg,)).astype('float32')                         # :232
+        params[_p(prefix, 'bm_att')] = numpy.zeros((dimctxm,)).astype('float32')                         # :235
+        params[_p(prefix, 'blt_att')] = numpy.zeros((dimctxl,)).astype('float32')                        # :239
+        params[_p(prefix, 'Wcl_att')] = norm_weight(dimctxl, ortho=False)                                # :243
+        params[_p(prefix, 'Wdl_att')] = norm_weight(dim, dimctxl)                                        # :247
+        params[_p(prefix, 'bl_att')] = numpy.zeros((dimctxl,)).astype('float32')                         # :251
+        for nm, dd in (('g', dimctxg), ('m', dimctxm), ('lt', dimctxl), ('l', dimctxl)):                 # :255-274
+            params[_p(prefix, 'U%s_att' % nm)] = norm_weight(dd, 1)
+            params[_p(prefix, 'c%s_att' % nm)] = numpy.zeros((1,)).astype('float32')
+        if options['selector']:                                                                          # :276-281
+            params[_p(prefix, 'W_sel')] = norm_weight(dim, 1)
+            params[_p(prefix, 'b_sel')] = numpy.float32(0.)
+        return params
+
+    def init_params(self, options):
+        """model_attention.py:518-581 with encoder == 'none' and n_layers_init == 0."""
+        if options.get('encoder', 'none') not in ('none', None):
+            raise ValueError("encoder must be 'none': the lstm encoder branches of the reference are broken")
+        if options.get('n_layers_init', 0) != 0:
+            raise ValueError('n_layers_init must be 0 (model_attention.py:546-548 uses undefined names)')
+        self._options = dict(options)
+        params = OrderedDict()
+        params['Wemb'] = norm_weight(options['n_words'], options['dim_word'])                            # :522
+        ctxg_dim, ctxl_dim, ctxm_dim = options['ctxg_dim'], options['ctxl_dim'], options['ctxm_dim']
+        params = self.param_init_fflayer(options, params, prefix='ff_state', nin=ctxg_dim, nout=options['dim'])
+        params = self.param_init_fflayer(options, params, prefix='ff_memory', nin=ctxg_dim, nout=options['dim'])
+        params = self.param_init_fflayer(options, params, prefix='ff_local', nin=ctxl_dim, nout=options['dim'])
+        params = self.param_init_fflayer(options, params, prefix='ff_motion', nin=ctxm_dim, nout=options['dim'])
+        params = self.param_init_lstm_cond(options, params, prefix='decoder', nin=options['dim_word'],
+                                           dim=options['dim'], dimctxg=options['dim'], dimctxl=options['dim'],
+                                           dimctxm=options['dim'], dimctxglm=options['dim'])             # :561-563
+        params = self.param_init_fflayer(options, params, prefix='ff_logit_lstm', nin=options['dim'],
+                                         nout=options['dim_word'])
+        if options['ctx2out']:
+            params = self.param_init_fflayer(options, params, prefix='ff_logit_ctxglm',
+                                             nin=options['ctxglm_dim'], nout=options['dim_word'])
+        if options.get('n_layers_out', 1) > 1:
+            raise ValueError('only n_layers_out == 1 is supported')
+        params = self.param_init_fflayer(options, params, prefix='ff_logit', nin=options['dim_word'],
+                                         nout=options['n_words'])
+        return params
+
+    def init_tparams(self, params, force_cpu=False):
+        """model_attention.py:70-78.  `force_cpu` is accepted for signature compatibility; there is
+        no CPU execution path -- the parameters always live in HBM."""
+        tparams = TParams()
+        for kk, pp in params.items():
+            tparams[kk] = common.SharedVar(pp, kk)
+        return tparams
+
+    def _bind(self, tparams, options):
+        """Create the native decoder for these parameters on first use (options arrive only with
+        build_model / build_sampler, exactly like the reference's graph construction)."""
+        if getattr(tparams, 'decoder', None) is not None:
+            return tparams.decoder
+        dec = Decoder(options, device=self.device, stream=self.stream)
+        dec.set_params(OrderedDict((k, v.get_value()) for k, v in tparams.items()))
+        for v in tparams.values():
+            v.bind(dec)
+        tparams.decoder = dec
+        return dec
+
+    # ---------------------------------------------------------------- graphs
+    def build_model(self, tparams, options):
+        """model_attention.py:583-717.  Returns the reference's 16-tuple; the tensors are name tags
+        (see `function`).  `use_noise.set_value(1.)` switches the dropout draws on (:1248)."""
+        dec = self._bind(tparams, options)
+        trng = common.rng_theano
+        use_noise = common.SharedScalar(0., on_change=dec.set_use_noise)
+        names = ('x', 'mask', 'ctxg', 'mask_ctxg', 'ctxl', 'mask_ctxl', 'ctxm', 'mask_ctxm')
+        x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm = [Sym(n) for n in names]
+        alphals, alphags, alphams, alphalts = Sym('alphal'), Sym('alphag'), Sym('alpham'), Sym('alphalt')
+        cost = Sym('cost')
+        extra = [Sym('probs'), alphals, alphags, alphams, alphalts]
+        self._train_decoder = dec
+        return (trng, use_noise, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm,
+                alphals, alphags, alphams, alphalts, cost, extra)
+
+    def function(self, inputs, outputs, tparams=None, **kwargs):
+        """Stand-in for theano.function over build_model's variables, e.g.
+        f_log_probs = function([x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm], -cost) (:1126)
+        f_alphal    = function([...8 inputs...], [alphals, 0.0])                                     (:1167)"""
+        dec = tparams.decoder if tparams is not None else self._train_decoder
+        single = not isinstance(outputs, (list, tuple))
+        outs = [outputs] if single else list(outputs)
+        want_probs = any(isinstance(o, Sym) and o.name == 'probs' for o in outs)
+        want_alpha = any(isinstance(o, Sym) and o.name.startswith('alpha') for o in outs)
+
+        def fn(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
+            dec.set_batch(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm)
+            dec.forward_train()
+            r = dec.get_forward(probs=want_probs, alphas=want_alpha)
+            vals = []
+            for o in outs:
+                if isinstance(o, Sym):
+                    v = r[o.name]
+                    vals.append(-v if o.neg else v)
+                else:
+                    vals.append(o)
+            return vals[0] if single else vals
+        return fn
+
+    def build_sampler(self, tparams, options, use_noise, trng, mode=None):
+        """model_attention.py:719-850 -> (f_init, f_next), same signatures and return orders."""
+        dec = self._bind(tparams, options)
+
+        def f_init(ctxg_0, ctxg_mask):                                      # :791-795
+            return dec.f_init(ctxg_0, ctxg_mask)
+
+        def f_next(x, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, init_state, init_memory):
+            return dec.f_next(x, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask,
+                              init_state, init_memory)                      # :845-848
+        f_next.decoder = dec
+        return f_init, f_next
+
+    # ---------------------------------------------------------------- beam search driver
+    def gen_sample(self, tparams, f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, options,
+                   trng=None, k=1, maxlen=30, stochastic=False, restrict_voc=False):
+        """model_attention.py:852-994, host-side beam search around f_next.  Python-2 integer
+        division at :926 becomes `//`."""
+        if k > 1:
+            assert not stochastic, 'Beam search does not support stochastic sampling'
+        sample = []
+        sample_score = []
+        if stochastic:
+            sample_score = 0
+        live_k = 1
+        dead_k = 0
+        hyp_samples = [[]] * live_k
+        hyp_scores = numpy.zeros(live_k).astype('float32')
+        rval = f_init(ctxg_0, ctxg_mask)
+        ctxg_0 = rval[0]
+        next_state = rval[1].reshape([live_k, rval[1].shape[0]])
+        next_memory = rval[2].reshape([live_k, rval[2].shape[0]])
+        next_w = -1 * numpy.ones((1,)).astype('int64')
+        for ii in range(maxlen):
+            rval = f_next(next_w, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, next_state, next_memory)
+            next_p = rval[0]
+            if restrict_voc:
+                raise NotImplementedError()
+            next_w = rval[1]
+            next_state = rval[2]
+            next_memory = rval[3]
+            if stochastic:
+                sample.append(next_w[0])
+                sample_score += next_p[0, next_w[0]]
+                if next_w[0] == 0:
+                    break
+            else:
+                with numpy.errstate(divide='ignore'):
+                    cand_scores = hyp_scores[:, None] - numpy.log(next_p)
+                cand_flat = cand_scores.flatten()
+                ranks_flat = cand_flat.argsort()[:(k - dead_k)]
+                voc_size = next_p.shape[1]
+                trans_indices = ranks_flat // voc_size
+                word_indices = ranks_flat % voc_size
+                costs = cand_flat[ranks_flat]
+                new_hyp_samples = []
+                new_hyp_scores = numpy.zeros(k - dead_k).astype('float32')
+                new_hyp_states = []
+                new_hyp_memories = []
+                for idx, [ti, wi] in enumerate(zip(trans_indices, word_indices)):
+                    new_hyp_samples.append(hyp_samples[ti] + [int(wi)])
+                    new_hyp_scores[idx] = copy.copy(costs[idx])
+                    new_hyp_states.append(copy.copy(next_state[ti]))
+                    new_hyp_memories.append(copy.copy(next_memory[ti]))
+                new_live_k = 0
+                hyp_samples = []
+                hyp_scores = []
+                hyp_states = []
+                hyp_memories = []
+                for idx in range(len(new_hyp_samples)):
+                    if new_hyp_samples[idx][-1] == 0:
+                        sample.append(new_hyp_samples[idx])
+                        sample_score.append(new_hyp_scores[idx])
+                        dead_k += 1
+                    else:
+                        new_live_k += 1
+                        hyp_samples.append(new_hyp_samples[idx])
+                        hyp_scores.append(new_hyp_scores[idx])
+                        hyp_states.append(new_hyp_states[idx])
+                        hyp_memories.append(new_hyp_memories[idx])
+                hyp_scores = numpy.array(hyp_scores)
+                live_k = new_live_k
+                if new_live_k < 1:
+                    break
+                if dead_k >= k:
+                    break
+                next_w = numpy.array([w[-1] for w in hyp_samples]).astype('int64')
+                next_state = numpy.array(hyp_states)
+                next_memory = numpy.array(hyp_memories)
+        if not stochastic:
+            if live_k > 0:
+                for idx in range(live_k):
+                    sample.append(hyp_samples[idx])
+                    sample_score.append(hyp_scores[idx])
+        return sample, sample_score, next_state, next_memory
+
+    # ---------------------------------------------------------------- teacher-forced scoring
+    def pred_probs(self, batches, f_log_probs, verbose=False):
+        """model_attention.py:996-1032 over an iterable of prepare_data() 8-tuples: mean NLL and
+        perplexity 2 ** (sum NLL / sum L / ln 2)."""
+        probs, NLL, L = [], [], []
+        for (x, mask, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask) in batches:
+            pred = f_log_probs(x, mask, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask)
+            L.append(mask.sum(0).tolist())
+            NLL.append((-1 * pred).tolist())
+            probs.append(pred.tolist())
+        probs = common.flatten_list_of_list(probs)
+        NLL = common.flatten_list_of_list(NLL)
+        L = common.flatten_list_of_list(L)
+        perp = 2 ** (numpy.sum(NLL) / numpy.sum(L) / numpy.log(2))
+        return -1 * numpy.mean(probs), perp

@@ -180,11 +180,12 @@ class Decoder(object):
         return OrderedDict(self._shapes)
 
     def set_param(self, name, value):
-        v = np.ascontiguousarray(np.asarray(value, dtype=np.float32))
+        v = np.asarray(value, dtype=np.float32)
         if name not in self._shapes:
             raise KeyError(name)
         if tuple(v.shape) != self._shapes[name]:
             raise ValueError("%s: shape %s, expected %s" % (name, v.shape, self._shapes[name]))
+        v = np.ascontiguousarray(v).reshape(-1)      # (0-d arrays become 1 element)
         self._chk(self._lib.stattn_set_param(self._h, name.encode(), _fp(v), v.size))
 
     def get_param(self, name):

@@ -1,0 +1,204 @@
+#!/usr/bin/env python
+"""bench.py -- decoder steps/sec (batch x timestep) on MSVD-shaped context, 1/2/4/8 MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+A "step" is one pass of the hot path over one synthetic minibatch that is already resident in
+HBM: the training graph of model_attention.py (build_model, :583-717) on BASELINE.json
+configs[1] -- batch 64 per GPU, T=26 frames, K=8 regions, feat 4096, hidden 1024, E=512, vocab
+12k, caption length 30, fp32.  metric = row-steps/s = rows x timesteps / wall seconds, whole job.
+Rows are sharded over ranks with no data-path collective in the forward pass (weak scaling).
+
+One JSON line is printed by rank 0.  Besides the contract fields it carries
+  roofline     -- the dominant kernel (spatial attention, HBM-bound) timed live with HIP events on
+                  the library's stream: algorithmic bytes per launch / average launch duration
+  cpu_baseline -- the CPU oracle (numpy restatement of the reference graph, `kind: port`) timed on
+                  this box's host cores on a bounded sample of the same workload.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # BASELINE.json configs[1] "Single MI355X" / configs[2] per-GPU shard
+    "c2": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    # configs[0] "MSVD tiny"
+    "c1": dict(B=4, T=26, K=8, F=4096, D=512, E=512, V=12000, t=30),
+    "smoke": dict(B=8, T=6, K=4, F=128, D=128, E=64, V=500, t=5),
+}
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
+
+
+def make_options(c):
+    return dict(dim=c["D"], dim_word=c["E"], n_words=c["V"], ctxg_dim=c["D"], ctxl_dim=c["F"], ctxm_dim=c["F"],
+                ctxglm_dim=c["D"], selector=True, use_dropout=True, prev2out=True, ctx2out=True,
+                n_layers_out=1, n_layers_init=0, encoder="none")
+
+
+def synthetic_batch(c, seed):
+    """RandomState(1234)-seeded N(0,1) features, all-ones masks, captions with
+    lengths ~ U{5..29}, zero padded, mask[:len+1] = 1 (data_engine.py:331-335)."""
+    rng = np.random.RandomState(seed)
+    B, T, K, t = c["B"], c["T"], c["K"], c["t"]
+    x = np.zeros((t, B), np.int64)
+    mask = np.zeros((t, B), np.float32)
+    for b in range(B):
+        ln = t - 1 if b == 0 else rng.randint(min(5, t - 1), t)
+        x[:ln, b] = rng.randint(2, c["V"], size=ln)
+        mask[:ln + 1, b] = 1.0
+    return dict(x=x, mask=mask,
+                ctxg=rng.standard_normal((B, T, c["D"])).astype(np.float32), mask_ctxg=np.ones((B, T), np.float32),
+                ctxl=rng.standard_normal((B, T, K, c["F"])).astype(np.float32), mask_ctxl=np.ones((B, T, K), np.float32),
+                ctxm=rng.standard_normal((B, T, c["F"])).astype(np.float32), mask_ctxm=np.ones((B, T), np.float32))
+
+
+def fast_params(options, seed):
+    """Random-init weights of the architecture with the reference's init *scales* (0.01 N(0,1); the
+    orthogonal blocks are replaced by N(0,1)/sqrt(n), same spectrum scale) -- avoids a dozen 1024^2
+    SVDs per rank at start-up.  The product's init_params reproduces the exact reference init."""
+    from oracle.stattn_oracle import param_shapes      # shape table only (bench is allowed to use oracle/)
+    rng = np.random.RandomState(seed)
+    P = {}
+    for k, shp in param_shapes(options).items():
+        if len(shp) == 2 and shp[0] == shp[1]:
+            P[k] = (rng.standard_normal(shp) / np.sqrt(shp[0])).astype(np.float32)
+        elif k == "decoder_U":
+            P[k] = (rng.standard_normal(shp) / np.sqrt(shp[0])).astype(np.float32)
+        elif len(shp) == 2:
+            P[k] = (0.01 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            P[k] = np.zeros(shp, np.float32)
+    return P
+
+
+def cpu_baseline(c, options, params, seed, budget_s=20.0):
+    """Oracle (kind = port) on host cores: same graph, same shapes, a bounded sample of rows."""
+    from oracle import stattn_oracle as O
+    def run(rows):
+        batch = synthetic_batch(dict(c, B=rows), seed)
+        t0 = time.time()
+        O.build_model_forward(params, options, **batch)
+        return time.time() - t0
+    run(2)                                   # warm-up (BLAS thread pool, page faults)
+    rows = min(8, c["B"])
+    dt = run(rows)
+    rows2 = int(min(c["B"], max(rows, rows * budget_s / max(dt, 1e-3))))
+    if rows2 > rows:                         # grow the sample towards the time budget, at most one batch
+        rows = rows2
+        dt = run(rows)
+    try:
+        import threadpoolctl
+        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+    except Exception:
+        threads = os.cpu_count()
+    return dict(value=rows * c["t"] / dt, unit="row-steps/s", cores=int(threads), kind="port",
+                sample="oracle build_model_forward, float32 numpy (BLAS GEMMs), %d rows x %d steps of the same "
+                       "shapes incl. the once-per-batch F->D projections; %.1f s" % (rows, c["t"], dt))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--lt-mode", type=int, default=None)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libstattn has no CPU path)")
+    torch.cuda.set_device(local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+
+    import stattn
+    c = CONFIGS[args.config]
+    options = make_options(c)
+    params = fast_params(options, 1234)
+    dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode)
+    dec.set_params(params)
+    batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
+    dec.set_batch(**batch)                            # inputs resident in HBM before the timed region
+    dec.set_use_noise(0.0)
+
+    def barrier():
+        dec.sync()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        dec.forward_train()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.forward_train()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+
+    rowsteps = c["B"] * c["t"] * args.steps * world
+    value = rowsteps / dt
+
+    # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
+    dec.set_profiling(True)
+    for _ in range(3):
+        dec.forward_train()
+    kms = dec.kernel_ms()
+    dec.set_profiling(False)
+    B, T, K, D = c["B"], c["T"], c["K"], c["D"]
+    nslab = 3 if dec.lt_mode == 1 else 2              # PL, L (and LW in lt_mode 1)
+    sp_bytes = B * T * D * 4.0 * (nslab * K + 3)      # + PG, PM reads and the CL write
+    sp_ms = kms["spatial"][0]
+    roofline = dict(kernel="spatial_kernel", bound="hbm", achieved=sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms else None,
+                    peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
+                    bytes_per_launch=sp_bytes, ms_per_launch=sp_ms)
+    if roofline["achieved"]:
+        roofline["frac"] = roofline["achieved"] / HBM_PEAK_GBS
+    if args.kernel_breakdown and rank == 0:
+        print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)
+
+    out = dict(metric="decoder steps/sec (batch x timestep)", value=value, unit="row-steps/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="%s: build_model forward (teacher-forced decoder pass: prologue + %d steps + readout + "
+                                    "softmax/NLL), batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
+                                    % (args.config, c["t"], B, T, K, c["F"], D, c["E"], c["V"], dec.lt_mode),
+                           global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world),
+               roofline=roofline,
+               kernel_ms={k: v[0] for k, v in kms.items()})
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(c, options, params, 99)
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

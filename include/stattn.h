@@ -135,6 +135,22 @@ int stattn_get_forward(stattn_handle* h, float* cost, float* probs,
 /* per-step state of the last forward, for tests: hs, cs (t,m,D), ctx (t,m,D) */
 int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx);
 
+/* ---- gradients and optimizer: f_grad_shared / f_update (model_attention.py:1129-1147, 1193-1209;
+ *      common.py:178-195) ------------------------------------------------------------- */
+/* Hand-written BPTT over the last stattn_forward_train: fills the flat gradient buffer (same
+ * layout as the parameters) with d/dtheta of
+ *     nll_scale * sum_b cost[b]  +  alpha_c * sum_{4 alphas} mean_{T(,K)} sum_b (1 - sum_t alpha)^2 .
+ * nll_scale = 1/m reproduces cost.mean() (:1129); a data-parallel rank passes 1/B_global and the
+ * all-reduce SUMS the buffers (the regulariser is a batch sum, :1140-1143).  The L2 term
+ * (:1130-1136) is batch-independent and is applied once, in stattn_update.  lt_mode 1 only. */
+int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c);
+/* value of the loss above + decay_c * sum ||theta||^2, after stattn_backward */
+int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss);
+/* g += 2 decay_c theta; global-norm clip to clip_c (:1194-1203); Adadelta running averages and
+ * parameter update (common.py:183-191; the reference ignores `lr`, Appendix C.8). */
+int stattn_update(stattn_handle* h, float decay_c, float clip_c);
+int stattn_reset_optimizer(stattn_handle* h);
+
 /* ---- kernel-level entry points (used by tests/ and bench.py to check and time the
  *      building blocks in isolation; not part of the reference surface) ------------- */
 /* C[M,N] = act(alpha * op(A).op(B) + bias[n] + add[m,n]);  host pointers.

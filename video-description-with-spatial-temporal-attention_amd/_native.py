@@ -58,6 +58,10 @@ _SIGNATURES = {
     "stattn_forward_train": (C.c_int, [_H]),
     "stattn_get_forward": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F]),
     "stattn_get_states": (C.c_int, [_H, _F, _F, _F]),
+    "stattn_backward": (C.c_int, [_H, C.c_float, C.c_float]),
+    "stattn_get_loss": (C.c_int, [_H, C.c_float, C.c_float, _F]),
+    "stattn_update": (C.c_int, [_H, C.c_float, C.c_float]),
+    "stattn_reset_optimizer": (C.c_int, [_H]),
     "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   _F, _F, _F, _F, C.c_int, _F]),
     "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
@@ -313,6 +317,27 @@ class Decoder(object):
         ctx = np.empty((t, m, self.D), np.float32)
         self._chk(self._lib.stattn_get_states(self._h, _fp(hs), _fp(cs), _fp(ctx)))
         return dict(h=hs, c=cs, ctx=ctx)
+
+    # -- gradients and optimizer (f_grad_shared / f_update)
+    def backward(self, nll_scale=None, alpha_c=0.0):
+        if nll_scale is None:
+            nll_scale = 1.0 / self._batch[1]          # cost.mean()  (model_attention.py:1129)
+        self._chk(self._lib.stattn_backward(self._h, float(nll_scale), float(alpha_c)))
+        self._nll_scale = float(nll_scale)
+
+    def get_loss(self, decay_c=0.0):
+        v = C.c_float()
+        self._chk(self._lib.stattn_get_loss(self._h, self._nll_scale, float(decay_c), C.byref(v)))
+        return v.value
+
+    def get_grads(self):
+        return OrderedDict((k, self.get_grad(k)) for k in self._shapes)
+
+    def update(self, decay_c=0.0, clip_c=0.0):
+        self._chk(self._lib.stattn_update(self._h, float(decay_c), float(clip_c)))
+
+    def reset_optimizer(self):
+        self._chk(self._lib.stattn_reset_optimizer(self._h))
 
     # -- kernel-level entry points
     def gemm(self, A, B, bias=None, add=None, act=0, alpha=1.0, kind=0, transA=False, transB=False):

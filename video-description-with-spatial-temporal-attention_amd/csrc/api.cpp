@@ -66,6 +66,9 @@ struct stattn_handle {
     std::map<std::string, int> pindex;
     float* d_params = nullptr;
     float* d_grads = nullptr;
+    float* d_rg2 = nullptr;      // Adadelta running averages (common.py:180-181), allocated on first update
+    float* d_ru2 = nullptr;
+    bool have_bwd = false;
     size_t nflat = 0;
     Weights w{};
 
@@ -488,6 +491,8 @@ void stattn_destroy(stattn_handle* h) {
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_grads) (void)hipFree(h->d_grads);
+    if (h->d_rg2) (void)hipFree(h->d_rg2);
+    if (h->d_ru2) (void)hipFree(h->d_ru2);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -789,7 +794,7 @@ int stattn_forward_train(stattn_handle* h) {
     CtxPtrs c{};
     c.G = findbuf(h, "G");
     float *mean, *emb, *xproj, *hs, *cs, *hd, *ctx, *csum, *sel, *al, *ag, *am, *alt, *CL, *gates, *sproj, *preh,
-          *eg, *em, *elt, *plt, *z1, *a1, *lg, *pr, *nll, *cost, *dp, *d1, *d2;
+          *eg, *em, *elt, *plt, *z1, *a1, *tz, *lg, *pr, *nll, *cost, *dp, *d1, *d2;
     CHK(getbuf_t(h, "L", (size_t)m * T * K * D, &c.L));
     CHK(getbuf_t(h, "Mo", (size_t)m * T * D, &c.Mo));
     CHK(getbuf_t(h, "PG", (size_t)m * T * D, &c.PG));
@@ -819,6 +824,7 @@ int stattn_forward_train(stattn_handle* h) {
     CHK(getbuf_t(h, "plt", h->opt.lt_mode == 0 ? R * T * D : 1, &plt));
     CHK(getbuf_t(h, "z1", R * E, &z1));
     CHK(getbuf_t(h, "a1", R * E, &a1));
+    CHK(getbuf_t(h, "tz", R * E, &tz));
     CHK(getbuf_t(h, "logits", R * Vp, &lg));
     CHK(getbuf_t(h, "probs", R * Vp, &pr));
     CHK(getbuf_t(h, "nll", R, &nll));
@@ -863,12 +869,13 @@ int stattn_forward_train(stattn_handle* h) {
         g.A = hd; g.lda = D; g.B = w.Wl1; g.ldb = E; g.C = h->opt.ctx2out ? z1 : a1; g.ldc = E;
         g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
-        if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; }
+        if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; g.Cact = tz; g.ldcact = E; }
         HIPCHK(h, launch_gemm(s, g, false, false));
         if (h->opt.ctx2out) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
             gemm_defaults(g);
             g.A = ctx; g.lda = D; g.B = w.Wl2; g.ldb = E; g.C = a1; g.ldc = E;
             g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E;
+            g.Cact = tz; g.ldcact = E;
             HIPCHK(h, launch_gemm(s, g, false, false));
         }
         gemm_defaults(g);      // logit = a.Wo + bo
@@ -911,6 +918,296 @@ int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx) {
     if (cs) HIPCHK(h, hipMemcpyAsync(cs, findbuf(h, "cs") + m * D, R * D * 4, hipMemcpyDeviceToHost, s));
     if (ctx) HIPCHK(h, hipMemcpyAsync(ctx, findbuf(h, "ctx"), R * D * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    return STATTN_OK;
+}
+
+// ---- backward pass, optimizer (model_attention.py:1129-1147, 1193-1203; common.py:178-195) ---------
+int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_fwd) return fail(h, STATTN_ESTATE, "backward: no forward pass has run on the staged batch");
+    if (h->opt.lt_mode != 1) return fail(h, STATTN_EINVAL, "backward is implemented for lt_mode 1 only");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp, Fl = h->Fl, Fm = h->Fm;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)t * m, MT = (size_t)m * T, MTK = MT * K;
+    auto G_ = [&](const char* n) { return h->d_grads + h->params[h->pindex[n]].off; };
+
+    // forward tensors
+    int64_t* dx = (int64_t*)h->bufs["x"].p;
+    float *dmask = findbuf(h, "mask"), *Gc = findbuf(h, "G"), *rawl = findbuf(h, "rawl"), *rawm = findbuf(h, "rawm"),
+          *L = findbuf(h, "L"), *Mo = findbuf(h, "Mo"), *PG = findbuf(h, "PG"), *PL = findbuf(h, "PL"), *PM = findbuf(h, "PM"),
+          *LW = findbuf(h, "LW"), *mean = findbuf(h, "mean"), *emb = findbuf(h, "emb"), *hs = findbuf(h, "hs"),
+          *cs = findbuf(h, "cs"), *hd = findbuf(h, "hd"), *ctx = findbuf(h, "ctx"), *csum = findbuf(h, "csum"),
+          *sel = findbuf(h, "sel"), *al = findbuf(h, "alphal"), *ag = findbuf(h, "alphag"), *am = findbuf(h, "alpham"),
+          *alt = findbuf(h, "alphalt"), *CL = findbuf(h, "CL"), *gates = findbuf(h, "gates"), *sproj = findbuf(h, "sproj"),
+          *a1 = findbuf(h, "a1"), *tz = findbuf(h, "tz"), *lg = findbuf(h, "logits"), *pr = findbuf(h, "probs"),
+          *dp = findbuf(h, "dp"), *d1 = findbuf(h, "d1"), *d2 = findbuf(h, "d2");
+
+    // backward workspaces
+    float *da, *dhd, *dctx_r, *demb, *rg, *rm, *rlt, *rl, *sqg, *sqm, *sqlt, *sql, *UT, *WcT, *WdT, *dpre, *dsproj, *dcsum,
+          *dselpre, *deg, *dem, *delt, *del, *dplt, *dslp, *dc, *dhp0, *dhp1, *dctxP, *dhUP, *dhWP, *dPL, *dL, *dLW, *dPG,
+          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg;
+    const int KZ1 = 8, KZ2 = 16;
+    const size_t WS = (size_t)16 << 20;
+    CHK(getbuf_t(h, "b_da", R * E, &da));
+    CHK(getbuf_t(h, "b_dhd", R * D, &dhd));
+    CHK(getbuf_t(h, "b_dctx_r", R * D, &dctx_r));
+    CHK(getbuf_t(h, "b_demb", R * E, &demb));
+    CHK(getbuf_t(h, "b_rg", MT, &rg)); CHK(getbuf_t(h, "b_rm", MT, &rm)); CHK(getbuf_t(h, "b_rlt", MT, &rlt));
+    CHK(getbuf_t(h, "b_rl", MTK, &rl));
+    CHK(getbuf_t(h, "b_sqg", MT, &sqg)); CHK(getbuf_t(h, "b_sqm", MT, &sqm)); CHK(getbuf_t(h, "b_sqlt", MT, &sqlt));
+    CHK(getbuf_t(h, "b_sql", MTK, &sql));
+    CHK(getbuf_t(h, "b_UT", (size_t)4 * D * D, &UT));
+    CHK(getbuf_t(h, "b_WcT", (size_t)4 * D * D, &WcT));
+    CHK(getbuf_t(h, "b_WdT", (size_t)4 * D * D, &WdT));
+    CHK(getbuf_t(h, "b_dpre", R * 4 * D, &dpre));
+    CHK(getbuf_t(h, "b_dsproj", R * 4 * D, &dsproj));
+    CHK(getbuf_t(h, "b_dcsum", R * D, &dcsum));
+    CHK(getbuf_t(h, "b_dselpre", R, &dselpre));
+    CHK(getbuf_t(h, "b_deg", R * T, &deg)); CHK(getbuf_t(h, "b_dem", R * T, &dem)); CHK(getbuf_t(h, "b_delt", R * T, &delt));
+    CHK(getbuf_t(h, "b_del", R * T * K, &del));
+    CHK(getbuf_t(h, "b_dplt", R * T * D, &dplt));
+    CHK(getbuf_t(h, "b_dslp", MT * D, &dslp));
+    CHK(getbuf_t(h, "b_dc", (size_t)m * D, &dc));
+    CHK(getbuf_t(h, "b_dhp0", (size_t)m * D, &dhp0)); CHK(getbuf_t(h, "b_dhp1", (size_t)m * D, &dhp1));
+    CHK(getbuf_t(h, "b_dctxP", (size_t)KZ1 * m * D, &dctxP));
+    CHK(getbuf_t(h, "b_dhUP", (size_t)KZ1 * m * D, &dhUP));
+    CHK(getbuf_t(h, "b_dhWP", (size_t)KZ2 * m * D, &dhWP));
+    CHK(getbuf_t(h, "b_dPL", MTK * D, &dPL)); CHK(getbuf_t(h, "b_dL", MTK * D, &dL)); CHK(getbuf_t(h, "b_dLW", MTK * D, &dLW));
+    CHK(getbuf_t(h, "b_dPG", MT * D, &dPG)); CHK(getbuf_t(h, "b_dPM", MT * D, &dPM)); CHK(getbuf_t(h, "b_dMo", MT * D, &dMo));
+    CHK(getbuf_t(h, "b_pUl", MT * D, &pUl)); CHK(getbuf_t(h, "b_pUlt", MT * D, &pUlt));
+    CHK(getbuf_t(h, "b_pUg", MT * D, &pUg)); CHK(getbuf_t(h, "b_pUm", MT * D, &pUm));
+    CHK(getbuf_t(h, "b_cpart", (size_t)256 * (size_t)(Vp > 4 * D ? Vp : 4 * D), &cpart));
+    CHK(getbuf_t(h, "b_ws", WS, &ws));
+    CHK(getbuf_t(h, "b_dph0", (size_t)m * D, &dph0)); CHK(getbuf_t(h, "b_dpc0", (size_t)m * D, &dpc0));
+    CHK(getbuf_t(h, "b_lossreg", 4, &lossreg));
+
+    auto gemm = [&](bool tA, bool tB, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kd,
+                    int accumulate, const float* add = nullptr, int ldadd = 0) -> hipError_t {
+        GemmArgs g;
+        gemm_defaults(g);
+        g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = Kd;
+        g.accumulate = accumulate; g.add = add; g.ldadd = ldadd;
+        if (!add) { g.ws = ws; g.ws_floats = WS; }
+        return launch_gemm(s, g, tA, tB);
+    };
+
+    HIPCHK(h, hipMemsetAsync(h->d_grads, 0, h->nflat * sizeof(float), s));
+
+    // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
+    const bool reg = alpha_c > 0.f;
+    if (reg) {
+        HIPCHK(h, launch_alpha_reg(s, ag, rg, sqg, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, am, rm, sqm, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, alt, rlt, sqlt, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, al, rl, sql, t, MTK, alpha_c / (T * K)));
+        HIPCHK(h, launch_sum_all(s, sqg, MT, lossreg, alpha_c / T, 0));
+        HIPCHK(h, launch_sum_all(s, sqm, MT, lossreg, alpha_c / T, 1));
+        HIPCHK(h, launch_sum_all(s, sqlt, MT, lossreg, alpha_c / T, 1));
+        HIPCHK(h, launch_sum_all(s, sql, MTK, lossreg, alpha_c / (T * K), 1));
+    } else {
+        HIPCHK(h, hipMemsetAsync(lossreg, 0, 4 * sizeof(float), s));
+    }
+
+    // ---- softmax / NLL and readout (:687-715), all (t*m) rows at once
+    HIPCHK(h, launch_dlogit(s, pr, Vp, dx, dmask, nll_scale, lg, Vp, (int)R, V, Vp));           // dlogit overwrites logits
+    HIPCHK(h, gemm(true, false, a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R, 0));         // dWo = a^T dlogit
+    HIPCHK(h, launch_colsum(s, lg, Vp, (int)R, Vp, cpart, G_("ff_logit_b"), 0));
+    HIPCHK(h, gemm(false, true, lg, Vp, w.Wo, Vp, da, E, (int)R, E, Vp, 0));                     // da = dlogit Wo^T
+    HIPCHK(h, launch_tanh_bwd(s, da, tz, d2, da, R * E));                                        // dz (in place)
+    float* dz = da;
+    HIPCHK(h, gemm(true, false, hd, D, dz, E, G_("ff_logit_lstm_W"), E, D, E, (int)R, 0));
+    HIPCHK(h, launch_colsum(s, dz, E, (int)R, E, cpart, G_("ff_logit_lstm_b"), 0));
+    HIPCHK(h, gemm(false, true, dz, E, w.Wl1, E, dhd, D, (int)R, D, E, 0));                      // dhd = dz Wl1^T
+    if (h->opt.ctx2out) {
+        HIPCHK(h, gemm(true, false, ctx, D, dz, E, G_("ff_logit_ctxglm_W"), E, D, E, (int)R, 0));
+        HIPCHK(h, launch_colsum(s, dz, E, (int)R, E, cpart, G_("ff_logit_ctxglm_b"), 0));
+        HIPCHK(h, gemm(false, true, dz, E, w.Wl2, E, dctx_r, D, (int)R, D, E, 0));
+    }
+
+    // ---- transposed copies of the recurrent weights for the backward skinny GEMMs
+    HIPCHK(h, launch_transpose(s, w.U, 4 * D, UT, D, D, 4 * D));
+    HIPCHK(h, launch_transpose(s, w.Wc, 4 * D, WcT, D, D, 4 * D));
+    {
+        const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
+        for (int i = 0; i < 4; ++i) HIPCHK(h, launch_transpose(s, Wd[i], D, WdT + (size_t)i * D * D, D, D, D));
+    }
+
+    // ---- reverse scan
+    float* dhp_in = dhp0; float* dhp_out = dhp1;
+    for (int st = t - 1; st >= 0; --st) {
+        const size_t r0 = (size_t)st * m;
+        const bool last = (st == t - 1);
+        {
+            LstmBwdArgs a{};
+            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = KZ1; a.dhW = dhWP; a.nW = KZ2;
+            a.dselpre = dselpre + (r0 + m); a.W_sel = h->opt.selector ? w.W_sel : nullptr;
+            a.dhd = dhd + r0 * D; a.d1 = d1 + r0 * D; a.gates = gates + r0 * 4 * D;
+            a.c_prev = cs + r0 * D; a.c_new = cs + (r0 + m) * D; a.mask = dmask + r0; a.dp = dp + r0 * 3 * D;
+            a.dc = dc; a.dpre = dpre + r0 * 4 * D; a.dh_pass_out = dhp_out; a.M = m; a.D = D; a.last = last ? 1 : 0;
+            HIPCHK(h, launch_lstm_bwd(s, a));
+        }
+        {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
+            SkArgs a{};
+            a.M = m; a.nseg = 2; a.kz = KZ1; a.part_stride = (size_t)m * D;
+            for (int i = 0; i < 2; ++i) {
+                SkSeg& sg = a.seg[i];
+                skinny_seg_defaults(sg);
+                sg.npairs = 1; sg.p[0] = SkPair{dpre + r0 * 4 * D, i == 0 ? WcT : UT, 4 * D, D, 4 * D};
+                sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
+            }
+            HIPCHK(h, launch_skinny(s, a));
+        }
+        {
+            TemporalBwdArgs a{};
+            a.dctxP = dctxP; a.nP = KZ1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
+            a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.PG = PG; a.PM = PM; a.CL = CL + r0 * T * D;
+            a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
+            a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T;
+            a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
+            a.Ug = w.Ug; a.Um = w.Um; a.has_sel = h->opt.selector ? 1 : 0;
+            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0;
+            a.deg = deg + r0 * T; a.dem = dem + r0 * T; a.delt = delt + r0 * T;
+            a.dsproj = dsproj + r0 * 4 * D; a.lddsp = 4 * D; a.M = m; a.T = T; a.D = D;
+            HIPCHK(h, launch_temporal_bwd(s, a));
+        }
+        {
+            SpatialBwdArgs a{};
+            a.PL = PL; a.L = L; a.LW = LW; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
+            a.dcsum = dcsum + r0 * D; a.alphal = al + r0 * T * K; a.alt = alt + r0 * T; a.delt = delt + r0 * T;
+            a.rl = reg ? rl : nullptr; a.Ul = w.Ul; a.Ult = w.Ult; a.blt = w.blt;
+            a.dplt = dplt + r0 * T * D; a.del = del + r0 * T * K; a.dslp = dslp; a.M = m; a.T = T; a.K = K; a.D = D;
+            HIPCHK(h, launch_spatial_bwd(s, a));
+        }
+        HIPCHK(h, launch_reduce_T(s, dslp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D));
+        {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
+            SkArgs a{};
+            a.M = m; a.nseg = 1; a.kz = KZ2; a.part_stride = (size_t)m * D;
+            SkSeg& sg = a.seg[0];
+            skinny_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = SkPair{dsproj + r0 * 4 * D, WdT, 4 * D, D, 4 * D};
+            sg.C = dhWP; sg.ldc = D; sg.N = D;
+            HIPCHK(h, launch_skinny(s, a));
+        }
+        float* tmp = dhp_in; dhp_in = dhp_out; dhp_out = tmp;
+    }
+    // gradient wrt the initial state -> ff_state / ff_memory (:657-660)
+    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, KZ1, dhWP, KZ2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
+                                dph0, dpc0, m, D));
+    HIPCHK(h, gemm(true, false, mean, D, dph0, D, G_("ff_state_W"), D, D, D, m, 0));
+    HIPCHK(h, launch_colsum(s, dph0, D, m, D, cpart, G_("ff_state_b"), 0));
+    HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
+    HIPCHK(h, launch_colsum(s, dpc0, D, m, D, cpart, G_("ff_memory_b"), 0));
+
+    // ---- deferred context gradients
+    {
+        CtxGradArgs a{};
+        a.PL = PL; a.LW = LW; a.PG = PG; a.PM = PM; a.sproj = sproj; a.dcsum = dcsum; a.dplt = dplt;
+        a.alphal = al; a.del = del; a.alt = alt; a.delt = delt; a.am = am; a.deg = deg; a.dem = dem;
+        a.Ul = w.Ul; a.Ult = w.Ult; a.Ug = w.Ug; a.Um = w.Um; a.blt = w.blt;
+        a.dPL = dPL; a.dL = dL; a.dLW = dLW; a.dPG = dPG; a.dPM = dPM; a.dMo = dMo;
+        a.pUl = pUl; a.pUlt = pUlt; a.pUg = pUg; a.pUm = pUm; a.S = t; a.M = m; a.T = T; a.K = K; a.D = D;
+        HIPCHK(h, launch_ctxgrad(s, a));
+    }
+    HIPCHK(h, launch_colsum(s, pUl, D, (int)MT, D, cpart, G_("decoder_Ul_att"), 0));
+    HIPCHK(h, launch_colsum(s, pUlt, D, (int)MT, D, cpart, G_("decoder_Ult_att"), 0));
+    HIPCHK(h, launch_colsum(s, pUg, D, (int)MT, D, cpart, G_("decoder_Ug_att"), 0));
+    HIPCHK(h, launch_colsum(s, pUm, D, (int)MT, D, cpart, G_("decoder_Um_att"), 0));
+    HIPCHK(h, launch_sum_all(s, del, R * T * K, G_("decoder_cl_att"), 1.f, 0));
+    HIPCHK(h, launch_sum_all(s, delt, R * T, G_("decoder_clt_att"), 1.f, 0));
+    HIPCHK(h, launch_sum_all(s, deg, R * T, G_("decoder_cg_att"), 1.f, 0));
+    HIPCHK(h, launch_sum_all(s, dem, R * T, G_("decoder_cm_att"), 1.f, 0));
+    HIPCHK(h, launch_colsum(s, dplt, D, (int)(R * T), D, cpart, G_("decoder_blt_att"), 0));
+    if (h->opt.selector) {
+        HIPCHK(h, launch_wsum_rows(s, dselpre, hs, D, (int)R, D, G_("decoder_W_sel")));
+        HIPCHK(h, launch_sum_all(s, dselpre, R, G_("decoder_b_sel"), 1.f, 0));
+    }
+    // attention pre-projections (:322-326) and the hoisted L.Wclt
+    HIPCHK(h, gemm(true, false, L, D, dPL, D, G_("decoder_Wcl_att"), D, D, D, (int)MTK, 0));
+    HIPCHK(h, launch_colsum(s, dPL, D, (int)MTK, D, cpart, G_("decoder_bl_att"), 0));
+    HIPCHK(h, gemm(true, false, L, D, dLW, D, G_("decoder_Wclt_att"), D, D, D, (int)MTK, 0));
+    HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
+    HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+    HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));                                  // L = tanh(ff_local) (:664-665)
+    HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
+    HIPCHK(h, launch_colsum(s, dL, D, (int)MTK, D, cpart, G_("ff_local_b"), 0));
+    HIPCHK(h, gemm(true, false, Gc, D, dPG, D, G_("decoder_Wcg_att"), D, D, D, (int)MT, 0));
+    HIPCHK(h, launch_colsum(s, dPG, D, (int)MT, D, cpart, G_("decoder_bg_att"), 0));
+    HIPCHK(h, gemm(true, false, Mo, D, dPM, D, G_("decoder_Wcm_att"), D, D, D, (int)MT, 0));
+    HIPCHK(h, launch_colsum(s, dPM, D, (int)MT, D, cpart, G_("decoder_bm_att"), 0));
+    HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
+    HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));                                // M = tanh(ff_motion) (:666-667)
+    HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
+    HIPCHK(h, launch_colsum(s, dMo, D, (int)MT, D, cpart, G_("ff_motion_b"), 0));
+    // recurrent weights: one batched TN GEMM over all (t*m) rows each
+    HIPCHK(h, gemm(true, false, hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R, 0));
+    HIPCHK(h, gemm(true, false, ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R, 0));
+    {
+        const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
+        for (int i = 0; i < 4; ++i)
+            HIPCHK(h, gemm(true, false, hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), D, D, D, (int)R, 0));
+    }
+    HIPCHK(h, gemm(true, false, emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R, 0));
+    HIPCHK(h, launch_colsum(s, dpre, 4 * D, (int)R, 4 * D, cpart, G_("decoder_b"), 0));
+    // embedding: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
+    HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, 0, h->opt.prev2out ? dz : nullptr, E));
+    HIPCHK(h, launch_embed_bwd(s, dx, demb, G_("Wemb"), (int)R, E, V, m));
+    h->have_bwd = true;
+    return STATTN_OK;
+}
+
+int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss) {
+    if (!h || !loss) return STATTN_EINVAL;
+    if (!h->have_bwd) return fail(h, STATTN_ESTATE, "get_loss: call stattn_backward first (it evaluates the regulariser)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<float> cost(h->m);
+    float regv = 0.f, p2 = 0.f;
+    float *part, *sc;
+    CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
+    CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
+    if (decay_c > 0.f) {   // decay_c * sum ||theta||^2 (:1130-1136); two_decay = 0 leaves the buffer unchanged
+        HIPCHK(h, launch_decay_sumsq(s, h->d_params, h->d_params, 0.f, h->nflat, part, 1024));
+        HIPCHK(h, launch_sum_all(s, part, 1024, sc, 1.f, 0));
+        HIPCHK(h, hipMemcpyAsync(&p2, sc, sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipMemcpyAsync(cost.data(), findbuf(h, "cost"), (size_t)h->m * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(&regv, findbuf(h, "b_lossreg"), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    double tot = 0.0;
+    for (float c : cost) tot += c;
+    *loss = (float)(nll_scale * tot + regv + (double)decay_c * p2);
+    return STATTN_OK;
+}
+
+int stattn_update(stattn_handle* h, float decay_c, float clip_c) {
+    if (!h) return STATTN_EINVAL;
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (!h->d_rg2) {
+        HIPCHK(h, hipMalloc((void**)&h->d_rg2, h->nflat * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&h->d_ru2, h->nflat * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->d_rg2, 0, h->nflat * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(h->d_ru2, 0, h->nflat * sizeof(float), s));
+    }
+    float *part, *sc;
+    CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
+    CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
+    // g += 2 decay_c theta (:1130-1136); ||g||^2 in a fixed two-stage order; clip + Adadelta in one pass
+    HIPCHK(h, launch_decay_sumsq(s, h->d_grads, h->d_params, 2.f * decay_c, h->nflat, part, 1024));
+    HIPCHK(h, launch_sum_all(s, part, 1024, sc, 1.f, 0));
+    HIPCHK(h, launch_adadelta(s, h->d_params, h->d_grads, h->d_rg2, h->d_ru2, h->nflat, sc, clip_c));
+    h->ck_valid = false; h->have_fwd = false; h->have_bwd = false;
+    return STATTN_OK;
+}
+
+int stattn_reset_optimizer(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    if (h->d_rg2) {
+        HIPCHK(h, hipMemsetAsync(h->d_rg2, 0, h->nflat * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_ru2, 0, h->nflat * sizeof(float), h->stream));
+    }
     return STATTN_OK;
 }
 

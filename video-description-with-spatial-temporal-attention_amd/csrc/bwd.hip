@@ -1,0 +1,598 @@
+// Backward pass (BPTT) kernels of the decoder for gfx950 -- what the reference obtains from
+// `tensor.grad(cost, wrt=itemlist(tparams))` (model_attention.py:1193) over the graph of
+// build_model (:583-717) + the loss terms (:1129-1147).  lt_mode 1 only.
+//
+// Structure.  Inside the reverse time loop only what the recurrence needs is computed:
+//   lstm_bwd  -> dpre (gate pre-activation grads), carried dc, pass-through dh
+//   [skinny GEMM: dctx = dpre.Wc^T, dhU = dpre.U^T]
+//   temporal_bwd -> dcsum, selector grad, the three temporal softmax backwards, dsg/dsm
+//   spatial_bwd  -> dplt, spatial softmax backward (del), per-frame dsl
+//   reduce_T     -> dsl, dslt summed over frames
+//   [skinny GEMM: dhW = dsproj.[Wdl|Wdg|Wdm|Wdlt]^T]
+// Every gradient that accumulates over time WITHOUT feeding the recurrence (dPL, dL, dLW, dPG, dPM,
+// dMo, the U*_att vectors and all weight matrices) is deferred: the per-step factors (del, deg, dem,
+// dplt, dcsum, dpre, dsproj) are stored -- HBM is 288 GB -- and ctxgrad_kernel / batched MFMA GEMMs
+// consume them once after the loop, instead of a read-modify-write of 54 MB tensors in every step.
+#include "kernels.h"
+#include "devmath.h"
+
+namespace stattn {
+
+namespace {
+
+constexpr int KMAX = 64;
+constexpr int TMAX = 256;
+
+template <int N>
+__device__ __forceinline__ void block_sum(float (&v)[N], float* s_red /*[nwaves][N]*/, int tid, int nwaves) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float r = wave_sum(v[i]);
+        if (lane == 0) s_red[w * N + i] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float r = 0.f;
+        for (int k = 0; k < nwaves; ++k) r += s_red[k * N + i];
+        v[i] = r;
+    }
+    __syncthreads();
+}
+
+__device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
+__device__ __forceinline__ float4 tanh4s(float4 x, float4 s) {
+    return make_float4(fast_tanh(x.x + s.x), fast_tanh(x.y + s.y), fast_tanh(x.z + s.z), fast_tanh(x.w + s.w));
+}
+__device__ __forceinline__ float4 one_minus_sq(float4 t) {
+    return make_float4(1.f - t.x * t.x, 1.f - t.y * t.y, 1.f - t.z * t.z, 1.f - t.w * t.w);
+}
+__device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
+__device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
+__device__ __forceinline__ void fma4(float4& acc, float s, float4 v) { acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w; }
+__device__ __forceinline__ void add4(float4& acc, float4 v) { acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w; }
+
+// ---------------------------------------------------------------------------------------------
+// d(loss)/d(logit) for the masked NLL with the +1e-8 inside the log (:712):
+//   dlogit[r,j] = w_r (p_j - [j == x_r]),  w_r = nll_scale * mask_r * p_x / (p_x + 1e-8);  pad columns = 0
+__global__ __launch_bounds__(256) void dlogit_kernel(const float* __restrict__ probs, int ldp, const int64_t* __restrict__ x,
+                                                     const float* __restrict__ mask, float nll_scale,
+                                                     float* __restrict__ dl, int ldd, int V, int Vp) {
+    const int r = blockIdx.x;
+    int64_t xi = x[r];
+    xi = xi < 0 ? 0 : (xi >= V ? V - 1 : xi);
+    const float* p = probs + (size_t)r * ldp;
+    const float px = p[xi];
+    const float w = nll_scale * mask[r] * px / (px + 1e-8f);
+    float* d = dl + (size_t)r * ldd;
+    for (int j = threadIdx.x; j < Vp; j += 256) {
+        float v = 0.f;
+        if (j < V) v = w * (p[j] - (j == (int)xi ? 1.f : 0.f));
+        d[j] = v;
+    }
+}
+
+// r tensors of the doubly-stochastic regulariser (:1140-1147): d/d alpha[s,...] = -2 alpha_c / n * (1 - sum_s alpha)
+__global__ void alpha_reg_kernel(const float* __restrict__ alpha, float* __restrict__ r, float* __restrict__ sq,
+                                 int steps, size_t n, float coef) {
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    float s = 0.f;
+    for (int t = 0; t < steps; ++t) s += alpha[(size_t)t * n + i];
+    r[i] = -2.f * coef * (1.f - s);
+    if (sq) sq[i] = (1.f - s) * (1.f - s);
+}
+
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
+    const int D = a.D;
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)a.M * D) return;
+    const int b = (int)(idx / D), d = (int)(idx % D);
+    const size_t MD = (size_t)a.M * D;
+    float dh = 0.f;
+    if (!a.last) {
+        dh = a.dh_pass[idx];
+        for (int p = 0; p < a.nU; ++p) dh += a.dhU[(size_t)p * MD + idx];
+        for (int p = 0; p < a.nW; ++p) dh += a.dhW[(size_t)p * MD + idx];
+        if (a.W_sel) dh += a.dselpre[b] * a.W_sel[d];
+    }
+    dh += a.dhd[idx] * a.d1[idx];                                   // hd = h * d1  (:684-685)
+    const float* gt = a.gates + (size_t)b * 4 * D + d;
+    const float gi = gt[0], gf = gt[D], go = gt[2 * D], gg = gt[3 * D];
+    const float cp = a.c_prev[idx], cn = a.c_new[idx], m = a.mask[b];
+    const float tc = fast_tanh(cn);
+    const float dcn = (a.last ? 0.f : a.dc[idx]) + m * dh * go * (1.f - tc * tc);   // h = m o tanh(c) + (1-m) h_ (:456-457)
+    const float dct = m * dcn;                                      // c = m (f c_ + i g) + (1-m) c_   (:453-454)
+    a.dc[idx] = (1.f - m) * dcn + dct * gf;
+    const float* dp = a.dp + (size_t)b * 3 * D;
+    float* o = a.dpre + (size_t)b * 4 * D + d;
+    o[0] = dct * gg * gi * (1.f - gi) * dp[d];                      // i = sigma(pre_i * dp_i) (:445-448)
+    o[D] = dct * cp * gf * (1.f - gf) * dp[D + d];
+    o[2 * D] = m * dh * tc * go * (1.f - go) * dp[2 * D + d];
+    o[3 * D] = dct * gi * (1.f - gg * gg);
+    a.dh_pass_out[idx] = (1.f - m) * dh;
+}
+
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void temporal_bwd_kernel(const TemporalBwdArgs a) {
+    __shared__ float s_red[4 * 24];
+    __shared__ float s_da[3][TMAX];
+    const int T = a.T, D = a.D, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int nd4 = D >> 2;
+    const size_t MD = (size_t)a.M * D;
+    const float sel = a.has_sel ? a.sel[b] : 1.f;
+
+    // dctx (sum of GEMM partials + readout term), selector backward, dcsum
+    float ps[1] = {0.f};
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const size_t o = (size_t)b * D + 4 * d4;
+        float4 dc = a.dctx_r ? ld4(a.dctx_r + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int p = 0; p < a.nP; ++p) add4(dc, ld4(a.dctxP + (size_t)p * MD + o));
+        ps[0] += dot4(dc, ld4(a.csum + o));
+        st4(a.dcsum + o, scale4(dc, sel));                                 // ctx = sel * csum (:435)
+    }
+    block_sum<1>(ps, s_red, tid, 4);
+    if (tid == 0) a.dselpre[b] = a.has_sel ? ps[0] * sel * (1.f - sel) : 0.f;
+    __syncthreads();   // dcsum of this block is re-read below by other threads of the block
+
+    // d alpha = <dcsum, X_t> (+ regulariser), 8 frames per reduction round
+    for (int t0 = 0; t0 < T; t0 += 8) {
+        float p[24];
+#pragma unroll
+        for (int i = 0; i < 24; ++i) p[i] = 0.f;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const float4 dc = ld4(a.dcsum + (size_t)b * D + 4 * d4);
+#pragma unroll
+            for (int tt = 0; tt < 8; ++tt) {
+                const int t = min(t0 + tt, T - 1);
+                const size_t o = ((size_t)b * T + t) * D + 4 * d4;
+                p[tt] += dot4(dc, ld4(a.G + o));
+                p[8 + tt] += dot4(dc, ld4(a.Mo + o));
+                p[16 + tt] += dot4(dc, ld4(a.CL + o));
+            }
+        }
+        block_sum<24>(p, s_red, tid, 4);
+        if (tid < 24) {
+            const int which = tid >> 3, t = t0 + (tid & 7);
+            if (t < T) {
+                const float* r = which == 0 ? a.rg : (which == 1 ? a.rm : a.rlt);
+                s_da[which][t] = p[tid] + (r ? r[(size_t)b * T + t] : 0.f);
+            }
+        }
+        __syncthreads();
+    }
+    // softmax backward, one wave per attention: de_t = alpha_t (dalpha_t - sum alpha dalpha)
+    if (w < 3) {
+        const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
+        float dotp = 0.f;
+        for (int t = lane; t < T; t += 64) dotp += al[t] * s_da[w][t];
+        dotp = wave_sum(dotp);
+        float* out = (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt)) + (size_t)b * T;
+        for (int t = lane; t < T; t += 64) {
+            const float de = al[t] * (s_da[w][t] - dotp);
+            s_da[w][t] = de;
+            out[t] = de;
+        }
+    }
+    __syncthreads();
+    // dsg = sum_t deg_t Ug (1 - tanh^2(PG_t + sg)), same for motion
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const float4 sg = ld4(a.sproj + (size_t)b * a.ldsp + D + 4 * d4), sm = ld4(a.sproj + (size_t)b * a.ldsp + 2 * D + 4 * d4);
+        float4 ag4 = make_float4(0.f, 0.f, 0.f, 0.f), am4 = ag4;
+#pragma unroll 4
+        for (int t = 0; t < T; ++t) {
+            const size_t o = ((size_t)b * T + t) * D + 4 * d4;
+            fma4(ag4, s_da[0][t], one_minus_sq(tanh4s(ld4(a.PG + o), sg)));
+            fma4(am4, s_da[1][t], one_minus_sq(tanh4s(ld4(a.PM + o), sm)));
+        }
+        st4(a.dsproj + (size_t)b * a.lddsp + D + 4 * d4, mul4(ag4, ld4(a.Ug + 4 * d4)));
+        st4(a.dsproj + (size_t)b * a.lddsp + 2 * D + 4 * d4, mul4(am4, ld4(a.Um + 4 * d4)));
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+
+__global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a) {
+    __shared__ float s_red[4 * 8];
+    __shared__ float s_al[KMAX], s_da[KMAX];
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
+    const size_t slab = (size_t)bt * K * D;
+    const float* __restrict__ PL = a.PL + slab;
+    const float* __restrict__ L = a.L + slab;
+    const float* __restrict__ LW = a.LW + slab;
+    const float* __restrict__ sp = a.sproj + (size_t)b * a.ldsp;
+    const int nd4 = D >> 2;
+    if (tid < K) s_al[tid] = a.alphal[(size_t)bt * K + tid];
+    __syncthreads();
+    const float alt = a.alt[bt], delt = a.delt[bt];
+
+    // pass 1: recompute plt = sum_k alpha_k LW_k + blt, dplt = delt Ult (1 - tanh^2(plt + slt))  (:416-422)
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        float4 pl = ld4(a.blt + 4 * d4);
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) fma4(pl, s_al[k], ld4(LW + (size_t)k * D + 4 * d4));
+        const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
+        st4(a.dplt + (size_t)bt * D + 4 * d4, scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt));
+    }
+    __syncthreads();
+    // pass 2: dalpha_k = <alt dcsum, L_k> + <dplt, LW_k> + r_k     (CL = sum alpha L :383; plt as above)
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float p[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) p[i] = 0.f;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
+            const float4 dpl = ld4(a.dplt + (size_t)bt * D + 4 * d4);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const size_t o = (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
+                p[kk] += dot4(dcl, ld4(L + o)) + dot4(dpl, ld4(LW + o));
+            }
+        }
+        block_sum<8>(p, s_red, tid, 4);
+        if (tid < 8 && k0 + tid < K) s_da[k0 + tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + k0 + tid] : 0.f);
+        __syncthreads();
+    }
+    // softmax backward over the K regions
+    float dotp = 0.f;
+    for (int k = 0; k < K; ++k) dotp += s_al[k] * s_da[k];
+    __syncthreads();
+    if (tid < K) {
+        const float de = s_al[tid] * (s_da[tid] - dotp);
+        s_da[tid] = de;
+        a.del[(size_t)bt * K + tid] = de;
+    }
+    __syncthreads();
+    // pass 3: dsl (this frame) = sum_k del_k Ul (1 - tanh^2(PL_k + sl))
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const float4 sl = ld4(sp + 4 * d4);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) fma4(acc, s_da[k], one_minus_sq(tanh4s(ld4(PL + (size_t)k * D + 4 * d4), sl)));
+        st4(a.dslp + (size_t)bt * D + 4 * d4, mul4(acc, ld4(a.Ul + 4 * d4)));
+    }
+}
+
+// dsproj[b, 0:D] = sum_t dslp[b,t,:],  dsproj[b, 3D:4D] = sum_t dplt[b,t,:]
+__global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__ dslp, const float* __restrict__ dplt,
+                                                       float* __restrict__ dsproj, int lddsp, int T, int D) {
+    const int b = blockIdx.x, d4 = blockIdx.y * 256 + threadIdx.x;
+    if (d4 >= (D >> 2)) return;
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+#pragma unroll 4
+    for (int t = 0; t < T; ++t) {
+        const size_t o = ((size_t)b * T + t) * D + 4 * d4;
+        add4(s1, ld4(dslp + o));
+        add4(s2, ld4(dplt + o));
+    }
+    st4(dsproj + (size_t)b * lddsp + 4 * d4, s1);
+    st4(dsproj + (size_t)b * lddsp + 3 * D + 4 * d4, s2);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Deferred context gradients, one workgroup per (row b, frame t), looping over the time steps:
+//   dPL[k,:] = sum_s del[s,k] Ul (1 - tanh^2(PL_k + sl_s))        dL[k,:]  = sum_s alpha_l[s,k] alt_s dcsum_s
+//   dLW[k,:] = sum_s alpha_l[s,k] dplt_s                           dPG = sum_s deg_s Ug (1 - tanh^2(PG + sg_s)), dPM likewise
+//   dMo      = sum_s am_s dcsum_s
+// and the per-(b,t) partials of dUl, dUlt, dUg, dUm (summed over rows by colsum afterwards).
+
+__global__ __launch_bounds__(256) void ctxgrad_kernel(const CtxGradArgs a) {
+    const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
+    const int nd4 = D >> 2;
+    const size_t slab = (size_t)bt * K * D, MT = (size_t)M * T;
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const float4 ul = ld4(a.Ul + 4 * d4), blt = ld4(a.blt + 4 * d4);
+        // frame-level tensors
+        {
+            const size_t fo = (size_t)bt * D + 4 * d4;
+            const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
+            float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg;
+            for (int s = 0; s < S; ++s) {
+                const float* sp = a.sproj + ((size_t)s * M + b) * 4 * D;
+                const float deg = a.deg[s * MT + bt], dem = a.dem[s * MT + bt], am = a.am[s * MT + bt];
+                const float4 tg = tanh4s(pg, ld4(sp + D + 4 * d4)), tm = tanh4s(pm, ld4(sp + 2 * D + 4 * d4));
+                fma4(dpg, deg, one_minus_sq(tg)); fma4(ug, deg, tg);
+                fma4(dpm, dem, one_minus_sq(tm)); fma4(um, dem, tm);
+                fma4(dmo, am, ld4(a.dcsum + ((size_t)s * M + b) * D + 4 * d4));
+            }
+            st4(a.dPG + fo, mul4(dpg, ld4(a.Ug + 4 * d4)));
+            st4(a.dPM + fo, mul4(dpm, ld4(a.Um + 4 * d4)));
+            st4(a.dMo + fo, dmo);
+            st4(a.pUg + fo, ug);
+            st4(a.pUm + fo, um);
+        }
+        // region-level tensors, 8 regions at a time
+        float4 pul = make_float4(0.f, 0.f, 0.f, 0.f), pult = pul;
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float4 pl[8], lw[8], dpl[8], dl[8], dlw[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const size_t o = slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
+                pl[kk] = ld4(a.PL + o); lw[kk] = ld4(a.LW + o);
+                dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
+            }
+            for (int s = 0; s < S; ++s) {
+                const float* sp = a.sproj + ((size_t)s * M + b) * 4 * D;
+                const float4 sl = ld4(sp + 4 * d4);
+                const float4 dcl = scale4(ld4(a.dcsum + ((size_t)s * M + b) * D + 4 * d4), a.alt[s * MT + bt]);
+                const float4 dp = ld4(a.dplt + (s * MT + bt) * D + 4 * d4);
+                const float* als = a.alphal + (s * MT + bt) * K;
+                const float* des = a.del + (s * MT + bt) * K;
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const int k = min(k0 + kk, K - 1);
+                    const float al = als[k], de = des[k];
+                    const float4 th = tanh4s(pl[kk], sl);
+                    fma4(dpl[kk], de, one_minus_sq(th));
+                    if (k0 + kk < K) fma4(pul, de, th);
+                    fma4(dl[kk], al, dcl);
+                    fma4(dlw[kk], al, dp);
+                }
+                if (k0 == 0) {   // dUlt partial: delt * tanh(plt + slt), plt recomputed from LW (needs all K; K <= 8 fast path)
+                    if (K <= 8) {
+                        float4 plt = blt;
+#pragma unroll
+                        for (int kk = 0; kk < 8; ++kk) if (kk < K) fma4(plt, als[kk], lw[kk]);
+                        fma4(pult, a.delt[s * MT + bt], tanh4s(plt, ld4(sp + 3 * D + 4 * d4)));
+                    } else {
+                        float4 plt = blt;
+                        for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
+                        fma4(pult, a.delt[s * MT + bt], tanh4s(plt, ld4(sp + 3 * D + 4 * d4)));
+                    }
+                }
+            }
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                if (k0 + kk < K) {
+                    const size_t o = slab + (size_t)(k0 + kk) * D + 4 * d4;
+                    st4(a.dPL + o, mul4(dpl[kk], ul));
+                    st4(a.dL + o, dl[kk]);
+                    st4(a.dLW + o, dlw[kk]);
+                }
+            }
+        }
+        st4(a.pUl + (size_t)bt * D + 4 * d4, pul);
+        st4(a.pUlt + (size_t)bt * D + 4 * d4, pult);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// column sums with a fixed two-stage order: part[rs][n] = sum over a row range; then dst[n] (+)= sum_rs part
+__global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int ldx, int rows, int N,
+                                                          float* __restrict__ part, int rsplit) {
+    __shared__ float s[4][64];
+    const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, rs = blockIdx.y;
+    const int per = (rows + rsplit - 1) / rsplit;
+    const int r0 = rs * per, r1 = min(rows, r0 + per);
+    float acc = 0.f;
+    if (n < N)
+        for (int r = r0 + w; r < r1; r += 4) acc += X[(size_t)r * ldx + n];
+    s[w][threadIdx.x & 63] = acc;
+    __syncthreads();
+    if (w == 0 && n < N) part[(size_t)rs * N + n] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
+}
+__global__ void colsum_final_kernel(const float* __restrict__ part, int rsplit, int N, float* __restrict__ dst, int accumulate) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int r = 0; r < rsplit; ++r) acc += part[(size_t)r * N + n];
+    dst[n] = accumulate ? dst[n] + acc : acc;
+}
+// dst[0] (+)= scale * sum(x[0:n])   (single block, deterministic)
+__global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ x, size_t n, float* __restrict__ dst, float scale, int accumulate) {
+    __shared__ float s[16];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (int i = 0; i < 16; ++i) r += s[i];
+        dst[0] = accumulate ? dst[0] + scale * r : scale * r;
+    }
+}
+// dst[j] = sum_b v[b] * X[b, j]   (dW_sel = h_prev^T . dselpre over all (s,b) rows)
+__global__ __launch_bounds__(256) void wsum_rows_kernel(const float* __restrict__ v, const float* __restrict__ X, int ldx,
+                                                        int rows, int N, float* __restrict__ dst) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    float acc = 0.f;
+    for (int r = 0; r < rows; ++r) acc += v[r] * X[(size_t)r * ldx + n];
+    dst[n] = acc;
+}
+
+// y = dy * (1 - t^2) [* mulmat]  elementwise (tanh backward), in place allowed
+__global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, const float* __restrict__ mul,
+                                float* __restrict__ out, size_t n4) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = mul4(ld4(dy + 4 * i), one_minus_sq(ld4(t + 4 * i)));
+        if (mul) v = mul4(v, ld4(mul + 4 * i));
+        st4(out + 4 * i, v);
+    }
+}
+// out[i] (+)= a[i] (+ b[i])
+__global__ void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, size_t n4, int accumulate) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 v = ld4(a + 4 * i);
+        if (b) add4(v, ld4(b + 4 * i));
+        if (accumulate) add4(v, ld4(out + 4 * i));
+        st4(out + 4 * i, v);
+    }
+}
+// dWemb[x[r - shift], :] += demb[r, :]  for r >= shift   (embedding lookup backward, :613-617)
+__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ demb,
+                                                        float* __restrict__ dWemb, int rows, int E, int V, int shift) {
+    const int r = blockIdx.x + shift;
+    if (r >= rows) return;
+    int64_t w = x[r - shift];
+    if (w < 0 || w >= V) return;
+    for (int e = threadIdx.x; e < E; e += 256) atomicAdd(dWemb + (size_t)w * E + e, demb[(size_t)r * E + e]);
+}
+// out[c, r] = in[r, c]   (weight transposes for the backward skinny GEMMs), 32x32 LDS tiles
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
+                                                        int rows, int cols) {
+    __shared__ float tile[32][33];
+    const int c0 = blockIdx.x * 32, r0 = blockIdx.y * 32, tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    for (int i = ty; i < 32; i += 8)
+        if (r0 + i < rows && c0 + tx < cols) tile[i][tx] = in[(size_t)(r0 + i) * ldi + c0 + tx];
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8)
+        if (c0 + i < cols && r0 + tx < rows) out[(size_t)(c0 + i) * ldo + r0 + tx] = tile[tx][i];
+}
+
+// ---------------------------------------------------------------------------------------------
+// optimizer: L2 decay into the gradient + sum of squares (two-stage), then clip + Adadelta (common.py:178-195)
+__global__ __launch_bounds__(256) void decay_sumsq_kernel(float* __restrict__ g, const float* __restrict__ p, float two_decay,
+                                                          size_t n, float* __restrict__ part) {
+    __shared__ float s[4];
+    float acc = 0.f;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float v = g[i] + two_decay * p[i];
+        g[i] = v;
+        acc += v * v;
+    }
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ rg2,
+                                                       float* __restrict__ ru2, size_t n, const float* __restrict__ g2, float clip_c) {
+    const float n2 = g2[0];
+    const float scale = (clip_c > 0.f && n2 > clip_c * clip_c) ? clip_c / sqrtf(n2) : 1.f;   // :1194-1203
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float gi = g[i] * scale;
+        const float r = 0.95f * rg2[i] + 0.05f * gi * gi;                 // common.py:184
+        const float ud = -sqrtf(ru2[i] + 1e-6f) / sqrtf(r + 1e-6f) * gi;  // :189
+        rg2[i] = r;
+        ru2[i] = 0.95f * ru2[i] + 0.05f * ud * ud;                        // :190
+        p[i] += ud;                                                        // :191
+    }
+}
+
+// gradient wrt the initial state: h0 = tanh(mean.Ws + bs), c0 = tanh(mean.Wm + bm) (:657-660)
+__global__ __launch_bounds__(256) void state0_bwd_kernel(const float* __restrict__ dh_pass, const float* __restrict__ dhU, int nU,
+                                                         const float* __restrict__ dhW, int nW, const float* __restrict__ dselpre,
+                                                         const float* __restrict__ W_sel, const float* __restrict__ dc,
+                                                         const float* __restrict__ h0, const float* __restrict__ c0,
+                                                         float* __restrict__ dph0, float* __restrict__ dpc0, int M, int D) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (size_t)M * D) return;
+    const int b = (int)(idx / D), d = (int)(idx % D);
+    const size_t MD = (size_t)M * D;
+    float dh = dh_pass[idx];
+    for (int p = 0; p < nU; ++p) dh += dhU[(size_t)p * MD + idx];
+    for (int p = 0; p < nW; ++p) dh += dhW[(size_t)p * MD + idx];
+    if (W_sel) dh += dselpre[b] * W_sel[d];
+    const float h = h0[idx], c = c0[idx];
+    dph0[idx] = dh * (1.f - h * h);
+    dpc0[idx] = dc[idx] * (1.f - c * c);
+}
+
+inline int grid_for(size_t n, int block, int cap = 4096) {
+    size_t g = (n + block - 1) / block;
+    return (int)(g > (size_t)cap ? cap : (g < 1 ? 1 : g));
+}
+
+}  // namespace
+
+// ================================ launchers ===================================================
+hipError_t launch_dlogit(hipStream_t s, const float* probs, int ldp, const int64_t* x, const float* mask, float nll_scale,
+                         float* dl, int ldd, int rows, int V, int Vp) {
+    if (rows <= 0) return hipSuccess;
+    hipLaunchKernelGGL(dlogit_kernel, dim3(rows), dim3(256), 0, s, probs, ldp, x, mask, nll_scale, dl, ldd, V, Vp);
+    return hipGetLastError();
+}
+hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* sq, int steps, size_t n, float coef) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(alpha_reg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, alpha, r, sq, steps, n, coef);
+    return hipGetLastError();
+}
+hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)(((size_t)a.M * a.D + 255) / 256)), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {
+    if (a.T > TMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(temporal_bwd_kernel, dim3(a.M), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
+    if (a.K > KMAX) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spatial_bwd_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dplt, float* dsproj, int lddsp, int M, int T, int D) {
+    hipLaunchKernelGGL(reduce_T_kernel, dim3(M, ((D >> 2) + 255) / 256), dim3(256), 0, s, dslp, dplt, dsproj, lddsp, T, D);
+    return hipGetLastError();
+}
+hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
+    hipLaunchKernelGGL(ctxgrad_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+// dst[n] (+)= sum_r X[r, n]; `part` must hold colsum_parts(rows, N) * N floats
+int colsum_parts(int rows, int N) {
+    int rs = 1024 / ((N + 63) / 64);
+    if (rs > rows / 16) rs = rows / 16;
+    if (rs < 1) rs = 1;
+    if (rs > 256) rs = 256;
+    return rs;
+}
+hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate) {
+    if (rows <= 0 || N <= 0) return hipSuccess;
+    const int rs = colsum_parts(rows, N);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, s, X, ldx, rows, N, part, rs);
+    hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rs, N, dst, accumulate);
+    return hipGetLastError();
+}
+hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate) {
+    hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, s, x, n, dst, scale, accumulate);
+    return hipGetLastError();
+}
+hipError_t launch_wsum_rows(hipStream_t s, const float* v, const float* X, int ldx, int rows, int N, float* dst) {
+    hipLaunchKernelGGL(wsum_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, X, ldx, rows, N, dst);
+    return hipGetLastError();
+}
+hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, dy, t, mul, out, n / 4);
+    return hipGetLastError();
+}
+hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate) {
+    if (!n) return hipSuccess;
+    hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, accumulate);
+    return hipGetLastError();
+}
+hipError_t launch_embed_bwd(hipStream_t s, const int64_t* x, const float* demb, float* dWemb, int rows, int E, int V, int shift) {
+    if (rows - shift <= 0) return hipSuccess;
+    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows - shift), dim3(256), 0, s, x, demb, dWemb, rows, E, V, shift);
+    return hipGetLastError();
+}
+hipError_t launch_transpose(hipStream_t s, const float* in, int ldi, float* out, int ldo, int rows, int cols) {
+    hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, ldi, out, ldo, rows, cols);
+    return hipGetLastError();
+}
+hipError_t launch_state0_bwd(hipStream_t s, const float* dh_pass, const float* dhU, int nU, const float* dhW, int nW,
+                             const float* dselpre, const float* W_sel, const float* dc, const float* h0, const float* c0,
+                             float* dph0, float* dpc0, int M, int D) {
+    hipLaunchKernelGGL(state0_bwd_kernel, dim3((unsigned)(((size_t)M * D + 255) / 256)), dim3(256), 0, s, dh_pass, dhU, nU, dhW, nW,
+                       dselpre, W_sel, dc, h0, c0, dph0, dpc0, M, D);
+    return hipGetLastError();
+}
+hipError_t launch_decay_sumsq(hipStream_t s, float* g, const float* p, float two_decay, size_t n, float* part, int nblocks) {
+    hipLaunchKernelGGL(decay_sumsq_kernel, dim3(nblocks), dim3(256), 0, s, g, p, two_decay, n, part);
+    return hipGetLastError();
+}
+hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c) {
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, rg2, ru2, n, g2, clip_c);
+    return hipGetLastError();
+}
+
+}  // namespace stattn

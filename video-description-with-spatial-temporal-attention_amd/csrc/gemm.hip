@@ -110,10 +110,21 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
     float4 ra[TA::NF4], rb[TB::NF4];
-    const int nk = (g.K + BK - 1) / BK;
+    // split-K: slice blockIdx.y owns k in [kb, ke) and writes its partial tile to ws
+    int kb = 0, ke = g.K;
+    float* Cout = g.C;
+    int ldc = g.ldc;
+    if (g.kslices > 1) {
+        const int per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
+        kb = blockIdx.y * per;
+        ke = kb + per < g.K ? kb + per : g.K;
+        Cout = g.ws + (size_t)blockIdx.y * g.M * g.N;
+        ldc = g.N;
+    }
+    const int nk = ke > kb ? (ke - kb + BK - 1) / BK : 0;
 
-    TA::gload(ra, g.A, g.lda, m0, g.M, 0, g.K, tid);
-    TB::gload(rb, g.B, g.ldb, n0, g.N, 0, g.K, tid);
+    TA::gload(ra, g.A, g.lda, m0, g.M, kb, ke, tid);
+    TB::gload(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
     TA::sstore(ra, sA, tid);
     TB::sstore(rb, sB, tid);
     __syncthreads();
@@ -122,8 +133,8 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         const int st = kt & 1;
         const bool more = (kt + 1 < nk);
         if (more) {   // next tile's global loads fly while this tile is multiplied
-            TA::gload(ra, g.A, g.lda, m0, g.M, (kt + 1) * BK, g.K, tid);
-            TB::gload(rb, g.B, g.ldb, n0, g.N, (kt + 1) * BK, g.K, tid);
+            TA::gload(ra, g.A, g.lda, m0, g.M, kb + (kt + 1) * BK, ke, tid);
+            TB::gload(rb, g.B, g.ldb, n0, g.N, kb + (kt + 1) * BK, ke, tid);
         }
         const float* cA = sA + st * TA::ELEMS;
         const float* cB = sB + st * TB::ELEMS;
@@ -159,11 +170,14 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < g.M) {
+                if (row < g.M && g.kslices > 1) {
+                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
+                } else if (row < g.M) {
                     float v = g.alpha * acc[i][j][r] + bias;
                     if (g.add) v += g.add[(size_t)row * g.ldadd + col];
                     if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
                     if (g.act == 1) v = fast_tanh(v);
+                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
                     if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
                     float* c = g.C + (size_t)row * g.ldc + col;
                     if (g.accumulate) v += *c;
@@ -174,11 +188,29 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// C[i] (+)= alpha * sum_z ws[z][i]   (fixed summation order: deterministic)
+__global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int ldc, int M, int N,
+                                     int slices, float alpha, int accumulate) {
+    const size_t n4 = (size_t)M * N / 4;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ld4(ws + 4 * i);
+        for (int z = 1; z < slices; ++z) {
+            const float4 b = ld4(ws + (size_t)z * M * N + 4 * i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const size_t e = 4 * i, row = e / N, col = e % N;
+        float* c = C + row * ldc + col;
+        float4 o = make_float4(alpha * a.x, alpha * a.y, alpha * a.z, alpha * a.w);
+        if (accumulate) { const float4 p = ld4(c); o.x += p.x; o.y += p.y; o.z += p.z; o.w += p.w; }
+        st4(c, o);
+    }
+}
+
 template <int TM, int TN>
 hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
     const int BM = 64 * TM, BN = 64 * TN;
     const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
-    dim3 grid(tiles), block(256);
+    dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1), block(256);
     if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
     else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
     else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, g);
@@ -194,10 +226,36 @@ void gemm_defaults(GemmArgs& g) {
     g.rowgroup = 1;
 }
 
-hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
+hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
+    GemmArgs g = gin;
+    g.kslices = 1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
-    if (g.N % 64 != 0 || g.K % 4 != 0) return hipErrorInvalidValue;
+    if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
+    if (tB && g.K % 4 != 0) return hipErrorInvalidValue;
     if (tA && (g.M % 4 != 0)) return hipErrorInvalidValue;
+    if (g.ws && !g.bias && !g.add && !g.rowadd && !g.mul && !g.act && !g.Cact) {
+        // split-K decision on the 128x128 (or 64x64) tile grid
+        const int bm = g.M > 64 ? 128 : 64, bn = (g.N % 128 == 0 && g.M > 64) ? 128 : 64;
+        const int tiles = ((g.M + bm - 1) / bm) * (g.N / bn);
+        if (tiles < 160 && g.K >= 1024) {
+            int ks = (512 + tiles - 1) / tiles;
+            const int maxk = g.K / 256;
+            if (ks > maxk) ks = maxk;
+            if (ks > 32) ks = 32;
+            while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
+            if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
+                g.kslices = ks;
+                hipError_t e = (bm == 128 && bn == 128) ? launch_cfg<2, 2>(s, g, tA, tB)
+                             : (bm == 128 ? launch_cfg<2, 1>(s, g, tA, tB) : launch_cfg<1, 1>(s, g, tA, tB));
+                if (e != hipSuccess) return e;
+                const size_t n4 = (size_t)g.M * g.N / 4;
+                int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.ws, g.C, g.ldc, g.M, g.N,
+                                   ks, g.alpha, g.accumulate);
+                return hipGetLastError();
+            }
+        }
+    }
     // tile choice: the largest tile that still yields >= ~0.8 blocks per CU (256 CUs)
     auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
     const bool n128 = (g.N % 128 == 0);

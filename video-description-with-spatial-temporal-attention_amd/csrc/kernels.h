@@ -23,6 +23,12 @@ struct GemmArgs {
     const float* mul; int ldmul;       // [M,N] elementwise multiplier applied after act, or null
     int act;                           // 0 none, 1 tanh
     int accumulate;                    // C += result
+    float* Cact; int ldcact;           // optional second output: the activation BEFORE `mul` (tanh(z) for backward)
+    // deterministic split-K (weight-gradient shapes: small MxN, huge K): when `ws` is given and the tile grid
+    // would leave most CUs idle, K is cut into slices that write partial tiles to ws, and a second kernel
+    // sums them in a fixed order.  Only alpha / accumulate are honoured on that path.
+    float* ws; size_t ws_floats;
+    int kbeg, kend, kslices;           // internal
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);
@@ -44,7 +50,13 @@ struct SkSeg {
     const float* mul; int ldmul;
     float scale; int act;
 };
-struct SkArgs { SkSeg seg[6]; int nseg; int M; };
+struct SkArgs {
+    SkSeg seg[6]; int nseg; int M;
+    // K-split over blocks (backward recurrences: N = D is narrow, K = 4D is long).  kz > 1: block z owns every
+    // kz-th K-slice and stores its raw partial tile to C + z * part_stride; the consumer sums the kz partials
+    // in a fixed order.  No epilogue terms on that path.
+    int kz; size_t part_stride;
+};
 void skinny_seg_defaults(SkSeg& s);
 hipError_t launch_skinny(hipStream_t s, const SkArgs& a);
 
@@ -123,5 +135,90 @@ hipError_t launch_cost(hipStream_t s, const float* nll, const float* mask, float
 hipError_t launch_bernoulli(hipStream_t s, float* p, size_t n, uint64_t seed, uint64_t stream_id);
 // uniform in [-1, 1)
 hipError_t launch_uniform(hipStream_t s, float* p, size_t n, uint64_t seed, uint64_t stream_id);
+
+// ----------------------------------------------------------------------------
+// backward pass (bwd.hip) -- see the file header for the structure
+// ----------------------------------------------------------------------------
+struct LstmBwdArgs {
+    const float* dh_pass;                 // [M,D] (1-m) dh of the step after, or null at the last step
+    const float* dhU; int nU;             // K-slice partials of dpre_{s+1}.U^T   [nU][M,D]
+    const float* dhW; int nW;             // partials of dsproj_{s+1}.Wd^T        [nW][M,D]
+    const float* dselpre; const float* W_sel;   // rank-1 selector term of step s+1 (null if none)
+    const float* dhd; const float* d1;    // readout gradient wrt hd[s] and its dropout multiplier
+    const float* gates;                   // [M,4D] i,f,o,g of step s
+    const float* c_prev; const float* c_new; const float* mask; const float* dp;   // dp [M,3D]
+    float* dc;                            // [M,D] carried dc (in/out); read only if !last
+    float* dpre;                          // [M,4D] out
+    float* dh_pass_out;                   // [M,D] out
+    int M, D, last;
+};
+
+struct TemporalBwdArgs {
+    const float* dctxP; int nP;           // partials of dpre.Wc^T  [nP][M,D]
+    const float* dctx_r;                  // [M,D] readout gradient wrt ctx (null if !ctx2out)
+    const float* csum; const float* sel;  // forward: [M,D], [M]
+    const float* G; const float* Mo; const float* PG; const float* PM;   // [M,T,D]
+    const float* CL;                      // [M,T,D] of this step
+    const float* sproj; int ldsp;         // [M,4D] = sl|sg|sm|slt
+    const float* ag; const float* am; const float* alt;   // [M,T]
+    const float* rg; const float* rm; const float* rlt;   // [M,T] regulariser terms
+    const float* Ug; const float* Um;
+    int has_sel;
+    float* dcsum;                         // [M,D]
+    float* dselpre;                       // [M]
+    float* deg; float* dem; float* delt;  // [M,T]
+    float* dsproj; int lddsp;             // [M,4D]: writes the sg and sm quarters
+    int M, T, D;
+};
+
+struct SpatialBwdArgs {
+    const float* PL; const float* L; const float* LW;     // [M,T,K,D]
+    const float* sproj; int ldsp;
+    const float* dcsum;                                   // [M,D]
+    const float* alphal;                                  // [M,T,K]
+    const float* alt; const float* delt;                  // [M,T]
+    const float* rl;                                      // [M,T,K] or null
+    const float* Ul; const float* Ult; const float* blt;
+    float* dplt;                                          // [M,T,D]
+    float* del;                                           // [M,T,K]
+    float* dslp;                                          // [M,T,D] per-frame dsl
+    int M, T, K, D;
+};
+
+struct CtxGradArgs {
+    const float* PL; const float* LW; const float* PG; const float* PM;
+    const float* sproj;          // [S,M,4D]
+    const float* dcsum;          // [S,M,D]
+    const float* dplt;           // [S,M,T,D]
+    const float* alphal; const float* del;     // [S,M,T,K]
+    const float* alt; const float* delt; const float* am; const float* deg; const float* dem;   // [S,M,T]
+    const float* Ul; const float* Ult; const float* Ug; const float* Um; const float* blt;
+    float* dPL; float* dL; float* dLW;         // [M,T,K,D]
+    float* dPG; float* dPM; float* dMo;        // [M,T,D]
+    float* pUl; float* pUlt; float* pUg; float* pUm;   // [M*T, D] partials
+    int S, M, T, K, D;
+};
+
+hipError_t launch_dlogit(hipStream_t s, const float* probs, int ldp, const int64_t* x, const float* mask, float nll_scale,
+                         float* dl, int ldd, int rows, int V, int Vp);
+hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* sq, int steps, size_t n, float coef);
+hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a);
+hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a);
+hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a);
+hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dplt, float* dsproj, int lddsp, int M, int T, int D);
+hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a);
+int colsum_parts(int rows, int N);
+hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate);
+hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
+hipError_t launch_wsum_rows(hipStream_t s, const float* v, const float* X, int ldx, int rows, int N, float* dst);
+hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
+hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);
+hipError_t launch_embed_bwd(hipStream_t s, const int64_t* x, const float* demb, float* dWemb, int rows, int E, int V, int shift);
+hipError_t launch_transpose(hipStream_t s, const float* in, int ldi, float* out, int ldo, int rows, int cols);
+hipError_t launch_state0_bwd(hipStream_t s, const float* dh_pass, const float* dhU, int nU, const float* dhW, int nW,
+                             const float* dselpre, const float* W_sel, const float* dc, const float* h0, const float* c0,
+                             float* dph0, float* dpc0, int M, int D);
+hipError_t launch_decay_sumsq(hipStream_t s, float* g, const float* p, float two_decay, size_t n, float* part, int nblocks);
+hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c);
 
 }  // namespace stattn

@@ -30,7 +30,7 @@ constexpr int TILE_N = 64;
 // One wave: acc[nq][r] += sum over its K-slices of A[arow, k] * B[k, bcol + nq]
 // steps (16 k each) are dealt round-robin to the `nks` K-slice waves.
 __device__ __forceinline__ void sk_accumulate(f32x4 (&acc)[4], const SkPair& p, int arow, int bcol,
-                                              int ks, int nks, int g) {
+                                              int ks, int nks, int g) {   // ks / nks: global K-slice index / count
     const int nsteps = p.K >> 4;
     const float* __restrict__ Ap = p.A + (size_t)arow * p.lda + 4 * g;
     const float* __restrict__ Bp = p.B + (size_t)(4 * g) * p.ldb + bcol;
@@ -77,7 +77,9 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int 
     f32x4 acc[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
-    for (int p = 0; p < sg.npairs; ++p) sk_accumulate(acc, sg.p[p], arow, n0 + 4 * j, ks, nks, g);
+    const int kz = a.kz > 1 ? a.kz : 1;
+    for (int p = 0; p < sg.npairs; ++p)
+        sk_accumulate(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
     sk_spill(red, w, acc, j, g);
     __syncthreads();
 
@@ -88,6 +90,7 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int 
         float v = 0.f;
         for (int k = 0; k < nks; ++k) v += red[(size_t)(k * mtb + mo) * (16 * TILE_N) + row * TILE_N + col];
         const int n = n0 + col;
+        if (kz > 1) { sg.C[(size_t)blockIdx.z * a.part_stride + (size_t)grow * sg.ldc + n] = v; continue; }
         if (sg.bias) v += sg.bias[n];
         if (sg.bias2) v += sg.bias2[n];
         if (sg.add) v += sg.add[(size_t)grow * sg.ldadd + n];
@@ -189,8 +192,9 @@ hipError_t launch_skinny(hipStream_t s, const SkArgs& a) {
             if (sg.p[p].K % 16 != 0 || sg.p[p].lda % 4 != 0 || sg.p[p].ldb % 4 != 0) return hipErrorInvalidValue;
         ntiles += sg.N / TILE_N;
     }
-    const int mtb = pick_mtb(ntiles, a.M);
-    dim3 grid(ntiles, (a.M + 16 * mtb - 1) / (16 * mtb)), block(1024);
+    const int kz = a.kz > 1 ? a.kz : 1;
+    const int mtb = pick_mtb(ntiles * kz, a.M);
+    dim3 grid(ntiles, (a.M + 16 * mtb - 1) / (16 * mtb), kz), block(1024);
     hipLaunchKernelGGL(skinny_kernel, grid, block, 0, s, a, mtb);
     return hipGetLastError();
 }

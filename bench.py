@@ -5,10 +5,14 @@
     (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
 
 A "step" is one pass of the hot path over one synthetic minibatch that is already resident in
-HBM: the training graph of model_attention.py (build_model, :583-717) on BASELINE.json
-configs[1] -- batch 64 per GPU, T=26 frames, K=8 regions, feat 4096, hidden 1024, E=512, vocab
-12k, caption length 30, fp32.  metric = row-steps/s = rows x timesteps / wall seconds, whole job.
-Rows are sharded over ranks with no data-path collective in the forward pass (weak scaling).
+HBM.  Default (--mode train) = the reference's optimisation step on BASELINE.json configs[1]/[2]:
+f_grad_shared + f_update (model_attention.py:1259, 1278) = build_model forward (:583-717), the
+hand-written BPTT backward of the loss (:1129-1147), ONE RCCL all-reduce of the flat gradient
+buffer when N > 1, global-norm clip and Adadelta -- batch 64 per GPU, T=26 frames, K=8 regions,
+feat 4096, hidden 1024, E=512, vocab 12k, caption length 30, fp32, dropout draws on
+(use_noise=1).  --mode forward times the teacher-forced decoder pass alone (f_log_probs).
+metric = row-steps/s = rows x timesteps / wall seconds, whole job; rows are sharded over ranks
+(weak scaling: per-GPU work fixed).
 
 One JSON line is printed by rank 0.  Besides the contract fields it carries
   roofline     -- the dominant kernel (spatial attention, HBM-bound) timed live with HIP events on
@@ -112,6 +116,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
+    ap.add_argument("--mode", default="train", choices=["train", "forward"])
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
@@ -132,14 +137,22 @@ def main():
         dist.init_process_group("nccl", device_id=torch.device("cuda", local))
 
     import stattn
+    from stattn import dp
     c = CONFIGS[args.config]
     options = make_options(c)
-    params = fast_params(options, 1234)
-    dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode)
+    params = fast_params(options, 1234)               # same seed on every rank: replicas start identical
+    # the library runs on a torch stream so that torch.distributed's collective is ordered with its kernels
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode)
     dec.set_params(params)
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
     dec.set_batch(**batch)                            # inputs resident in HBM before the timed region
-    dec.set_use_noise(0.0)
+    train = args.mode == "train"
+    dec.set_use_noise(1.0 if train else 0.0)
+    dec.set_seed(1234 + rank)
+    step_fn = dp.DataParallelStep(dec, global_batch=c["B"] * world, alpha_c=0.70602, decay_c=1e-4, clip_c=10.0) \
+        if train else dec.forward_train               # config.py: decay_c 1e-4, alpha_c 0.70602, clip_c 10
 
     def barrier():
         dec.sync()
@@ -149,11 +162,11 @@ def main():
             torch.cuda.synchronize()
 
     for _ in range(args.warmup):
-        dec.forward_train()
+        step_fn()
     barrier()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dec.forward_train()
+        step_fn()
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
@@ -167,7 +180,7 @@ def main():
     # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
     dec.set_profiling(True)
     for _ in range(3):
-        dec.forward_train()
+        dec.forward_train()                           # forward only: the per-kernel-class events live there
     kms = dec.kernel_ms()
     dec.set_profiling(False)
     B, T, K, D = c["B"], c["T"], c["K"], c["D"]
@@ -185,9 +198,11 @@ def main():
     out = dict(metric="decoder steps/sec (batch x timestep)", value=value, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="%s: build_model forward (teacher-forced decoder pass: prologue + %d steps + readout + "
-                                    "softmax/NLL), batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
-                                    % (args.config, c["t"], B, T, K, c["F"], D, c["E"], c["V"], dec.lt_mode),
+               config=dict(workload="%s %s: %s, batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, caption length %d, lt_mode=%d"
+                                    % (args.config, args.mode,
+                                       "optimisation step = build_model forward + BPTT backward + gradient all-reduce + clip + Adadelta"
+                                       if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
+                                       B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),
                            global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world),
                roofline=roofline,
                kernel_ms={k: v[0] for k, v in kms.items()})

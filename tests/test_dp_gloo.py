@@ -1,0 +1,95 @@
+"""World-size-2 test of the data-parallel exactness rule on CPU (gloo): the product's shard /
+all-reduce host logic (stattn.dp) applied to oracle-computed shard gradients must reproduce the
+single-process full-batch gradient and Adadelta step."""
+import os
+import socket
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+TINY = dict(dim=16, dim_word=8, n_words=11, ctxg_dim=16, ctxl_dim=12, ctxm_dim=10, ctxglm_dim=16)
+ALPHA_C, DECAY_C, CLIP_C = 0.70602, 1e-3, 0.5
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import stattn
+    from stattn import dp
+    from oracle import stattn_oracle as O
+    from oracle import stattn_oracle_grad as OG
+    opt = O.default_options(**TINY)
+    P = O.random_params(opt, seed=4, dtype=np.float64)
+    batch = O.synthetic_batch(opt, B=5, T=4, K=3, t=5, seed=8, dtype=np.float64)   # 5 rows: uneven shards 2 / 3
+    shard = dp.shard_rows(batch, rank, world)
+    B_global = batch['x'].shape[1]
+    g = OG.loss_and_grads(P, opt, shard, alpha_c=ALPHA_C, nll_scale=1.0 / B_global)['grads']
+    flat = torch.from_numpy(np.concatenate([np.asarray(v).reshape(-1) for v in g.values()]))
+    dp.allreduce_sum(flat)                                   # the product's collective wrapper
+    flat = flat.numpy()
+    # decay once, after the reduce; clip on the global norm; Adadelta
+    off = 0
+    grads = OrderedDict()
+    for k, v in P.items():
+        n = v.size
+        grads[k] = flat[off:off + n].reshape(v.shape) + 2 * DECAY_C * v
+        off += n
+    grads = O.clip_grads(grads, CLIP_C)
+    rg2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+    ru2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+    O.adadelta_update(P, grads, rg2, ru2)
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), **{k: np.asarray(v) for k, v in P.items()})
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_rank_step_equals_single_process_step(tmp_path):
+    from oracle import stattn_oracle as O
+    from oracle import stattn_oracle_grad as OG
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    opt = O.default_options(**TINY)
+    P = O.random_params(opt, seed=4, dtype=np.float64)
+    batch = O.synthetic_batch(opt, B=5, T=4, K=3, t=5, seed=8, dtype=np.float64)
+    g = OG.loss_and_grads(P, opt, batch, alpha_c=ALPHA_C, decay_c=DECAY_C)['grads']      # single process, full batch
+    g2 = sum(float((v ** 2).sum()) for v in g.values())
+    assert g2 > CLIP_C ** 2                                                              # the clip is active
+    rg2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+    ru2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+    O.adadelta_update(P, O.clip_grads(g, CLIP_C), rg2, ru2)
+    r0 = np.load(os.path.join(str(tmp_path), "rank0.npz"))
+    r1 = np.load(os.path.join(str(tmp_path), "rank1.npz"))
+    for k in P:
+        np.testing.assert_array_equal(r0[k], r1[k])                 # replicas stay bit-identical
+        np.testing.assert_allclose(r0[k], P[k], rtol=1e-9, atol=1e-12)
+
+
+def test_shard_rows_partitions_every_row_once():
+    from stattn import dp
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**TINY)
+    b = O.synthetic_batch(opt, B=7, T=3, K=2, t=4, seed=1)
+    for world in (1, 2, 3, 4, 8):
+        rows = 0
+        xs = []
+        for r in range(world):
+            s = dp.shard_rows(b, r, world)
+            assert s['x'].shape[0] == 4 and s['ctxl'].shape[0] == s['x'].shape[1] == s['mask'].shape[1]
+            assert s['x'].flags['C_CONTIGUOUS']
+            rows += s['x'].shape[1]
+            xs.append(s['x'])
+        assert rows == 7
+        np.testing.assert_array_equal(np.concatenate(xs, 1), b['x'])

@@ -124,3 +124,56 @@ def test_sharded_gradient_equals_full_batch_gradient():
         for k, g in dec.get_grads().items():
             tot[k] += g
     _check_grads(tot, ref)
+
+
+def test_gradient_buffer_aliases_into_torch_and_rccl_allreduce_runs():
+    """The data-parallel step all-reduces a torch view of the library's flat gradient buffer
+    (no copy).  On a 1-GPU box: single-rank RCCL group -- checks the aliasing in both directions,
+    the stream ordering (library runs on a torch stream) and that the collective executes."""
+    import os
+    import torch
+    import torch.distributed as dist
+    import stattn
+    from stattn import dp
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**SMALL)
+    P = O.random_params(opt, seed=3, dtype=np.float32)
+    stream = torch.cuda.Stream()
+    torch.cuda.set_stream(stream)
+    dec = stattn.Decoder(opt, lt_mode=1, stream=stream.cuda_stream)
+    dec.set_params(P)
+    batch = O.synthetic_batch(opt, B=4, T=4, K=3, t=4, seed=3)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    dec.backward(alpha_c=0.5)
+    g0 = dec.get_grads()
+    gt = dp.grad_tensor(dec)
+    ptr, n = dec.grad_buffer_dev()
+    assert gt.data_ptr() == ptr and gt.numel() == n and gt.dtype == torch.float32
+    own_group = not dist.is_initialized()
+    if own_group:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        dist.all_reduce(gt, op=dist.ReduceOp.SUM)              # RCCL on the library's stream
+        gt.mul_(2.0)                                           # a torch write is visible to the library
+        torch.cuda.current_stream().synchronize()
+        g1 = dec.get_grads()
+        for k in g0:
+            np.testing.assert_allclose(g1[k], 2.0 * g0[k], rtol=1e-6, atol=1e-12)
+        # full DP step object on one rank == forward/backward/update by hand
+        step = dp.DataParallelStep(dec, global_batch=4, alpha_c=0.5, decay_c=1e-4, clip_c=10.0)
+        step()
+        p1 = dec.get_params()
+        dec2 = stattn.Decoder(opt, lt_mode=1)
+        dec2.set_params(P)
+        dec2.set_batch(**batch)
+        dec2.forward_train(); dec2.backward(nll_scale=0.25, alpha_c=0.5); dec2.update(decay_c=1e-4, clip_c=10.0)
+        p2 = dec2.get_params()
+        for k in p1:
+            np.testing.assert_allclose(p1[k], p2[k], rtol=1e-5, atol=1e-7)
+    finally:
+        if own_group:
+            dist.destroy_process_group()
+        torch.cuda.set_stream(torch.cuda.default_stream())

@@ -5,7 +5,7 @@ decoder): `model_attention.Attention` keeps init_params / init_tparams / build_m
 build_sampler -> (f_init, f_next) / gen_sample / pred_probs; `common` keeps zipp / unzip /
 itemlist / the weight initialisers.  All arithmetic runs in libstattn.so (hand-written
 gfx950 HIP kernels behind the C ABI of include/stattn.h); there is no CPU fallback."""
-from . import _native, common, model_attention  # noqa: F401
+from . import _native, common, dp, model_attention  # noqa: F401
 from ._native import Decoder, NativeError, library_path  # noqa: F401
 from .model_attention import Attention  # noqa: F401
 

@@ -164,6 +164,10 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
  * average milliseconds per launch measured with HIP events on the handle's stream. */
 int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K,
                          int iters, float* ms_per_launch);
+/* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
+ * 1 / 2 / 4 = ablations (loads only / MFMAs only / no reduction), see tools/skinny_probe.py. */
+int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,
+                           float* ms_per_launch);
 /* Average duration (ms) of the named kernel class over the last stattn_forward_train
  * when profiling is enabled: 0 = spatial attention, 1 = state projections, 2 = local-
  * temporal GEMM, 3 = temporal fuse, 4 = lstm, 5 = prologue GEMMs (sum), 6 = readout GEMMs (sum). */

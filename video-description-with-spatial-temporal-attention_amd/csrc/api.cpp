@@ -298,7 +298,7 @@ int init_state(stattn_handle* h, int nv, int T, const float* G, const float* mas
         SkSeg& s = a.seg[i];
         skinny_seg_defaults(s);
         s.npairs = 1;
-        s.p[0] = SkPair{mean, i == 0 ? h->w.ff_state_W : h->w.ff_memory_W, D, D, D};
+        s.p[0] = SkPair{mean, i == 0 ? h->w.ff_state_W : h->w.ff_memory_W, D, D, D, 0};
         s.C = i == 0 ? h0 : c0; s.ldc = D; s.N = D;
         s.bias = i == 0 ? h->w.ff_state_b : h->w.ff_memory_b;
         s.act = 1;
@@ -331,12 +331,12 @@ int run_step(stattn_handle* h, const StepIO& io) {
         for (int i = 0; i < 4; ++i) {
             SkSeg& s = a.seg[i];
             skinny_seg_defaults(s);
-            s.npairs = 1; s.p[0] = SkPair{io.h_prev, Wd[i], D, D, D};
+            s.npairs = 1; s.p[0] = SkPair{io.h_prev, Wd[i], D, D, D, 0};
             s.C = io.sproj + (size_t)i * D; s.ldc = 4 * D; s.N = D;
         }
         SkSeg& s = a.seg[4];
         skinny_seg_defaults(s);
-        s.npairs = 1; s.p[0] = SkPair{io.h_prev, w.U, D, 4 * D, D};
+        s.npairs = 1; s.p[0] = SkPair{io.h_prev, w.U, D, 4 * D, D, 0};
         s.C = io.preh; s.ldc = 4 * D; s.N = 4 * D;
         if (io.xproj) { s.add = io.xproj; s.ldadd = 4 * D; }
         HIPCHK(h, launch_skinny(h->stream, a));
@@ -376,8 +376,8 @@ int run_step(stattn_handle* h, const StepIO& io) {
     {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457)
         Prof pr(h, KC_LSTM);
         LstmArgs a{};
-        a.npairs = 1; a.p[0] = SkPair{io.ctx, w.Wc, D, 4 * D, D};
-        if (io.emb) { a.p[1] = SkPair{io.emb, w.W, E, 4 * D, E}; a.npairs = 2; a.bias = w.b; }
+        a.npairs = 1; a.p[0] = SkPair{io.ctx, w.Wc, D, 4 * D, D, 0};
+        if (io.emb) { a.p[1] = SkPair{io.emb, w.W, E, 4 * D, E, 0}; a.npairs = 2; a.bias = w.b; }
         a.pre_add = io.preh; a.ldpre = 4 * D;
         a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
         a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
@@ -702,8 +702,8 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
         a.M = m; a.nseg = 1;
         SkSeg& sg = a.seg[0];
         skinny_seg_defaults(sg);
-        sg.npairs = 1; sg.p[0] = SkPair{hd, w.Wl1, D, E, D};
-        if (h->opt.ctx2out) { sg.p[1] = SkPair{ctx, w.Wl2, D, E, D}; sg.npairs = 2; sg.bias2 = w.bl2; }
+        sg.npairs = 1; sg.p[0] = SkPair{hd, w.Wl1, D, E, D, 0};
+        if (h->opt.ctx2out) { sg.p[1] = SkPair{ctx, w.Wl2, D, E, D, 0}; sg.npairs = 2; sg.bias2 = w.bl2; }
         sg.bias = w.bl1;
         if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
         sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
@@ -712,7 +712,7 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
         b.M = m; b.nseg = 1;
         SkSeg& so = b.seg[0];
         skinny_seg_defaults(so);
-        so.npairs = 1; so.p[0] = SkPair{a1, w.Wo, E, Vp, E};
+        so.npairs = 1; so.p[0] = SkPair{a1, w.Wo, E, Vp, E, 0};
         so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
         HIPCHK(h, launch_skinny(s, b));
         HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, dargmax, m, V));   // :840
@@ -947,7 +947,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // backward workspaces
     float *da, *dhd, *dctx_r, *demb, *rg, *rm, *rlt, *rl, *sqg, *sqm, *sqlt, *sql, *UT, *WcT, *WdT, *dpre, *dsproj, *dcsum,
           *dselpre, *deg, *dem, *delt, *del, *dplt, *dslp, *dc, *dhp0, *dhp1, *dctxP, *dhUP, *dhWP, *dPL, *dL, *dLW, *dPG,
-          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg;
+          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg, *da_raw, *dsgp, *dsmp;
     const int KZ1 = 8, KZ2 = 16;
     const size_t WS = (size_t)16 << 20;
     CHK(getbuf_t(h, "b_da", R * E, &da));
@@ -969,6 +969,9 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CHK(getbuf_t(h, "b_del", R * T * K, &del));
     CHK(getbuf_t(h, "b_dplt", R * T * D, &dplt));
     CHK(getbuf_t(h, "b_dslp", MT * D, &dslp));
+    CHK(getbuf_t(h, "b_dsgp", MT * D, &dsgp));
+    CHK(getbuf_t(h, "b_dsmp", MT * D, &dsmp));
+    CHK(getbuf_t(h, "b_da_raw", 3 * MT, &da_raw));
     CHK(getbuf_t(h, "b_dc", (size_t)m * D, &dc));
     CHK(getbuf_t(h, "b_dhp0", (size_t)m * D, &dhp0)); CHK(getbuf_t(h, "b_dhp1", (size_t)m * D, &dhp1));
     CHK(getbuf_t(h, "b_dctxP", (size_t)KZ1 * m * D, &dctxP));
@@ -1002,10 +1005,14 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         HIPCHK(h, launch_alpha_reg(s, am, rm, sqm, t, MT, alpha_c / T));
         HIPCHK(h, launch_alpha_reg(s, alt, rlt, sqlt, t, MT, alpha_c / T));
         HIPCHK(h, launch_alpha_reg(s, al, rl, sql, t, MTK, alpha_c / (T * K)));
-        HIPCHK(h, launch_sum_all(s, sqg, MT, lossreg, alpha_c / T, 0));
-        HIPCHK(h, launch_sum_all(s, sqm, MT, lossreg, alpha_c / T, 1));
-        HIPCHK(h, launch_sum_all(s, sqlt, MT, lossreg, alpha_c / T, 1));
-        HIPCHK(h, launch_sum_all(s, sql, MTK, lossreg, alpha_c / (T * K), 1));
+        MultiSumArgs ms{};
+        const float* srcs[4] = {sqg, sqm, sqlt, sql};
+        for (int i = 0; i < 4; ++i) {
+            ms.src[i] = srcs[i]; ms.n[i] = i < 3 ? MT : MTK; ms.dst[i] = lossreg + i;
+            ms.scale[i] = i < 3 ? alpha_c / T : alpha_c / (T * K);
+        }
+        ms.count = 4;
+        HIPCHK(h, launch_multi_sum(s, ms));
     } else {
         HIPCHK(h, hipMemsetAsync(lossreg, 0, 4 * sizeof(float), s));
     }
@@ -1054,7 +1061,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             for (int i = 0; i < 2; ++i) {
                 SkSeg& sg = a.seg[i];
                 skinny_seg_defaults(sg);
-                sg.npairs = 1; sg.p[0] = SkPair{dpre + r0 * 4 * D, i == 0 ? WcT : UT, 4 * D, D, 4 * D};
+                sg.npairs = 1; sg.p[0] = SkPair{dpre + r0 * 4 * D, i == 0 ? WcT : UT, 4 * D, D, 4 * D, 0};
                 sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
             }
             HIPCHK(h, launch_skinny(s, a));
@@ -1062,31 +1069,30 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         {
             TemporalBwdArgs a{};
             a.dctxP = dctxP; a.nP = KZ1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
-            a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.PG = PG; a.PM = PM; a.CL = CL + r0 * T * D;
-            a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
-            a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T;
+            a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.CL = CL + r0 * T * D;
             a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
-            a.Ug = w.Ug; a.Um = w.Um; a.has_sel = h->opt.selector ? 1 : 0;
-            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0;
-            a.deg = deg + r0 * T; a.dem = dem + r0 * T; a.delt = delt + r0 * T;
-            a.dsproj = dsproj + r0 * 4 * D; a.lddsp = 4 * D; a.M = m; a.T = T; a.D = D;
+            a.has_sel = h->opt.selector ? 1 : 0;
+            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0; a.da_raw = da_raw; a.M = m; a.T = T; a.D = D;
             HIPCHK(h, launch_temporal_bwd(s, a));
         }
         {
             SpatialBwdArgs a{};
             a.PL = PL; a.L = L; a.LW = LW; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
-            a.dcsum = dcsum + r0 * D; a.alphal = al + r0 * T * K; a.alt = alt + r0 * T; a.delt = delt + r0 * T;
+            a.dcsum = dcsum + r0 * D; a.alphal = al + r0 * T * K;
+            a.PG = PG; a.PM = PM; a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T; a.da_raw = da_raw;
+            a.Ug = w.Ug; a.Um = w.Um;
+            a.deg = deg + r0 * T; a.dem = dem + r0 * T; a.delt = delt + r0 * T; a.dsgp = dsgp; a.dsmp = dsmp;
             a.rl = reg ? rl : nullptr; a.Ul = w.Ul; a.Ult = w.Ult; a.blt = w.blt;
             a.dplt = dplt + r0 * T * D; a.del = del + r0 * T * K; a.dslp = dslp; a.M = m; a.T = T; a.K = K; a.D = D;
             HIPCHK(h, launch_spatial_bwd(s, a));
         }
-        HIPCHK(h, launch_reduce_T(s, dslp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D));
+        HIPCHK(h, launch_reduce_T(s, dslp, dsgp, dsmp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D));
         {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
             SkArgs a{};
             a.M = m; a.nseg = 1; a.kz = KZ2; a.part_stride = (size_t)m * D;
             SkSeg& sg = a.seg[0];
             skinny_seg_defaults(sg);
-            sg.npairs = 1; sg.p[0] = SkPair{dsproj + r0 * 4 * D, WdT, 4 * D, D, 4 * D};
+            sg.npairs = 1; sg.p[0] = SkPair{dsproj + r0 * 4 * D, WdT, 4 * D, D, 4 * D, 0};
             sg.C = dhWP; sg.ldc = D; sg.N = D;
             HIPCHK(h, launch_skinny(s, a));
         }
@@ -1114,14 +1120,18 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, launch_colsum(s, pUlt, D, (int)MT, D, cpart, G_("decoder_Ult_att"), 0));
     HIPCHK(h, launch_colsum(s, pUg, D, (int)MT, D, cpart, G_("decoder_Ug_att"), 0));
     HIPCHK(h, launch_colsum(s, pUm, D, (int)MT, D, cpart, G_("decoder_Um_att"), 0));
-    HIPCHK(h, launch_sum_all(s, del, R * T * K, G_("decoder_cl_att"), 1.f, 0));
-    HIPCHK(h, launch_sum_all(s, delt, R * T, G_("decoder_clt_att"), 1.f, 0));
-    HIPCHK(h, launch_sum_all(s, deg, R * T, G_("decoder_cg_att"), 1.f, 0));
-    HIPCHK(h, launch_sum_all(s, dem, R * T, G_("decoder_cm_att"), 1.f, 0));
+    {   // scalar biases of the four attention scorers (+ the selector bias): full sums, one launch
+        MultiSumArgs ms{};
+        const float* srcs[5] = {del, delt, deg, dem, dselpre};
+        const size_t ns[5] = {R * T * K, R * T, R * T, R * T, R};
+        const char* names[5] = {"decoder_cl_att", "decoder_clt_att", "decoder_cg_att", "decoder_cm_att", "decoder_b_sel"};
+        ms.count = h->opt.selector ? 5 : 4;
+        for (int i = 0; i < ms.count; ++i) { ms.src[i] = srcs[i]; ms.n[i] = ns[i]; ms.dst[i] = G_(names[i]); ms.scale[i] = 1.f; }
+        HIPCHK(h, launch_multi_sum(s, ms));
+    }
     HIPCHK(h, launch_colsum(s, dplt, D, (int)(R * T), D, cpart, G_("decoder_blt_att"), 0));
     if (h->opt.selector) {
-        HIPCHK(h, launch_wsum_rows(s, dselpre, hs, D, (int)R, D, G_("decoder_W_sel")));
-        HIPCHK(h, launch_sum_all(s, dselpre, R, G_("decoder_b_sel"), 1.f, 0));
+        HIPCHK(h, launch_colsum(s, hs, D, (int)R, D, cpart, G_("decoder_W_sel"), 0, dselpre));   // h_prev^T . dselpre
     }
     // attention pre-projections (:322-326) and the hoisted L.Wclt
     HIPCHK(h, gemm(true, false, L, D, dPL, D, G_("decoder_Wcl_att"), D, D, D, (int)MTK, 0));
@@ -1163,7 +1173,7 @@ int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* los
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     std::vector<float> cost(h->m);
-    float regv = 0.f, p2 = 0.f;
+    float regv4[4] = {0.f, 0.f, 0.f, 0.f}, p2 = 0.f;
     float *part, *sc;
     CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
     CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
@@ -1173,10 +1183,11 @@ int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* los
         HIPCHK(h, hipMemcpyAsync(&p2, sc, sizeof(float), hipMemcpyDeviceToHost, s));
     }
     HIPCHK(h, hipMemcpyAsync(cost.data(), findbuf(h, "cost"), (size_t)h->m * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(h, hipMemcpyAsync(&regv, findbuf(h, "b_lossreg"), sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(regv4, findbuf(h, "b_lossreg"), 4 * sizeof(float), hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
     double tot = 0.0;
     for (float c : cost) tot += c;
+    const double regv = (double)regv4[0] + regv4[1] + regv4[2] + regv4[3];
     *loss = (float)(nll_scale * tot + regv + (double)decay_c * p2);
     return STATTN_OK;
 }
@@ -1243,7 +1254,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         a.M = M; a.nseg = 1;
         SkSeg& sg = a.seg[0];
         skinny_seg_defaults(sg);
-        sg.npairs = 1; sg.p[0] = SkPair{dA, dB, K, N, K};
+        sg.npairs = 1; sg.p[0] = SkPair{dA, dB, K, N, K, 0};
         sg.C = dC; sg.ldc = N; sg.N = N; sg.bias = bias ? dbias : nullptr;
         if (add) { sg.add = dadd; sg.ldadd = N; }
         sg.act = act; sg.scale = 1.f;
@@ -1271,6 +1282,11 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     gemm_defaults(g);
     g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
+    {   // same split-K workspace the backward pass hands to its weight-gradient GEMMs
+        float* ws;
+        CHK(getbuf_t(h, "b_ws", (size_t)16 << 20, &ws));
+        g.ws = ws; g.ws_floats = (size_t)16 << 20;
+    }
     for (int i = 0; i < 2; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
     hipEvent_t a, b;
     HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
@@ -1281,6 +1297,40 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     float ms = 0.f;
     HIPCHK(h, hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || nseg < 1 || nseg > 6 || !ms_per_launch)
+        return fail(h, STATTN_EINVAL, "dbg_time_skinny: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB, *dC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N * nseg, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N * nseg, &dC));
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N * nseg, 11, 2));
+    SkArgs a{};
+    a.M = M; a.nseg = nseg; a.dbg = variant;
+    for (int i = 0; i < nseg; ++i) {
+        SkSeg& sg = a.seg[i];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{dA, dB + (size_t)i * K * N, K, N, K, (variant & 16) ? (size_t)K * 64 : 0};
+        sg.C = dC + (size_t)i * N; sg.ldc = N * nseg; sg.N = N;
+    }
+    a.dbg = variant & 15;
+    for (int i = 0; i < 2; ++i) HIPCHK(h, launch_skinny(s, a));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_skinny(s, a));
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
     *ms_per_launch = ms / iters;
     return STATTN_OK;
 }

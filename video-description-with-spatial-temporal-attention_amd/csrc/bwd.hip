@@ -21,7 +21,6 @@ namespace stattn {
 namespace {
 
 constexpr int KMAX = 64;
-constexpr int TMAX = 256;
 
 template <int N>
 __device__ __forceinline__ void block_sum(float (&v)[N], float* s_red /*[nwaves][N]*/, int tid, int nwaves) {
@@ -118,79 +117,44 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 
-__global__ __launch_bounds__(256) void temporal_bwd_kernel(const TemporalBwdArgs a) {
-    __shared__ float s_red[4 * 24];
-    __shared__ float s_da[3][TMAX];
-    const int T = a.T, D = a.D, b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+// temporal backward, part 0 (one workgroup per row): dctx = sum of the GEMM K-slice partials + readout term,
+// selector backward (ctx = sel * csum, :433-435), dcsum
+__global__ __launch_bounds__(256) void tbwd0_kernel(const TemporalBwdArgs a) {
+    __shared__ float s_red[4];
+    const int D = a.D, b = blockIdx.x, tid = threadIdx.x;
     const int nd4 = D >> 2;
     const size_t MD = (size_t)a.M * D;
     const float sel = a.has_sel ? a.sel[b] : 1.f;
-
-    // dctx (sum of GEMM partials + readout term), selector backward, dcsum
     float ps[1] = {0.f};
     for (int d4 = tid; d4 < nd4; d4 += 256) {
         const size_t o = (size_t)b * D + 4 * d4;
         float4 dc = a.dctx_r ? ld4(a.dctx_r + o) : make_float4(0.f, 0.f, 0.f, 0.f);
         for (int p = 0; p < a.nP; ++p) add4(dc, ld4(a.dctxP + (size_t)p * MD + o));
         ps[0] += dot4(dc, ld4(a.csum + o));
-        st4(a.dcsum + o, scale4(dc, sel));                                 // ctx = sel * csum (:435)
+        st4(a.dcsum + o, scale4(dc, sel));
     }
     block_sum<1>(ps, s_red, tid, 4);
     if (tid == 0) a.dselpre[b] = a.has_sel ? ps[0] * sel * (1.f - sel) : 0.f;
-    __syncthreads();   // dcsum of this block is re-read below by other threads of the block
+}
 
-    // d alpha = <dcsum, X_t> (+ regulariser), 8 frames per reduction round
-    for (int t0 = 0; t0 < T; t0 += 8) {
-        float p[24];
-#pragma unroll
-        for (int i = 0; i < 24; ++i) p[i] = 0.f;
-        for (int d4 = tid; d4 < nd4; d4 += 256) {
-            const float4 dc = ld4(a.dcsum + (size_t)b * D + 4 * d4);
-#pragma unroll
-            for (int tt = 0; tt < 8; ++tt) {
-                const int t = min(t0 + tt, T - 1);
-                const size_t o = ((size_t)b * T + t) * D + 4 * d4;
-                p[tt] += dot4(dc, ld4(a.G + o));
-                p[8 + tt] += dot4(dc, ld4(a.Mo + o));
-                p[16 + tt] += dot4(dc, ld4(a.CL + o));
-            }
-        }
-        block_sum<24>(p, s_red, tid, 4);
-        if (tid < 24) {
-            const int which = tid >> 3, t = t0 + (tid & 7);
-            if (t < T) {
-                const float* r = which == 0 ? a.rg : (which == 1 ? a.rm : a.rlt);
-                s_da[which][t] = p[tid] + (r ? r[(size_t)b * T + t] : 0.f);
-            }
-        }
-        __syncthreads();
-    }
-    // softmax backward, one wave per attention: de_t = alpha_t (dalpha_t - sum alpha dalpha)
-    if (w < 3) {
-        const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
-        float dotp = 0.f;
-        for (int t = lane; t < T; t += 64) dotp += al[t] * s_da[w][t];
-        dotp = wave_sum(dotp);
-        float* out = (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt)) + (size_t)b * T;
-        for (int t = lane; t < T; t += 64) {
-            const float de = al[t] * (s_da[w][t] - dotp);
-            s_da[w][t] = de;
-            out[t] = de;
-        }
-    }
-    __syncthreads();
-    // dsg = sum_t deg_t Ug (1 - tanh^2(PG_t + sg)), same for motion
+// part 1 (one workgroup per (row, frame)): d alpha = <dcsum, X_t> + regulariser for the three temporal
+// attentions (cg = sum_t ag_t G_t :399, cm :412, clt = sum_t alt_t CL_t :426)
+__global__ __launch_bounds__(256) void tbwd1_kernel(const TemporalBwdArgs a) {
+    __shared__ float s_red[4 * 3];
+    const int T = a.T, D = a.D, bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
+    const int nd4 = D >> 2;
+    float p[3] = {0.f, 0.f, 0.f};
     for (int d4 = tid; d4 < nd4; d4 += 256) {
-        const float4 sg = ld4(a.sproj + (size_t)b * a.ldsp + D + 4 * d4), sm = ld4(a.sproj + (size_t)b * a.ldsp + 2 * D + 4 * d4);
-        float4 ag4 = make_float4(0.f, 0.f, 0.f, 0.f), am4 = ag4;
-#pragma unroll 4
-        for (int t = 0; t < T; ++t) {
-            const size_t o = ((size_t)b * T + t) * D + 4 * d4;
-            fma4(ag4, s_da[0][t], one_minus_sq(tanh4s(ld4(a.PG + o), sg)));
-            fma4(am4, s_da[1][t], one_minus_sq(tanh4s(ld4(a.PM + o), sm)));
-        }
-        st4(a.dsproj + (size_t)b * a.lddsp + D + 4 * d4, mul4(ag4, ld4(a.Ug + 4 * d4)));
-        st4(a.dsproj + (size_t)b * a.lddsp + 2 * D + 4 * d4, mul4(am4, ld4(a.Um + 4 * d4)));
+        const float4 dc = ld4(a.dcsum + (size_t)b * D + 4 * d4);
+        const size_t o = (size_t)bt * D + 4 * d4;
+        p[0] += dot4(dc, ld4(a.G + o));
+        p[1] += dot4(dc, ld4(a.Mo + o));
+        p[2] += dot4(dc, ld4(a.CL + o));
+    }
+    block_sum<3>(p, s_red, tid, 4);
+    if (tid < 3) {
+        const float* r = tid == 0 ? a.rg : (tid == 1 ? a.rm : a.rlt);
+        a.da_raw[(size_t)tid * a.M * T + bt] = p[tid] + (r ? r[bt] : 0.f);
     }
 }
 
@@ -207,9 +171,34 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
     const float* __restrict__ LW = a.LW + slab;
     const float* __restrict__ sp = a.sproj + (size_t)b * a.ldsp;
     const int nd4 = D >> 2;
+    __shared__ float s_de[3];
     if (tid < K) s_al[tid] = a.alphal[(size_t)bt * K + tid];
+    // softmax backward of the three temporal attentions for this frame: de_t = alpha_t (dalpha_t - <alpha, dalpha>)
+    // (every (b,t) workgroup redoes the T-long dot product of its row: 3 T floats, wave 0..2)
+    if (tid < 192) {
+        const int w = tid >> 6, lane = tid & 63;
+        const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
+        const float* da = a.da_raw + (size_t)w * a.M * T + (size_t)b * T;
+        float dotp = 0.f;
+        for (int t = lane; t < T; t += 64) dotp += al[t] * da[t];
+        dotp = wave_sum(dotp);
+        if (lane == 0) {
+            const int t = bt - b * T;
+            const float de = al[t] * (da[t] - dotp);
+            s_de[w] = de;
+            (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt))[bt] = de;
+        }
+    }
     __syncthreads();
-    const float alt = a.alt[bt], delt = a.delt[bt];
+    const float alt = a.alt[bt], delt = s_de[2];
+    // per-frame dsg / dsm: de Ug (1 - tanh^2(PG_t + sg))   (:389-397, :402-410)
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const size_t fo = (size_t)bt * D + 4 * d4;
+        const float4 tg = tanh4s(ld4(a.PG + fo), ld4(sp + D + 4 * d4));
+        const float4 tm = tanh4s(ld4(a.PM + fo), ld4(sp + 2 * D + 4 * d4));
+        st4(a.dsgp + fo, scale4(mul4(ld4(a.Ug + 4 * d4), one_minus_sq(tg)), s_de[0]));
+        st4(a.dsmp + fo, scale4(mul4(ld4(a.Um + 4 * d4), one_minus_sq(tm)), s_de[1]));
+    }
 
     // pass 1: recompute plt = sum_k alpha_k LW_k + blt, dplt = delt Ult (1 - tanh^2(plt + slt))  (:416-422)
     for (int d4 = tid; d4 < nd4; d4 += 256) {
@@ -258,20 +247,17 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
     }
 }
 
-// dsproj[b, 0:D] = sum_t dslp[b,t,:],  dsproj[b, 3D:4D] = sum_t dplt[b,t,:]
-__global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__ dslp, const float* __restrict__ dplt,
+// dsproj[b] = [sum_t dslp | sum_t dsgp | sum_t dsmp | sum_t dplt]   (the four state-projection gradients)
+__global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__ dslp, const float* __restrict__ dsgp,
+                                                       const float* __restrict__ dsmp, const float* __restrict__ dplt,
                                                        float* __restrict__ dsproj, int lddsp, int T, int D) {
-    const int b = blockIdx.x, d4 = blockIdx.y * 256 + threadIdx.x;
+    const int b = blockIdx.x, which = blockIdx.y, d4 = blockIdx.z * 256 + threadIdx.x;
     if (d4 >= (D >> 2)) return;
-    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
-#pragma unroll 4
-    for (int t = 0; t < T; ++t) {
-        const size_t o = ((size_t)b * T + t) * D + 4 * d4;
-        add4(s1, ld4(dslp + o));
-        add4(s2, ld4(dplt + o));
-    }
-    st4(dsproj + (size_t)b * lddsp + 4 * d4, s1);
-    st4(dsproj + (size_t)b * lddsp + 3 * D + 4 * d4, s2);
+    const float* __restrict__ src = which == 0 ? dslp : (which == 1 ? dsgp : (which == 2 ? dsmp : dplt));
+    float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+    for (int t = 0; t < T; ++t) add4(s1, ld4(src + ((size_t)b * T + t) * D + 4 * d4));
+    st4(dsproj + (size_t)b * lddsp + which * D + 4 * d4, s1);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -365,14 +351,14 @@ __global__ __launch_bounds__(256) void ctxgrad_kernel(const CtxGradArgs a) {
 // ---------------------------------------------------------------------------------------------
 // column sums with a fixed two-stage order: part[rs][n] = sum over a row range; then dst[n] (+)= sum_rs part
 __global__ __launch_bounds__(256) void colsum_part_kernel(const float* __restrict__ X, int ldx, int rows, int N,
-                                                          float* __restrict__ part, int rsplit) {
+                                                          float* __restrict__ part, int rsplit, const float* __restrict__ rw) {
     __shared__ float s[4][64];
     const int n = blockIdx.x * 64 + (threadIdx.x & 63), w = threadIdx.x >> 6, rs = blockIdx.y;
     const int per = (rows + rsplit - 1) / rsplit;
     const int r0 = rs * per, r1 = min(rows, r0 + per);
     float acc = 0.f;
     if (n < N)
-        for (int r = r0 + w; r < r1; r += 4) acc += X[(size_t)r * ldx + n];
+        for (int r = r0 + w; r < r1; r += 4) acc += (rw ? rw[r] : 1.f) * X[(size_t)r * ldx + n];
     s[w][threadIdx.x & 63] = acc;
     __syncthreads();
     if (w == 0 && n < N) part[(size_t)rs * N + n] = s[0][threadIdx.x] + s[1][threadIdx.x] + s[2][threadIdx.x] + s[3][threadIdx.x];
@@ -381,8 +367,25 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int rsplit, 
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     float acc = 0.f;
+#pragma unroll 16
     for (int r = 0; r < rsplit; ++r) acc += part[(size_t)r * N + n];
     dst[n] = accumulate ? dst[n] + acc : acc;
+}
+// several independent full sums in one launch: block i reduces job i (fixed order: deterministic)
+__global__ __launch_bounds__(1024) void multi_sum_kernel(const MultiSumArgs a) {
+    __shared__ float s[16];
+    const float* __restrict__ x = a.src[blockIdx.x];
+    const size_t n = a.n[blockIdx.x];
+    float acc = 0.f;
+    for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float r = 0.f;
+        for (int i = 0; i < 16; ++i) r += s[i];
+        a.dst[blockIdx.x][0] = a.scale[blockIdx.x] * r;
+    }
 }
 // dst[0] (+)= scale * sum(x[0:n])   (single block, deterministic)
 __global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ x, size_t n, float* __restrict__ dst, float scale, int accumulate) {
@@ -398,16 +401,6 @@ __global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__
         dst[0] = accumulate ? dst[0] + scale * r : scale * r;
     }
 }
-// dst[j] = sum_b v[b] * X[b, j]   (dW_sel = h_prev^T . dselpre over all (s,b) rows)
-__global__ __launch_bounds__(256) void wsum_rows_kernel(const float* __restrict__ v, const float* __restrict__ X, int ldx,
-                                                        int rows, int N, float* __restrict__ dst) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
-    float acc = 0.f;
-    for (int r = 0; r < rows; ++r) acc += v[r] * X[(size_t)r * ldx + n];
-    dst[n] = acc;
-}
-
 // y = dy * (1 - t^2) [* mulmat]  elementwise (tanh backward), in place allowed
 __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, const float* __restrict__ mul,
                                 float* __restrict__ out, size_t n4) {
@@ -520,8 +513,8 @@ hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {
-    if (a.T > TMAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(temporal_bwd_kernel, dim3(a.M), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tbwd0_kernel, dim3(a.M), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tbwd1_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
@@ -529,8 +522,10 @@ hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     hipLaunchKernelGGL(spatial_bwd_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dplt, float* dsproj, int lddsp, int M, int T, int D) {
-    hipLaunchKernelGGL(reduce_T_kernel, dim3(M, ((D >> 2) + 255) / 256), dim3(256), 0, s, dslp, dplt, dsproj, lddsp, T, D);
+hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
+                           float* dsproj, int lddsp, int M, int T, int D) {
+    const int nd4 = D >> 2, bx = nd4 < 256 ? ((nd4 + 63) / 64) * 64 : 256;
+    hipLaunchKernelGGL(reduce_T_kernel, dim3(M, 4, (nd4 + 255) / 256), dim3(bx), 0, s, dslp, dsgp, dsmp, dplt, dsproj, lddsp, T, D);
     return hipGetLastError();
 }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
@@ -545,19 +540,21 @@ int colsum_parts(int rows, int N) {
     if (rs > 256) rs = 256;
     return rs;
 }
-hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate) {
+hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,
+                         const float* row_weights) {
     if (rows <= 0 || N <= 0) return hipSuccess;
     const int rs = colsum_parts(rows, N);
-    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, s, X, ldx, rows, N, part, rs);
+    hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, s, X, ldx, rows, N, part, rs, row_weights);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rs, N, dst, accumulate);
+    return hipGetLastError();
+}
+hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a) {
+    if (a.count <= 0) return hipSuccess;
+    hipLaunchKernelGGL(multi_sum_kernel, dim3(a.count), dim3(1024), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate) {
     hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, s, x, n, dst, scale, accumulate);
-    return hipGetLastError();
-}
-hipError_t launch_wsum_rows(hipStream_t s, const float* v, const float* X, int ldx, int rows, int N, float* dst) {
-    hipLaunchKernelGGL(wsum_rows_kernel, dim3((N + 255) / 256), dim3(256), 0, s, v, X, ldx, rows, N, dst);
     return hipGetLastError();
 }
 hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n) {

@@ -17,6 +17,8 @@
 #include "kernels.h"
 #include "devmath.h"
 
+#include <cstdlib>
+
 namespace stattn {
 
 namespace {
@@ -138,20 +140,33 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
         }
         const float* cA = sA + st * TA::ELEMS;
         const float* cB = sB + st * TB::ELEMS;
+        // Fragment reads are software-pipelined through two register sets: the ds_reads of k-block
+        // kk+1 are issued before the 16 MFMAs of k-block kk, so LDS latency hides under the matrix
+        // pipe instead of serialising with it (sched_barrier pins the order; the compiler's own
+        // schedule sank every B read to just before its first use: read -> wait -> 4 MFMA).
+        float a[2][TM][4], b[2][TN][4];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) TA::frag(a[0][i], cA, wm * 32 * TM + i * 32 + l31, 0, kh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) TB::frag(b[0][j], cB, wn * 32 * TN + j * 32 + l31, 0, kh);
 #pragma unroll
         for (int kk = 0; kk < BK / 8; ++kk) {
-            float a[TM][4], b[TN][4];
+            const int cur = kk & 1, nxt = cur ^ 1;
+            if (kk + 1 < BK / 8) {
 #pragma unroll
-            for (int i = 0; i < TM; ++i) TA::frag(a[i], cA, wm * 32 * TM + i * 32 + l31, kk, kh);
+                for (int i = 0; i < TM; ++i) TA::frag(a[nxt][i], cA, wm * 32 * TM + i * 32 + l31, kk + 1, kh);
 #pragma unroll
-            for (int j = 0; j < TN; ++j) TB::frag(b[j], cB, wn * 32 * TN + j * 32 + l31, kk, kh);
+                for (int j = 0; j < TN; ++j) TB::frag(b[nxt][j], cB, wn * 32 * TN + j * 32 + l31, kk + 1, kh);
+            }
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int q = 0; q < 4; ++q)
 #pragma unroll
                 for (int i = 0; i < TM; ++i)
 #pragma unroll
                     for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[i][q], b[j][q], acc[i][j], 0, 0, 0);
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][q], b[cur][j][q], acc[i][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (more) {   // the other stage was last read before the previous barrier
             TA::sstore(ra, sA + (st ^ 1) * TA::ELEMS, tid);
@@ -233,34 +248,37 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
     if (tB && g.K % 4 != 0) return hipErrorInvalidValue;
     if (tA && (g.M % 4 != 0)) return hipErrorInvalidValue;
+    auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
+    const bool n128 = (g.N % 128 == 0);
     if (g.ws && !g.bias && !g.add && !g.rowadd && !g.mul && !g.act && !g.Cact) {
-        // split-K decision on the 128x128 (or 64x64) tile grid
-        const int bm = g.M > 64 ? 128 : 64, bn = (g.N % 128 == 0 && g.M > 64) ? 128 : 64;
-        const int tiles = ((g.M + bm - 1) / bm) * (g.N / bn);
-        if (tiles < 160 && g.K >= 1024) {
-            int ks = (512 + tiles - 1) / tiles;
-            const int maxk = g.K / 256;
-            if (ks > maxk) ks = maxk;
+        // split-K (weight-gradient shapes): 64x64 tiles, ~4 resident blocks per CU
+        const int t11 = blocks(64, 64);
+        if (t11 < 768 && g.K >= 1024) {
+            int ks = (1024 + t11 - 1) / t11;
+            if (ks > g.K / 512) ks = g.K / 512;
             if (ks > 32) ks = 32;
             while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
             if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
                 g.kslices = ks;
-                hipError_t e = (bm == 128 && bn == 128) ? launch_cfg<2, 2>(s, g, tA, tB)
-                             : (bm == 128 ? launch_cfg<2, 1>(s, g, tA, tB) : launch_cfg<1, 1>(s, g, tA, tB));
+                hipError_t e = launch_cfg<1, 1>(s, g, tA, tB);
                 if (e != hipSuccess) return e;
                 const size_t n4 = (size_t)g.M * g.N / 4;
-                int blocks = (int)((n4 + 255) / 256); if (blocks > 2048) blocks = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, s, g.ws, g.C, g.ldc, g.M, g.N,
+                int nb = (int)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
+                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, g.ws, g.C, g.ldc, g.M, g.N,
                                    ks, g.alpha, g.accumulate);
                 return hipGetLastError();
             }
         }
     }
-    // tile choice: the largest tile that still yields >= ~0.8 blocks per CU (256 CUs)
-    auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
-    const bool n128 = (g.N % 128 == 0);
-    if (n128 && g.M > 64 && blocks(128, 128) >= 200) return launch_cfg<2, 2>(s, g, tA, tB);
-    if (g.M > 64 && blocks(128, 64) >= 200) return launch_cfg<2, 1>(s, g, tA, tB);
+    // Measured on MI355X (tools/gemm_probe.py, profiles/r01_gemm_probe.txt): on a 4096^3 problem the 128x128 /
+    // 128x64 / 64x64 tiles reach 125 / 118 / 114 TFLOP/s, but what decides the decoder's shapes (N = 1024,
+    // M = 13312: 3.25 big tiles per CU) is the tail: whole tiles per CU quantise, so the big tile is only used
+    // when its per-CU tile count is (nearly) integral; otherwise the 64x64 tile (4 resident blocks per CU).
+    if (n128 && g.M > 64) {
+        const double per_cu = blocks(128, 128) / 256.0;
+        const double q = per_cu / (double)(long)(per_cu + 0.999999);
+        if (per_cu >= 2.0 && q >= 0.95) return launch_cfg<2, 2>(s, g, tA, tB);
+    }
     return launch_cfg<1, 1>(s, g, tA, tB);
 }
 

@@ -41,7 +41,13 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool trans
 //   epi(v)[m,n] = scale * act(v + bias[n] + bias2[n] + add[m,n]) * (mul ? mul[m,n] : 1)
 // N % 64 == 0, K_p % 16 == 0, rows of A_p 16-byte aligned.
 // ----------------------------------------------------------------------------
-struct SkPair { const float* A; const float* B; int lda, ldb, K; };
+struct SkPair {
+    const float* A; const float* B; int lda, ldb, K;
+    // tile-packed B (0 = plain row-major [K][ldb]): column tile t of 64 columns is stored as its own contiguous
+    // [K][64] panel at B + t * tile_stride, so a K-slice of a tile is one linear stream instead of 256-byte
+    // pieces at a power-of-two stride (which all map to the same few L2 channels)
+    size_t tile_stride;
+};
 struct SkSeg {
     SkPair p[3]; int npairs;
     float* C; int ldc; int N;          // N = number of output columns of this segment
@@ -56,6 +62,7 @@ struct SkArgs {
     // kz-th K-slice and stores its raw partial tile to C + z * part_stride; the consumer sums the kz partials
     // in a fixed order.  No epilogue terms on that path.
     int kz; size_t part_stride;
+    int dbg;                        // ablation switch for tools/skinny_probe.py (0 in the product path)
 };
 void skinny_seg_defaults(SkSeg& s);
 hipError_t launch_skinny(hipStream_t s, const SkArgs& a);
@@ -157,17 +164,13 @@ struct TemporalBwdArgs {
     const float* dctxP; int nP;           // partials of dpre.Wc^T  [nP][M,D]
     const float* dctx_r;                  // [M,D] readout gradient wrt ctx (null if !ctx2out)
     const float* csum; const float* sel;  // forward: [M,D], [M]
-    const float* G; const float* Mo; const float* PG; const float* PM;   // [M,T,D]
+    const float* G; const float* Mo;      // [M,T,D]
     const float* CL;                      // [M,T,D] of this step
-    const float* sproj; int ldsp;         // [M,4D] = sl|sg|sm|slt
-    const float* ag; const float* am; const float* alt;   // [M,T]
     const float* rg; const float* rm; const float* rlt;   // [M,T] regulariser terms
-    const float* Ug; const float* Um;
     int has_sel;
     float* dcsum;                         // [M,D]
     float* dselpre;                       // [M]
-    float* deg; float* dem; float* delt;  // [M,T]
-    float* dsproj; int lddsp;             // [M,4D]: writes the sg and sm quarters
+    float* da_raw;                        // [3][M,T] d alpha (g, m, lt) before the softmax backward
     int M, T, D;
 };
 
@@ -176,7 +179,12 @@ struct SpatialBwdArgs {
     const float* sproj; int ldsp;
     const float* dcsum;                                   // [M,D]
     const float* alphal;                                  // [M,T,K]
-    const float* alt; const float* delt;                  // [M,T]
+    const float* PG; const float* PM;                     // [M,T,D]
+    const float* ag; const float* am; const float* alt;   // [M,T] forward temporal attention weights
+    const float* da_raw;                                  // [3][M,T] from tbwd1
+    const float* Ug; const float* Um;
+    float* deg; float* dem; float* delt;                  // [M,T] out: temporal softmax backward
+    float* dsgp; float* dsmp;                             // [M,T,D] out: per-frame dsg / dsm
     const float* rl;                                      // [M,T,K] or null
     const float* Ul; const float* Ult; const float* blt;
     float* dplt;                                          // [M,T,D]
@@ -205,12 +213,15 @@ hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* 
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a);
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a);
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a);
-hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dplt, float* dsproj, int lddsp, int M, int T, int D);
+hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
+                           float* dsproj, int lddsp, int M, int T, int D);
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a);
 int colsum_parts(int rows, int N);
-hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate);
+hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,
+                         const float* row_weights = nullptr);
+struct MultiSumArgs { const float* src[12]; size_t n[12]; float* dst[12]; float scale[12]; int count; };
+hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]])
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
-hipError_t launch_wsum_rows(hipStream_t s, const float* v, const float* X, int ldx, int rows, int N, float* dst);
 hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);
 hipError_t launch_embed_bwd(hipStream_t s, const int64_t* x, const float* demb, float* dWemb, int rows, int E, int V, int shift);

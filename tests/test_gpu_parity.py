@@ -281,3 +281,45 @@ def test_c1_msvd_tiny_config_logits_and_alphas(stattn_mod, O):
         for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
             assert np.abs(out[name] - ref[name]).max() < TOL, (lt, name)
         assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL, lt
+
+
+# ------------------------------------------------------------------ committed golden vectors
+def test_hip_path_matches_committed_golden_vectors(stattn_mod, O):
+    """tests/golden/*.npz (float64 oracle outputs, fixed seeds; generator: tests/golden/make_golden.py)."""
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    P32 = dict(np.load(os.path.join(gold, 'params.npz')))
+    opt = O.default_options(dim=64, dim_word=64, n_words=37, ctxg_dim=64, ctxl_dim=32, ctxm_dim=32, ctxglm_dim=64)
+    for lt in (0, 1):
+        dec = stattn_mod.Decoder(opt, lt_mode=lt)
+        dec.set_params(P32)
+        tg = np.load(os.path.join(gold, 'train_graph.npz'))
+        batch = {k[3:]: tg[k] for k in tg.files if k.startswith('in_')}
+        dec.set_batch(**batch)
+        dec.forward_train()
+        out = dec.get_forward(logits=True)
+        st = dec.get_states()
+        for k in ('alphal', 'alphag', 'alpham', 'alphalt', 'probs'):
+            assert np.abs(out[k] - tg[k]).max() < TOL, (lt, k)
+        assert np.abs(out['logit'] - tg['logit'].reshape(out['logit'].shape)).max() < TOL
+        np.testing.assert_allclose(out['cost'], tg['cost'], rtol=1e-4, atol=1e-4)
+        assert np.abs(st['h'] - tg['h']).max() < TOL and np.abs(st['ctx'] - tg['ctx']).max() < TOL
+        if lt == 1:
+            dec.backward(alpha_c=0.70602)
+            np.testing.assert_allclose(dec.get_loss(1e-4), float(tg['loss']), rtol=2e-4)
+            for k in P32:
+                # golden gradients include the L2 term 2 * decay_c * theta, applied by update() in the product
+                ref = tg['grad_' + k] - 2e-4 * P32[k].astype(np.float64)
+                got = dec.get_grad(k)
+                assert np.abs(got - ref).max() <= 2e-3 * np.abs(ref).max() + 1e-6, k
+        sc = np.load(os.path.join(gold, 'sampler_chain.npz'))
+        g, l, m, gm = sc['ctxg'], sc['ctxl'], sc['ctxm'], sc['ctxg_mask']
+        _, h0, c0 = dec.f_init(g, gm)
+        assert np.abs(h0 - sc['h0']).max() < TOL and np.abs(c0 - sc['c0']).max() < TOL
+        for mm in (1, 3):
+            h, c = sc['m%d_h_in' % mm].astype(np.float32), sc['m%d_c_in' % mm].astype(np.float32)
+            for s in range(3):
+                (probs, _, h2, c2), ex = dec.f_next(sc['m%d_s%d_x' % (mm, s)], g, gm, l, None, m, None, h, c, extras=True)
+                for k in ('alphal', 'alphag', 'alpham', 'alphalt', 'logit'):
+                    assert np.abs(ex[k] - sc['m%d_s%d_%s' % (mm, s, k)]).max() < TOL, (lt, mm, s, k)
+                assert np.abs(probs - sc['m%d_s%d_probs' % (mm, s)]).max() < TOL
+                h = sc['m%d_s%d_h' % (mm, s)].astype(np.float32); c = sc['m%d_s%d_c' % (mm, s)].astype(np.float32)

@@ -209,3 +209,47 @@ def test_clip_and_adadelta_follow_common_py():
     ud = -np.sqrt(1e-6) / np.sqrt(e_rg2 + 1e-6) * gr['a']
     np.testing.assert_allclose(rg2['a'], e_rg2); np.testing.assert_allclose(p['a'], 1.0 + ud)
     np.testing.assert_allclose(ru2['a'], 0.05 * ud ** 2)
+
+
+# ------------------------------------------------------------------ committed golden vectors
+import os as _os
+
+GOLD = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), 'golden')
+GOLD_DIMS = dict(dim=64, dim_word=64, n_words=37, ctxg_dim=64, ctxl_dim=32, ctxm_dim=32, ctxglm_dim=64)
+
+
+def _gold():
+    P32 = OrderedDict(np.load(_os.path.join(GOLD, 'params.npz')))
+    opt = O.default_options(**GOLD_DIMS)
+    order = list(O.param_shapes(opt))
+    return opt, OrderedDict((k, P32[k]) for k in order)
+
+
+def test_oracle_reproduces_committed_golden_vectors():
+    """tests/golden/*.npz were written by make_golden.py with the float64 oracle; the oracle must keep
+    reproducing them (float64: to rounding; float32 arithmetic: within the 1e-4 parity bar)."""
+    opt, P32 = _gold()
+    P = O.cast_params(P32, np.float64)
+    tg = np.load(_os.path.join(GOLD, 'train_graph.npz'))
+    batch = {k[3:]: tg[k] for k in tg.files if k.startswith('in_')}
+    b64 = {k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()}
+    fwd = O.build_model_forward(P, opt, **b64)
+    for k in ('cost', 'probs', 'alphal', 'alphag', 'alpham', 'alphalt', 'logit', 'h', 'c', 'ctx'):
+        np.testing.assert_allclose(fwd[k], tg[k], rtol=1e-10, atol=1e-12)
+    f32 = O.build_model_forward(P32, opt, **batch)                      # the reference's floatX=float32 arithmetic
+    for k in ('alphal', 'alphag', 'alpham', 'alphalt', 'logit'):
+        assert np.abs(f32[k] - tg[k]).max() < 1e-4, k
+    gr = OG.loss_and_grads(P, opt, batch, decay_c=1e-4, alpha_c=0.70602)
+    np.testing.assert_allclose(gr['loss'], float(tg['loss']), rtol=1e-12)
+    for k, v in gr['grads'].items():
+        np.testing.assert_allclose(v, tg['grad_' + k], rtol=1e-9, atol=1e-13)
+    sc = np.load(_os.path.join(GOLD, 'sampler_chain.npz'))
+    g, l, m, gm = sc['ctxg'].astype(np.float64), sc['ctxl'].astype(np.float64), sc['ctxm'].astype(np.float64), sc['ctxg_mask']
+    _, h0, c0 = O.f_init(P, opt, g, gm.astype(np.float64))
+    np.testing.assert_allclose(h0, sc['h0'], rtol=1e-10)
+    for mm in (1, 3):
+        h, c = sc['m%d_h_in' % mm], sc['m%d_c_in' % mm]
+        for s in range(3):
+            (probs, _, h, c), r = O.f_next(P, opt, sc['m%d_s%d_x' % (mm, s)], g, gm, l, None, m, None, h, c, extras=True)
+            np.testing.assert_allclose(probs, sc['m%d_s%d_probs' % (mm, s)], rtol=1e-10, atol=1e-14)
+            np.testing.assert_allclose(r['alphal'], sc['m%d_s%d_alphal' % (mm, s)], rtol=1e-10)

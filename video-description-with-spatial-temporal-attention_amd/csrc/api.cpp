@@ -43,7 +43,7 @@ struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
 };
 
-enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_COUNT };
+enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_COUNT };
 
 struct Weights {   // device pointers into the flat parameter buffer
     float *Wemb, *ff_state_W, *ff_state_b, *ff_memory_W, *ff_memory_b, *ff_local_W, *ff_local_b,
@@ -249,6 +249,13 @@ void prof_collect(stattn_handle* h) {
     h->ev_used.clear();
 }
 
+// every plain (NN) launch of the LDS-tiled GEMM in the forward pass is timed as one class: its average
+// duration is what rocprofv3 reports for the symbol gemm_kernel<.., false, false>
+hipError_t gemm_nn(stattn_handle* h, const GemmArgs& g) {
+    Prof pr(h, KC_GEMM_NN);
+    return launch_gemm(h->stream, g, false, false);
+}
+
 // ---- shared building blocks ---------------------------------------------------------
 // Project raw features of `nv` videos to the decoder's context tensors (the part f_next
 // recomputes on every call in the reference, model_attention.py:782-785 + 322-326).
@@ -264,26 +271,26 @@ int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, c
     gemm_defaults(g);
     g.A = ctxl; g.lda = h->Fl; g.B = w.ff_local_W; g.ldb = D; g.C = c.L; g.ldc = D;
     g.M = nv * T * K; g.N = D; g.K = h->Fl; g.bias = w.ff_local_b; g.act = 1;
-    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    HIPCHK(h, gemm_nn(h, g));
     // M = tanh(ctxm . ff_motion_W + b) (:666-667 / :784-785)
     gemm_defaults(g);
     g.A = ctxm; g.lda = h->Fm; g.B = w.ff_motion_W; g.ldb = D; g.C = c.Mo; g.ldc = D;
     g.M = nv * T; g.N = D; g.K = h->Fm; g.bias = w.ff_motion_b; g.act = 1;
-    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    HIPCHK(h, gemm_nn(h, g));
     // pctxg_, pctxl_, pctxm_ (:322-326)
     gemm_defaults(g);
     g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
-    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    HIPCHK(h, gemm_nn(h, g));
     gemm_defaults(g);
     g.A = c.L; g.lda = D; g.B = w.Wcl; g.ldb = D; g.C = c.PL; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D; g.bias = w.bl;
-    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    HIPCHK(h, gemm_nn(h, g));
     gemm_defaults(g);
     g.A = c.Mo; g.lda = D; g.B = w.Wcm; g.ldb = D; g.C = c.PM; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bm;
-    HIPCHK(h, launch_gemm(h->stream, g, false, false));
+    HIPCHK(h, gemm_nn(h, g));
     if (h->opt.lt_mode == 1) {   // LW = L . Wclt  (the :416 projection hoisted out of the time loop)
         gemm_defaults(g);
         g.A = c.L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = c.LW; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D;
-        HIPCHK(h, launch_gemm(h->stream, g, false, false));
+        HIPCHK(h, gemm_nn(h, g));
     }
     return STATTN_OK;
 }
@@ -841,7 +848,7 @@ int stattn_forward_train(stattn_handle* h) {
         gemm_defaults(g);                                                   // x_ = emb.W + b (:334-335)
         g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
         g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
-        HIPCHK(h, launch_gemm(s, g, false, false));
+        HIPCHK(h, gemm_nn(h, g));
     }
 
     // ---- the scan over caption positions (:495-512)
@@ -870,18 +877,18 @@ int stattn_forward_train(stattn_handle* h) {
         g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
         if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; g.Cact = tz; g.ldcact = E; }
-        HIPCHK(h, launch_gemm(s, g, false, false));
+        HIPCHK(h, gemm_nn(h, g));
         if (h->opt.ctx2out) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
             gemm_defaults(g);
             g.A = ctx; g.lda = D; g.B = w.Wl2; g.ldb = E; g.C = a1; g.ldc = E;
             g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E;
             g.Cact = tz; g.ldcact = E;
-            HIPCHK(h, launch_gemm(s, g, false, false));
+            HIPCHK(h, gemm_nn(h, g));
         }
         gemm_defaults(g);      // logit = a.Wo + bo
         g.A = a1; g.lda = E; g.B = w.Wo; g.ldb = Vp; g.C = lg; g.ldc = Vp;
         g.M = (int)R; g.N = Vp; g.K = E; g.bias = w.bo;
-        HIPCHK(h, launch_gemm(s, g, false, false));
+        HIPCHK(h, gemm_nn(h, g));
     }
     HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, dx, nll, nullptr, (int)R, V));
     HIPCHK(h, launch_cost(s, nll, dmask, cost, t, m));

@@ -86,29 +86,129 @@ def fast_params(options, seed):
     return P
 
 
-def cpu_baseline(c, options, params, seed, budget_s=20.0):
-    """Oracle (kind = port) on host cores: same graph, same shapes, a bounded sample of rows."""
+def cpu_baseline(c, options, params, seed, train, budget_s=20.0):
+    """Oracle (kind = port) on host cores: same graph, same shapes, a bounded sample of rows.
+    train: torch-autograd restatement of the loss (forward + backward, the analogue of Theano's
+    tensor.grad) + clip + Adadelta in numpy; forward: the numpy restatement of build_model."""
+    from collections import OrderedDict
     from oracle import stattn_oracle as O
-    def run(rows):
-        batch = synthetic_batch(dict(c, B=rows), seed)
-        t0 = time.time()
-        O.build_model_forward(params, options, **batch)
-        return time.time() - t0
-    run(2)                                   # warm-up (BLAS thread pool, page faults)
-    rows = min(8, c["B"])
+    if train:
+        import torch
+        from oracle import stattn_oracle_grad as OG
+        P = OrderedDict((k, np.asarray(v)) for k, v in params.items())
+        rg2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+        ru2 = OrderedDict((k, np.zeros_like(v)) for k, v in P.items())
+
+        def run(rows):
+            batch = synthetic_batch(dict(c, B=rows), seed)
+            t0 = time.time()
+            g = OG.loss_and_grads(P, options, batch, decay_c=1e-4, alpha_c=0.70602, dtype=torch.float32)['grads']
+            O.adadelta_update(P, O.clip_grads(g, 10.0), rg2, ru2)
+            return time.time() - t0
+        threads = torch.get_num_threads()
+        what = "oracle train step: torch-autograd float32 forward+backward + numpy clip/Adadelta"
+    else:
+        def run(rows):
+            batch = synthetic_batch(dict(c, B=rows), seed)
+            t0 = time.time()
+            O.build_model_forward(params, options, **batch)
+            return time.time() - t0
+        try:
+            import threadpoolctl
+            threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+        except Exception:
+            threads = os.cpu_count()
+        what = "oracle build_model_forward, float32 numpy (BLAS GEMMs)"
+    run(2)                                   # warm-up (thread pools, page faults)
+    rows = min(4, c["B"])
     dt = run(rows)
     rows2 = int(min(c["B"], max(rows, rows * budget_s / max(dt, 1e-3))))
     if rows2 > rows:                         # grow the sample towards the time budget, at most one batch
         rows = rows2
         dt = run(rows)
-    try:
-        import threadpoolctl
-        threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
-    except Exception:
-        threads = os.cpu_count()
     return dict(value=rows * c["t"] / dt, unit="row-steps/s", cores=int(threads), kind="port",
-                sample="oracle build_model_forward, float32 numpy (BLAS GEMMs), %d rows x %d steps of the same "
-                       "shapes incl. the once-per-batch F->D projections; %.1f s" % (rows, c["t"], dt))
+                sample="%s, %d rows x %d steps of the same shapes incl. the once-per-batch F->D projections; %.1f s"
+                       % (what, rows, c["t"], dt))
+
+
+def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
+    """BASELINE.md section 3 protocol: gen_sample (model_attention.py:852-994) per video through f_init / f_next,
+    <eos> suppressed so every hypothesis runs maxlen = caption length steps; row-steps = hypotheses x steps.
+    The boundary hands host arrays to f_next on every call exactly like the reference (:903); the library caches
+    the projected video.  Videos are sharded over ranks, no collective (replicas only)."""
+    import stattn
+    model = stattn.Attention()
+    t = c["t"]
+    V = c["V"]
+
+    def f_init(g, m):
+        return dec.f_init(g, m)
+    nsteps = [0]
+
+    def f_next(*a):
+        r = dec.f_next(*a)
+        r[0][:, 0] = 0.0                     # forbid <eos>: deterministic step counts (SURVEY section 8d)
+        nsteps[0] += a[0].shape[0]
+        return r
+    vids = [(batch['ctxg'][i], batch['mask_ctxg'][i], batch['ctxl'][i], batch['mask_ctxl'][i], batch['ctxm'][i],
+             batch['mask_ctxm'][i]) for i in range(c["B"])]
+
+    def one_pass():
+        for v in vids:
+            model.gen_sample(None, f_init, f_next, *v, options, None, args.beam, maxlen=t)
+    for _ in range(args.warmup):
+        one_pass()
+    dec.sync()
+    nsteps[0] = 0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_pass()
+    dec.sync()
+    dt = time.perf_counter() - t0
+    rowsteps = nsteps[0] * world
+    out = dict(metric="decoder steps/sec (batch x timestep)", value=rowsteps / dt, unit="row-steps/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="%s decode: gen_sample(k=%d, maxlen=%d, <eos> suppressed) over %d videos per GPU through "
+                                    "f_init/f_next with host arrays per call, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
+                                    % (args.config, args.beam, t, c["B"], c["T"], c["K"], c["F"], c["D"], c["E"], V, dec.lt_mode),
+                           videos=c["B"] * world, beam=args.beam, parallelism="replicas%d" % world))
+    if rank == 0:
+        if not args.no_cpu_baseline:
+            from oracle import stattn_oracle as O
+            nv = min(2, c["B"])
+            res = {}
+            for label, cached in (("reference-faithful (F->D re-projection on every f_next call, model_attention.py:782-785)", False),
+                                  ("projection cached", True)):
+                cnt = [0]
+                cache = {}
+
+                def fn(x, g, gm, l, lm, m, mm, h, cc):
+                    cnt[0] += x.shape[0]
+                    cv = None
+                    if cached:
+                        key = id(l)
+                        if key not in cache:
+                            cache[key] = O.project_video(params, options, g, l, m)
+                        cv = cache[key]
+                    return O.f_next(params, options, x, g, gm, l, lm, m, mm, h, cc, cached=cv)
+                t0 = time.time()
+                for v in vids[:nv]:
+                    O.gen_sample(lambda g, m: O.f_init(params, options, g, m), fn, *v, k=args.beam, maxlen=t, suppress_eos=True)
+                res[label] = cnt[0] / (time.time() - t0)
+            keys = list(res)
+            try:
+                import threadpoolctl
+                threads = max([p.get("num_threads", 1) for p in threadpoolctl.threadpool_info()] or [1])
+            except Exception:
+                threads = os.cpu_count()
+            out["cpu_baseline"] = dict(value=res[keys[0]], unit="row-steps/s", cores=int(threads), kind="port",
+                                       sample="oracle gen_sample over %d videos, float32 numpy; %s; with the projection cached: %.1f row-steps/s"
+                                              % (nv, keys[0], res[keys[1]]))
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
 
 
 def main():
@@ -117,7 +217,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="train", choices=["train", "forward"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward", "decode"])
+    ap.add_argument("--beam", type=int, default=1, help="decode mode: beam width k of gen_sample (1 = greedy)")
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
@@ -148,6 +249,8 @@ def main():
     dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode)
     dec.set_params(params)
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
+    if args.mode == "decode":
+        return decode_bench(args, c, options, params, dec, batch, rank, world, dist)
     dec.set_batch(**batch)                            # inputs resident in HBM before the timed region
     train = args.mode == "train"
     dec.set_use_noise(1.0 if train else 0.0)
@@ -227,7 +330,7 @@ def main():
                kernel_ms={k: v[0] for k, v in kms.items()})
     if rank == 0:
         if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(c, options, params, 99)
+            out["cpu_baseline"] = cpu_baseline(c, options, params, 99, train)
         print(json.dumps(out))
     if world > 1:
         dist.barrier()

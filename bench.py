@@ -38,6 +38,8 @@ CONFIGS = {
     "c2": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
     # configs[0] "MSVD tiny"
     "c1": dict(B=4, T=26, K=8, F=4096, D=512, E=512, V=12000, t=30),
+    # configs[4] "Long-context beam search": 32 videos, T=80, K=32, beam 5 (feat / hidden / vocab from configs[1])
+    "c5": dict(B=32, T=80, K=32, F=4096, D=1024, E=512, V=12000, t=30),
     "smoke": dict(B=8, T=6, K=4, F=128, D=128, E=64, V=500, t=5),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
@@ -211,13 +213,44 @@ def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
         dist.destroy_process_group()
 
 
+def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
+    """Batched device-side beam search (stattn_beam_search): all B videos x k beams advance together, the
+    bookkeeping of gen_sample (model_attention.py:921-985) runs on the device, <eos> suppressed.  The raw
+    features are staged in HBM by the warm-up call; every timed call redoes the per-video F->D projections.
+    row-steps = hypothesis-steps actually evaluated by the reference's loop: 1 + k (maxlen - 1) per video."""
+    k = args.beam if args.beam > 1 else 5
+    t = c["t"]
+    a = (batch['ctxg'], batch['mask_ctxg'], batch['ctxl'], batch['ctxm'])
+    for _ in range(max(1, args.warmup)):
+        dec.beam_search(*a, k=k, maxlen=t, suppress_eos=True)
+    dec.sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dec.beam_search(*a, k=k, maxlen=t, suppress_eos=True)
+    dec.sync()
+    dt = time.perf_counter() - t0
+    rowsteps = c["B"] * (1 + k * (t - 1)) * args.steps * world
+    out = dict(metric="decoder steps/sec (batch x timestep)", value=rowsteps / dt, unit="row-steps/s", n_gpus=world,
+               steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               config=dict(workload="%s beam: batched device-side beam search, %d videos x beam %d, maxlen %d, <eos> suppressed, "
+                                    "T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
+                                    % (args.config, c["B"], k, t, c["T"], c["K"], c["F"], c["D"], c["E"], c["V"], dec.lt_mode),
+                           videos=c["B"] * world, beam=k, parallelism="replicas%d" % world))
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
-    ap.add_argument("--mode", default="train", choices=["train", "forward", "decode"])
+    ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam"])
     ap.add_argument("--beam", type=int, default=1, help="decode mode: beam width k of gen_sample (1 = greedy)")
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -251,6 +284,8 @@ def main():
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
     if args.mode == "decode":
         return decode_bench(args, c, options, params, dec, batch, rank, world, dist)
+    if args.mode == "beam":
+        return beam_bench(args, c, options, params, dec, batch, rank, world, dist)
     dec.set_batch(**batch)                            # inputs resident in HBM before the timed region
     train = args.mode == "train"
     dec.set_use_noise(1.0 if train else 0.0)

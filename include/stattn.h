@@ -116,6 +116,17 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m,
                   float* out_logits);
 int stattn_invalidate_ctx_cache(stattn_handle* h);
 
+/* Batched beam search: gen_sample (model_attention.py:852-994) for `nvid` videos at once with the whole
+ * bookkeeping on the device (candidate costs hyp_score - log p, top (k - dead_k), hypothesis / state gather,
+ * :921-985) -- one fixed kernel sequence per word, no host round trip; the videos' F->D projections are done
+ * once.  ctxg (nvid,T,D), ctxg_mask (nvid,T), ctxl (nvid,T,K,F), ctxm (nvid,T,F); 1 <= k <= 8.
+ * Per video the hypotheses come back in gen_sample's order (finished ones in order of death, then the live
+ * ones): out_tokens (nvid,k,maxlen) int64, -1 padded; out_scores, out_lens (nvid,k); out_count (nvid).
+ * suppress_eos != 0 forbids word 0 so that every hypothesis runs maxlen steps (benchmarks). */
+int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                       const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
+                       int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count);
+
 /* ---- training graph: build_model / f_log_probs / f_grad_shared (:583-717, 1126, 1207) -- */
 /* Stage one minibatch in HBM: prepare_data()'s 8-tuple (data_engine.py:258-337).
  * x (t,m) int64, mask (t,m), ctxg (m,T,D), mask_ctxg (m,T), ctxl (m,T,K,F),

@@ -323,3 +323,85 @@ def test_hip_path_matches_committed_golden_vectors(stattn_mod, O):
                     assert np.abs(ex[k] - sc['m%d_s%d_%s' % (mm, s, k)]).max() < TOL, (lt, mm, s, k)
                 assert np.abs(probs - sc['m%d_s%d_probs' % (mm, s)]).max() < TOL
                 h = sc['m%d_s%d_h' % (mm, s)].astype(np.float32); c = sc['m%d_s%d_c' % (mm, s)].astype(np.float32)
+
+
+# ------------------------------------------------------------------ BASELINE.json configs[3], configs[4] shapes
+def test_c4_msrvtt_shape_fp32(stattn_mod, O):
+    """configs[3] 'MSR-VTT-shape stress': T=40, K=16 regions (two region groups in the kernels), feat=2048,
+    hidden=1024 -- run in fp32 (the bf16 MFMA variant of this config is not built yet)."""
+    dims = dict(dim=1024, dim_word=512, n_words=3000, ctxg_dim=1024, ctxl_dim=2048, ctxm_dim=2048, ctxglm_dim=1024)
+    opt, P, P64, dec = _decoder(stattn_mod, O, dims, 1, seed=21)
+    batch = O.synthetic_batch(opt, B=3, T=40, K=16, t=4, seed=60)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    ref = O.build_model_forward(P64, opt, **_f64(batch))
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name] - ref[name]).max() < TOL, name
+    assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL
+
+
+def test_c5_long_context_beam_shape(stattn_mod, O):
+    """configs[4] 'Long-context beam search': T=80, K=32 (four region groups), beam=5 hypotheses per video."""
+    dims = dict(dim=512, dim_word=256, n_words=2000, ctxg_dim=512, ctxl_dim=1024, ctxm_dim=1024, ctxglm_dim=512)
+    for lt in (0, 1):
+        opt, P, P64, dec = _decoder(stattn_mod, O, dims, lt, seed=22)
+        b = O.synthetic_batch(opt, B=1, T=80, K=32, t=3, seed=61)
+        g, l, m, gm = b['ctxg'][0], b['ctxl'][0], b['ctxm'][0], b['mask_ctxg'][0]
+        rng = np.random.RandomState(4)
+        h = (0.5 * rng.standard_normal((5, 512))).astype(np.float32); c = (0.5 * rng.standard_normal((5, 512))).astype(np.float32)
+        x = np.array([-1, 4, 99, 1500, 7], np.int64)
+        (probs, _, h1, c1), ex = dec.f_next(x, g, gm, l, None, m, None, h, c, extras=True)
+        (pr, _, h1r, c1r), r = O.f_next(P64, opt, x, g.astype(np.float64), gm, l.astype(np.float64), None,
+                                        m.astype(np.float64), None, h.astype(np.float64), c.astype(np.float64), extras=True)
+        for name in ('alphal', 'alphag', 'alpham', 'alphalt', 'logit'):
+            assert np.abs(ex[name] - r[name]).max() < TOL, (lt, name)
+        assert np.abs(h1 - h1r).max() < TOL and np.abs(c1 - c1r).max() < TOL
+    # beam search with k=5 on this shape: same hypotheses and scores as the oracle driver
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    args = (g, gm, l, b['mask_ctxl'][0], m, b['mask_ctxm'][0])
+    s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 5, maxlen=6)
+    a64 = tuple(a.astype(np.float64) for a in args)
+    sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=5, maxlen=6)
+    np.testing.assert_allclose(sorted(np.asarray(sc, np.float64)), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=1e-4)
+    assert s[int(np.argmin(sc))] == sr[int(np.argmin(scr))]
+
+
+# ------------------------------------------------------------------ batched device-side beam search
+@pytest.mark.parametrize("k", [1, 3, 5])
+def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
+    """stattn_beam_search (device-side bookkeeping, many videos at once) against gen_sample per video --
+    both the product's host-driven loop and the oracle's.  <eos> is made likely so hypotheses die at
+    different steps (dead_k bookkeeping, early termination, dump of the remaining live ones)."""
+    opt = O.default_options(**SMALL)
+    P = O.random_params(opt, seed=15, dtype=np.float32)
+    P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 3.0        # word 0 = <eos>
+    P64 = O.cast_params(P, np.float64)
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    nvid, T, K, maxlen = 6, 5, 4, 9
+    b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=70)
+    res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
+    assert len(res) == nvid
+    n_eos = 0
+    for v in range(nvid):
+        args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+        s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=maxlen)
+        a64 = tuple(a.astype(np.float64) for a in args)
+        sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=k, maxlen=maxlen)
+        bs, bsc = res[v]
+        assert len(bs) == len(s) == len(sr), (v, len(bs), len(s), len(sr))
+        assert bs == s, (v, bs, s)                                   # same hypotheses, same order as the host loop
+        np.testing.assert_allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)
+        np.testing.assert_allclose(sorted(bsc), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=1e-4)
+        assert bs[int(np.argmin(bsc))] == sr[int(np.argmin(scr))]
+        n_eos += sum(1 for x in bs if x[-1] == 0)
+    assert n_eos > 0                                                 # the death path was exercised
+    # eos suppressed: every hypothesis runs maxlen steps and never contains word 0
+    res2 = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen, suppress_eos=True)
+    for bs, bsc in res2:
+        assert len(bs) == k and all(len(x) == maxlen and 0 not in x for x in bs)
+        assert list(bsc) == sorted(bsc)

@@ -54,6 +54,8 @@ _SIGNATURES = {
     "stattn_f_next": (C.c_int, [_H, _I64, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _F, _F,
                                 _F, _I64, _F, _F, _F, _F, _F, _F, _F]),
     "stattn_invalidate_ctx_cache": (C.c_int, [_H]),
+    "stattn_beam_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                     _I64, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
     "stattn_forward_train": (C.c_int, [_H]),
     "stattn_get_forward": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F]),
@@ -275,6 +277,26 @@ class Decoder(object):
         out = [probs, sample, ho, co]
         if extras:
             return out, dict(alphal=al, alphag=ag, alpham=am, alphalt=alt, logit=lg)
+        return out
+
+    def beam_search(self, ctxg, ctxg_mask, ctxl, ctxm, k=5, maxlen=30, suppress_eos=False):
+        """gen_sample for a batch of videos, device-side (stattn_beam_search).  Returns a list with one
+        (samples, scores) pair per video, ordered like gen_sample's return value."""
+        ctxl = _f32(ctxl, "ctxl")
+        if ctxl.ndim != 4 or ctxl.shape[3] != self.Fl:
+            raise ValueError("ctxl must be (nvid, T, K, %d)" % self.Fl)
+        nvid, T, K = ctxl.shape[0], ctxl.shape[1], ctxl.shape[2]
+        ctxg = _f32(ctxg, "ctxg", (nvid, T, self.D)); ctxg_mask = _f32(ctxg_mask, "ctxg_mask", (nvid, T))
+        ctxm = _f32(ctxm, "ctxm", (nvid, T, self.Fm))
+        tok = np.empty((nvid, k, maxlen), np.int64); sc = np.empty((nvid, k), np.float32)
+        ln = np.empty((nvid, k), np.int32); cnt = np.empty((nvid,), np.int32)
+        self._chk(self._lib.stattn_beam_search(self._h, nvid, _fp(ctxg), _fp(ctxg_mask), _fp(ctxl), _fp(ctxm), T, K, int(k),
+                                               int(maxlen), int(bool(suppress_eos)), tok.ctypes.data_as(_I64), _fp(sc),
+                                               ln.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        out = []
+        for v in range(nvid):
+            samples = [tok[v, j, :ln[v, j]].tolist() for j in range(cnt[v])]
+            out.append((samples, sc[v, :cnt[v]].copy()))
         return out
 
     def invalidate_ctx_cache(self):

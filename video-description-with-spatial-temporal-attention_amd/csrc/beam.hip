@@ -1,0 +1,138 @@
+// Device-side beam search bookkeeping for the batched sampler (gfx950).
+//
+// The reference decodes one video at a time: per word one f_next call, then on the host
+// `cand = hyp_scores[:,None] - log(next_p)`, a flat argsort over live_k x V candidates, and Python
+// list surgery (model_attention.py:921-985) -- ~0.5 ms of numpy per word at k = 5, V = 12k, more than
+// the whole decoder step on the GPU.  Here the same bookkeeping runs on the device for many videos at
+// once (one workgroup per video), so a decode step is a fixed kernel sequence with no host round trip:
+//   beam_topk_kernel    the (k - dead_k) smallest candidate costs of a video           (:921-928)
+//   beam_update_kernel  new hypotheses, finished ones (word 0) retired, h/c gathered    (:939-985)
+#include "kernels.h"
+#include "devmath.h"
+
+namespace stattn {
+
+namespace {
+
+constexpr int KB = 8;   // maximum beam width
+
+__global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
+    __shared__ float s_cost[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_owner[4];
+    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int k = a.k, V = a.V;
+    const int live = a.live_k[v], dead = a.dead_k[v];
+    const int n = live > 0 ? k - dead : 0;                    // how many candidates survive (:923)
+    if (tid == 0) a.nsel[v] = n;
+    if (n <= 0) return;
+    // thread-local sorted list of its KB best (cost ascending; ties: lower flat index first)
+    float lc[KB]; int li[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+    for (int j = 0; j < live; ++j) {
+        const float hs = a.hyp_score[v * k + j];
+        const float* __restrict__ p = a.probs + (size_t)(v * k + j) * a.ldp;
+        for (int wd = tid; wd < V; wd += 256) {
+            float pr = p[wd];
+            if (a.suppress_eos && wd == 0) pr = 0.f;
+            const float c = hs - logf(pr);                    // hyp_scores[:,None] - log(next_p)  (:921), float32
+            const int flat = j * V + wd;
+            if (c < lc[KB - 1] || (c == lc[KB - 1] && flat < li[KB - 1])) {
+                lc[KB - 1] = c; li[KB - 1] = flat;
+#pragma unroll
+                for (int i = KB - 1; i > 0; --i) {            // one bubble pass keeps the list sorted
+                    const bool sw = lc[i] < lc[i - 1] || (lc[i] == lc[i - 1] && li[i] < li[i - 1]);
+                    if (sw) { const float tc = lc[i]; lc[i] = lc[i - 1]; lc[i - 1] = tc; const int ti = li[i]; li[i] = li[i - 1]; li[i - 1] = ti; }
+                }
+            }
+        }
+    }
+    // n rounds of a workgroup-wide arg-min over the list heads; the winner pops its head
+    for (int r = 0; r < n; ++r) {
+        float c = lc[0]; int idx = li[0]; int owner = tid;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
+            if (oc < c || (oc == c && oi < idx)) { c = oc; idx = oi; owner = oo; }
+        }
+        if (lane == 0) { s_cost[w] = c; s_idx[w] = idx; s_owner[w] = owner; }
+        __syncthreads();
+        c = s_cost[0]; idx = s_idx[0]; owner = s_owner[0];
+#pragma unroll
+        for (int i = 1; i < 4; ++i)
+            if (s_cost[i] < c || (s_cost[i] == c && s_idx[i] < idx)) { c = s_cost[i]; idx = s_idx[i]; owner = s_owner[i]; }
+        if (tid == 0) {
+            a.sel_cost[v * k + r] = c;
+            a.sel_ti[v * k + r] = idx / V;                    // trans_indices = ranks_flat // voc_size (:926)
+            a.sel_wi[v * k + r] = idx % V;                    // word_indices  = ranks_flat %  voc_size (:927)
+        }
+        if (tid == owner) {
+#pragma unroll
+            for (int i = 0; i < KB - 1; ++i) { lc[i] = lc[i + 1]; li[i] = li[i + 1]; }
+            lc[KB - 1] = INFINITY; li[KB - 1] = 0x7fffffff;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
+    __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
+    __shared__ int s_n;
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int k = a.k, D = a.D, L = a.maxlen, step = a.step;
+    if (tid == 0) {
+        const int n = a.nsel[v];
+        int dead = a.dead_k[v], nl = 0;
+        for (int r = 0; r < n; ++r) {
+            const int ti = a.sel_ti[v * k + r], wi = a.sel_wi[v * k + r];
+            s_ti[r] = ti; s_wi[r] = wi;
+            if (wi == 0) {                                     // <eos>: the hypothesis dies (:958-962)
+                s_fin[r] = 1; s_slot[r] = dead;
+                a.fin_score[v * k + dead] = a.sel_cost[v * k + r];
+                a.fin_len[v * k + dead] = step + 1;
+                ++dead;
+            } else {                                           // stays live (:963-970)
+                s_fin[r] = 0; s_slot[r] = nl;
+                a.hyp_score_out[v * k + nl] = a.sel_cost[v * k + r];
+                a.next_w[v * k + nl] = wi;
+                ++nl;
+            }
+        }
+        s_n = n;
+        if (n > 0) {
+            a.dead_k[v] = dead;
+            a.live_k[v] = (nl < 1 || dead >= k) ? 0 : nl;      // :974-977
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int r = 0; r < n; ++r) {
+        const int ti = s_ti[r], slot = s_slot[r];
+        const int* __restrict__ src = a.tok_in + (size_t)(v * k + ti) * L;
+        int* __restrict__ dst = (s_fin[r] ? a.fin_tok : a.tok_out) + (size_t)(v * k + slot) * L;
+        for (int i = tid; i < step; i += 256) dst[i] = src[i];
+        if (tid == 0) dst[step] = s_wi[r];
+        if (!s_fin[r]) {                                       // gather the state of the parent hypothesis (:943-945)
+            const float* __restrict__ hs = a.h_step + (size_t)(v * k + ti) * D;
+            const float* __restrict__ cs = a.c_step + (size_t)(v * k + ti) * D;
+            float* __restrict__ hd = a.h_next + (size_t)(v * k + slot) * D;
+            float* __restrict__ cd = a.c_next + (size_t)(v * k + slot) * D;
+            for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
+        }
+    }
+}
+
+}  // namespace
+
+hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a) {
+    if (a.k > KB || a.k < 1) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(beam_topk_kernel, dim3(a.nvid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a) {
+    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a);
+    return hipGetLastError();
+}
+
+}  // namespace stattn

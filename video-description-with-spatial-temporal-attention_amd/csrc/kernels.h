@@ -232,4 +232,22 @@ hipError_t launch_state0_bwd(hipStream_t s, const float* dh_pass, const float* d
 hipError_t launch_decay_sumsq(hipStream_t s, float* g, const float* p, float two_decay, size_t n, float* part, int nblocks);
 hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c);
 
+// ----------------------------------------------------------------------------
+// batched device-side beam search (beam.hip)
+// ----------------------------------------------------------------------------
+struct BeamArgs {
+    const float* probs; int ldp;        // [nvid*k, ldp] next-word probabilities of this step
+    int V, k, D, maxlen, nvid, step, suppress_eos;
+    int* live_k; int* dead_k;           // [nvid]
+    const float* hyp_score; float* hyp_score_out;   // [nvid*k] scores of the live hypotheses (in / out)
+    int* nsel; int* sel_ti; int* sel_wi; float* sel_cost;   // [nvid], [nvid*k] x3
+    const int* tok_in; int* tok_out;    // [nvid*k, maxlen] words of the live hypotheses (in / out)
+    int* fin_tok; float* fin_score; int* fin_len;   // finished hypotheses, in order of death
+    int64_t* next_w;                    // [nvid*k] word fed to the next step
+    const float* h_step; const float* c_step;       // [nvid*k, D] state after this step
+    float* h_next; float* c_next;       // [nvid*k, D] state gathered for the next step
+};
+hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a);
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);
+
 }  // namespace stattn

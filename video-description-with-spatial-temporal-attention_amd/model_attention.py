@@ -298,6 +298,13 @@ class Attention(object):
                     sample_score.append(hyp_scores[idx])
         return sample, sample_score, next_state, next_memory
 
+    def gen_sample_batch(self, tparams, options, ctxgs, ctxg_masks, ctxls, ctxms, k=5, maxlen=30, suppress_eos=False):
+        """Batched counterpart of the evaluation loop of metrics.py:121-135 (one gen_sample per video): all videos
+        and their beams advance together on the device.  Returns [(sample, sample_score), ...] per video with
+        gen_sample's ordering, so `sample[numpy.argmin(score)]` picks the caption exactly as metrics.py:130 does."""
+        dec = self._bind(tparams, options)
+        return dec.beam_search(ctxgs, ctxg_masks, ctxls, ctxms, k=k, maxlen=maxlen, suppress_eos=suppress_eos)
+
     # ---------------------------------------------------------------- teacher-forced scoring
     def pred_probs(self, batches, f_log_probs, verbose=False):
         """model_attention.py:996-1032 over an iterable of prepare_data() 8-tuples: mean NLL and

@@ -1499,7 +1499,7 @@ int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int 
         sg.npairs = 1; sg.p[0] = SkPair{dA, dB + (size_t)i * K * N, K, N, K, (variant & 16) ? (size_t)K * 64 : 0};
         sg.C = dC + (size_t)i * N; sg.ldc = N * nseg; sg.N = N;
     }
-    a.dbg = variant & 15;
+    a.dbg = (variant & 16) ? (variant & 15) : variant;
     for (int i = 0; i < 2; ++i) HIPCHK(h, launch_skinny(s, a));
     hipEvent_t e0, e1;
     HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));

@@ -20,6 +20,8 @@
 #include "kernels.h"
 #include "devmath.h"
 
+#include <cstdlib>
+
 namespace stattn {
 
 namespace {
@@ -33,11 +35,14 @@ constexpr int TILE_N = 64;
 // kernel is otherwise a chain of exposed HBM/L2 latencies (measured 18.8 us vs 9 us for h.[Wd*|U]).
 struct SkOperands { float4 a; float4 b[4]; };
 
+template <int SKIP = 0>   // ablation: 1 = no A loads, 2 = no B loads
 __device__ __forceinline__ void sk_load(SkOperands& o, const float* __restrict__ Ap, const float* __restrict__ Bp, int ldb, int s) {
     const int k0 = s << 4;
-    o.a = ld4(Ap + k0);
+    if (SKIP != 1) o.a = ld4(Ap + k0);
+    if (SKIP != 2) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q) o.b[q] = ld4(Bp + (size_t)(k0 + q) * ldb);
+        for (int q = 0; q < 4; ++q) o.b[q] = ld4(Bp + (size_t)(k0 + q) * ldb);
+    }
 }
 __device__ __forceinline__ void sk_mfma(f32x4 (&acc)[4], const SkOperands& o) {
     const float av[4] = {o.a.x, o.a.y, o.a.z, o.a.w};
@@ -49,6 +54,7 @@ __device__ __forceinline__ void sk_mfma(f32x4 (&acc)[4], const SkOperands& o) {
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], o.b[q].w, acc[3], 0, 0, 0);
     }
 }
+template <int SKIP = 0>
 __device__ __forceinline__ void sk_accumulate(f32x4 (&acc)[4], const SkPair& p, int arow, int bcol,
                                               int ks, int nks, int g) {   // ks / nks: global K-slice index / count
     const int nsteps = p.K >> 4;
@@ -59,18 +65,20 @@ __device__ __forceinline__ void sk_accumulate(f32x4 (&acc)[4], const SkPair& p, 
     int s = ks;
     if (s >= nsteps) return;
     SkOperands o0, o1;
-    sk_load(o0, Ap, Bp, ldb, s);
+    o0.a = make_float4(1.f, 2.f, 3.f, 4.f); o1.a = o0.a;
+    for (int q = 0; q < 4; ++q) { o0.b[q] = o0.a; o1.b[q] = o0.a; }
+    sk_load<SKIP>(o0, Ap, Bp, ldb, s);
     // The prefetch is UNCONDITIONAL (at the tail it re-requests the current step, an L1/L2 hit): a branch
     // around the loads makes hipcc count vmcnt for the no-load path and the wait then drains the prefetch too.
     while (true) {
         int sn = s + nks;
-        sk_load(o1, Ap, Bp, ldb, sn < nsteps ? sn : s);
+        sk_load<SKIP>(o1, Ap, Bp, ldb, sn < nsteps ? sn : s);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMAs (hipcc sinks it to its first use)
         sk_mfma(acc, o0);
         __builtin_amdgcn_sched_barrier(0);
         if (sn >= nsteps) break;
         s = sn; sn = s + nks;
-        sk_load(o0, Ap, Bp, ldb, sn < nsteps ? sn : s);
+        sk_load<SKIP>(o0, Ap, Bp, ldb, sn < nsteps ? sn : s);
         __builtin_amdgcn_sched_barrier(0);
         sk_mfma(acc, o1);
         __builtin_amdgcn_sched_barrier(0);
@@ -159,6 +167,12 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int 
                 }
             }
         }
+    } else if (a.dbg == 32) {
+        for (int p = 0; p < sg.npairs; ++p)
+            sk_accumulate<1>(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
+    } else if (a.dbg == 64) {
+        for (int p = 0; p < sg.npairs; ++p)
+            sk_accumulate<2>(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
     } else if (a.dbg & 8) {
         for (int p = 0; p < sg.npairs; ++p)
             sk_accumulate3(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
@@ -173,6 +187,88 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int 
     sk_spill(red, w, acc, j, g);
     __syncthreads();
 
+    for (int idx = tid; idx < 1024 * mtb; idx += 1024) {
+        const int mo = idx >> 10, rem = idx & 1023, row = rem >> 6, col = rem & 63;
+        const int grow = rowbase + mo * 16 + row;
+        if (grow >= a.M) continue;
+        float v = 0.f;
+        for (int k = 0; k < nks; ++k) v += red[(size_t)(k * mtb + mo) * (16 * TILE_N) + row * TILE_N + col];
+        const int n = n0 + col;
+        if (kz > 1) { sg.C[(size_t)blockIdx.z * a.part_stride + (size_t)grow * sg.ldc + n] = v; continue; }
+        if (sg.bias) v += sg.bias[n];
+        if (sg.bias2) v += sg.bias2[n];
+        if (sg.add) v += sg.add[(size_t)grow * sg.ldadd + n];
+        if (sg.act == 1) v = fast_tanh(v);
+        v *= sg.scale;
+        if (sg.mul) v *= sg.mul[(size_t)grow * sg.ldmul + n];
+        sg.C[(size_t)grow * sg.ldc + n] = v;
+    }
+}
+
+// Variant for mtb >= 2: the mtb waves of a K-slice group need the SAME 16 x 64 B sub-tile in every step.  Loading it
+// once per group (each wave fetches 16/mtb rows) and sharing it through LDS halves / quarters the bytes a CU
+// pulls through its vector-memory path -- which is what bounds this kernel (~10 B/clk/CU: tools/skinny_probe.py,
+// DESIGN.md section 5) -- at the price of one workgroup barrier per step.  Two LDS stages; the staging area
+// aliases the reduction buffer.
+__global__ __launch_bounds__(1024) void skinny_shared_kernel(const SkArgs a, const int mtb) {
+    __shared__ __attribute__((aligned(16))) float red[NW * 16 * TILE_N];
+    int tile = blockIdx.x, si = 0;
+    while (si + 1 < a.nseg && tile >= a.seg[si].N / TILE_N) { tile -= a.seg[si].N / TILE_N; ++si; }
+    const SkSeg& sg = a.seg[si];
+    const int n0 = tile * TILE_N;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int mt = w % mtb, ks = w / mtb, nks = NW / mtb;
+    const int rowbase = blockIdx.y * 16 * mtb;
+    int arow = rowbase + mt * 16 + j;
+    arow = arow < a.M ? arow : a.M - 1;
+    const int kz = a.kz > 1 ? a.kz : 1;
+    const int slice = (int)blockIdx.z * nks + ks, nslices = nks * kz;
+    const int rpw = 16 / mtb;                       // B rows each wave of the group fetches per step (8 or 4)
+    float* sB = red + (size_t)ks * (2 * 16 * TILE_N);   // [2 stages][16 k][64 cols] of this K-slice group
+
+    f32x4 acc[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    int stage = 0;
+    for (int p = 0; p < sg.npairs; ++p) {
+        const SkPair& pr = sg.p[p];
+        const int nsteps = pr.K >> 4;
+        const int iters = (nsteps + nslices - 1) / nslices;      // uniform over the workgroup (barriers inside)
+        const float* __restrict__ Ap = pr.A + (size_t)arow * pr.lda + 4 * g;
+        // this lane's part of the shared B sub-tile: rows mt*rpw + {g, g+4 (mtb = 2)}, columns 4j..4j+3
+        const float* __restrict__ Bp = pr.B + (size_t)(mt * rpw + g) * pr.ldb + n0 + 4 * j;
+        float4 ra, rb0, rb1 = make_float4(0.f, 0.f, 0.f, 0.f);
+        auto gload = [&](int it) {
+            const int s = slice + it * nslices;
+            const bool ok = s < nsteps;
+            const int k0 = (ok ? s : 0) << 4;
+            ra = ld4(Ap + k0);
+            rb0 = ld4(Bp + (size_t)k0 * pr.ldb);
+            if (rpw == 8) rb1 = ld4(Bp + (size_t)(k0 + 4) * pr.ldb);
+            if (!ok) { ra = make_float4(0.f, 0.f, 0.f, 0.f); }   // a zero A row block contributes nothing
+        };
+        gload(0);
+        for (int it = 0; it < iters; ++it) {
+            float* st = sB + stage * (16 * TILE_N);
+            st4(st + (mt * rpw + g) * TILE_N + 4 * j, rb0);
+            if (rpw == 8) st4(st + (mt * rpw + g + 4) * TILE_N + 4 * j, rb1);
+            const float4 acur = ra;
+            __syncthreads();
+            if (it + 1 < iters) gload(it + 1);                   // next step's operands fly during the MFMAs
+            SkOperands o;
+            o.a = acur;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) o.b[q] = ld4(st + (4 * g + q) * TILE_N + 4 * j);
+            __builtin_amdgcn_sched_barrier(0);
+            sk_mfma(acc, o);
+            __builtin_amdgcn_sched_barrier(0);
+            stage ^= 1;
+        }
+    }
+    __syncthreads();                                             // staging area is reused by the reduction
+    sk_spill(red, w, acc, j, g);
+    __syncthreads();
     for (int idx = tid; idx < 1024 * mtb; idx += 1024) {
         const int mo = idx >> 10, rem = idx & 1023, row = rem >> 6, col = rem & 63;
         const int grow = rowbase + mo * 16 + row;
@@ -285,7 +381,12 @@ hipError_t launch_skinny(hipStream_t s, const SkArgs& a) {
     const int kz = a.kz > 1 ? a.kz : 1;
     const int mtb = pick_mtb(ntiles * kz, a.M);
     dim3 grid(ntiles, (a.M + 16 * mtb - 1) / (16 * mtb), kz), block(1024);
-    hipLaunchKernelGGL(skinny_kernel, grid, block, 0, s, a, mtb);
+    bool packed = false;
+    for (int i = 0; i < a.nseg; ++i)
+        for (int p = 0; p < a.seg[i].npairs; ++p) packed = packed || a.seg[i].p[p].tile_stride != 0;
+    static const char* noshare = getenv("STATTN_SKINNY_NOSHARE");
+    if (mtb >= 2 && !packed && !a.dbg && !noshare) hipLaunchKernelGGL(skinny_shared_kernel, grid, block, 0, s, a, mtb);
+    else hipLaunchKernelGGL(skinny_kernel, grid, block, 0, s, a, mtb);
     return hipGetLastError();
 }
 

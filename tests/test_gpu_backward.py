@@ -177,3 +177,32 @@ def test_gradient_buffer_aliases_into_torch_and_rccl_allreduce_runs():
         if own_group:
             dist.destroy_process_group()
         torch.cuda.set_stream(torch.cuda.default_stream())
+
+
+def test_train_loop_counterpart_learns_and_checkpoints(tmp_path):
+    """Attention.train (minimal counterpart of model_attention.py:1239-1517): the loss goes down on a tiny
+    synthetic task, checkpoints use the reference's npz layout (key = parameter name + history_errs), reload works."""
+    import stattn
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**SMALL)
+    batches = []
+    for s in range(2):
+        b = O.synthetic_batch(opt, B=6, T=4, K=3, t=5, seed=80 + s)
+        batches.append((b['x'], b['mask'], b['ctxg'], b['mask_ctxg'], b['ctxl'], b['mask_ctxl'], b['ctxm'], b['mask_ctxm']))
+    model = stattn.Attention()
+    tparams, hist = model.train(batches, opt, valid_batches=batches, max_epochs=12, decay_c=1e-4, alpha_c=0.70602,
+                                clip_c=10., validFreq=4, save_model_dir=str(tmp_path))
+    errs = [h[3] for h in hist]
+    assert len(errs) >= 5 and errs[-1] < 0.8 * errs[0], errs
+    ck = np.load(str(tmp_path / 'model_best_so_far.npz'))
+    assert 'history_errs' in ck.files and set(O.param_shapes(opt)) <= set(ck.files)
+    assert ck['decoder_b_sel'].shape == () and ck['ff_logit_W'].shape == (64, 211)
+    # reload continues from the checkpoint
+    model2 = stattn.Attention()
+    tparams2, hist2 = model2.train(batches, opt, valid_batches=batches, max_epochs=1, validFreq=2, reload_=True,
+                                   from_dir=str(tmp_path), decay_c=1e-4, alpha_c=0.70602, clip_c=10.)
+    assert len(hist2) > len(hist) - 1 and hist2[-1][3] < errs[0]
+    # f_grad_shared returns the reference's list layout
+    f_grad_shared, f_update = model2.build_train_functions(tparams2, opt, 1e-4, 0.7, 10., return_grads=True)
+    rv = f_grad_shared(*batches[0])
+    assert len(rv) == 6 + len(O.param_shapes(opt)) and rv[1].shape == (5 * 6, 211) and rv[2].shape == (5, 6, 4, 3)

@@ -200,32 +200,57 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
         st4(a.dsmp + fo, scale4(mul4(ld4(a.Um + 4 * d4), one_minus_sq(tm)), s_de[1]));
     }
 
-    // pass 1: recompute plt = sum_k alpha_k LW_k + blt, dplt = delt Ult (1 - tanh^2(plt + slt))  (:416-422)
-    for (int d4 = tid; d4 < nd4; d4 += 256) {
-        float4 pl = ld4(a.blt + 4 * d4);
-#pragma unroll 8
-        for (int k = 0; k < K; ++k) fma4(pl, s_al[k], ld4(LW + (size_t)k * D + 4 * d4));
-        const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
-        st4(a.dplt + (size_t)bt * D + 4 * d4, scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt));
-    }
-    __syncthreads();
-    // pass 2: dalpha_k = <alt dcsum, L_k> + <dplt, LW_k> + r_k     (CL = sum alpha L :383; plt as above)
-    for (int k0 = 0; k0 < K; k0 += 8) {
+    // pass 1+2 fused per lane: recompute plt = sum_k alpha_k LW_k + blt, dplt = delt Ult (1 - tanh^2(plt + slt)) (:416-422),
+    // then dalpha_k = <alt dcsum, L_k> + <dplt, LW_k> + r_k (CL = sum alpha L :383).  dplt of a lane only needs the
+    // lane's own columns, so for K <= 8 the LW slab is read ONCE and held in registers for both uses.
+    if (K <= 8) {
         float p[8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) p[i] = 0.f;
         for (int d4 = tid; d4 < nd4; d4 += 256) {
-            const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
-            const float4 dpl = ld4(a.dplt + (size_t)bt * D + 4 * d4);
+            float4 lw[8];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-                const size_t o = (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
-                p[kk] += dot4(dcl, ld4(L + o)) + dot4(dpl, ld4(LW + o));
-            }
+            for (int kk = 0; kk < 8; ++kk) lw[kk] = ld4(LW + (size_t)min(kk, K - 1) * D + 4 * d4);
+            float4 pl = ld4(a.blt + 4 * d4);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
+            const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
+            const float4 dpl = scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt);
+            st4(a.dplt + (size_t)bt * D + 4 * d4, dpl);
+            const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk)
+                p[kk] += dot4(dcl, ld4(L + (size_t)min(kk, K - 1) * D + 4 * d4)) + dot4(dpl, lw[kk]);
         }
         block_sum<8>(p, s_red, tid, 4);
-        if (tid < 8 && k0 + tid < K) s_da[k0 + tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + k0 + tid] : 0.f);
+        if (tid < 8 && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
         __syncthreads();
+    } else {
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            float4 pl = ld4(a.blt + 4 * d4);
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) fma4(pl, s_al[k], ld4(LW + (size_t)k * D + 4 * d4));
+            const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
+            st4(a.dplt + (size_t)bt * D + 4 * d4, scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt));
+        }
+        __syncthreads();
+        for (int k0 = 0; k0 < K; k0 += 8) {
+            float p[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) p[i] = 0.f;
+            for (int d4 = tid; d4 < nd4; d4 += 256) {
+                const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
+                const float4 dpl = ld4(a.dplt + (size_t)bt * D + 4 * d4);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) {
+                    const size_t o = (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
+                    p[kk] += dot4(dcl, ld4(L + o)) + dot4(dpl, ld4(LW + o));
+                }
+            }
+            block_sum<8>(p, s_red, tid, 4);
+            if (tid < 8 && k0 + tid < K) s_da[k0 + tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + k0 + tid] : 0.f);
+            __syncthreads();
+        }
     }
     // softmax backward over the K regions
     float dotp = 0.f;

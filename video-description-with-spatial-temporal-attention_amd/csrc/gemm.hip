@@ -95,7 +95,7 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     const int nblk = gridDim.x;
     const int bid = blockIdx.x;
     const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
-    const int lin = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD;
+    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
     const int m0 = (lin / tiles_n) * BM;
     const int n0 = (lin % tiles_n) * BN;
 
@@ -244,6 +244,8 @@ void gemm_defaults(GemmArgs& g) {
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
     g.kslices = 1;
+    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    g.xcd_remap = noremap ? 0 : 1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
     if (tB && g.K % 4 != 0) return hipErrorInvalidValue;

@@ -29,6 +29,7 @@ struct GemmArgs {
     // sums them in a fixed order.  Only alpha / accumulate are honoured on that path.
     float* ws; size_t ws_floats;
     int kbeg, kend, kslices;           // internal
+    int xcd_remap;                     // internal: XCD-aware tile order on/off
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);

@@ -215,6 +215,100 @@ class Attention(object):
         f_next.decoder = dec
         return f_init, f_next
 
+    # ---------------------------------------------------------------- gradient / update functions
+    def build_train_functions(self, tparams, options, decay_c=0., alpha_c=0., clip_c=0., global_batch=None,
+                              group=None, return_grads=False):
+        """f_grad_shared, f_update -- what `eval(optimizer)(lr, tparams, grads, inps, cost, extra + grads)` returns
+        for optimizer='adadelta' (model_attention.py:1207-1209, common.py:178-195), with the loss assembled as in
+        :1129-1147 (mean NLL + L2 decay + doubly-stochastic attention regulariser) and the global-norm clip of
+        :1194-1203.
+
+        f_grad_shared(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm) -> [cost, probs, alphals, alphags,
+        alphams, alphalts] (+ the gradient list in parameter order when return_grads=True: 171 MB of device->host
+        copies at the MSVD config, which the reference pays on every update, :1260-1266).  The returned gradients
+        are those of mean-NLL + regulariser; the L2 term and the clip are applied inside f_update (same update).
+        `global_batch` / `group`: data-parallel use -- every rank passes its row shard, gradients are summed with one
+        RCCL all-reduce (stattn.dp)."""
+        try:
+            from . import dp
+        except ImportError:
+            import dp
+        dec = self._bind(tparams, options)
+
+        def f_grad_shared(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
+            dec.set_batch(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm)
+            dec.forward_train()
+            gb = global_batch if global_batch else x.shape[1]
+            dec.backward(nll_scale=1.0 / gb, alpha_c=alpha_c)
+            if global_batch:
+                if not hasattr(dec, '_grad_view'):
+                    dec._grad_view = dp.grad_tensor(dec)
+                dp.allreduce_sum(dec._grad_view, group)
+            r = dec.get_forward(probs=True, alphas=True)
+            out = [numpy.float32(dec.get_loss(decay_c)), r['probs'], r['alphal'], r['alphag'], r['alpham'], r['alphalt']]
+            if return_grads:
+                out += list(dec.get_grads().values())
+            return out
+
+        def f_update(lr):
+            # common.py:193: the reference's adadelta ignores lr too
+            dec.update(decay_c=decay_c, clip_c=clip_c)
+        return f_grad_shared, f_update
+
+    def train(self, batches, options, valid_batches=None, max_epochs=1, decay_c=0., alpha_c=0., clip_c=0.,
+              patience=10, validFreq=-1, dispFreq=0, save_model_dir=None, reload_=False, from_dir=None, params=None):
+        """Minimal counterpart of the optimisation loop of Attention.train (model_attention.py:1239-1517): epochs over
+        `batches` (an iterable of prepare_data() 8-tuples), f_grad_shared + f_update per minibatch with use_noise = 1,
+        validation NLL with use_noise = 0 (pred_probs), early stopping on it with `patience` (:1494-1503), and the
+        reference's checkpoint files: model_best_so_far.npz = numpy.savez(path, history_errs=..., **params)
+        (:1488-1490), reloaded with load_params when reload_ (:1109-1113).  Returns (tparams, history_errs)."""
+        import os
+        common.reset_rngs(1234)
+        if params is None:
+            params = self.init_params(options)
+        history_errs = []
+        if reload_:
+            saved = os.path.join(from_dir, 'model_best_so_far.npz')
+            params = common.load_params(saved, params)
+            history_errs = numpy.load(saved)['history_errs'].tolist()
+        tparams = self.init_tparams(params)
+        rv = self.build_model(tparams, options)
+        use_noise, inps, cost = rv[1], list(rv[2:10]), rv[14]
+        f_log_probs = self.function(inps, -cost, tparams=tparams)
+        f_grad_shared, f_update = self.build_train_functions(tparams, options, decay_c, alpha_c, clip_c)
+        best_p, bad_counter, uidx, estop = None, 0, 0, False
+        for eidx in range(max_epochs):
+            for batch in batches:
+                uidx += 1
+                use_noise.set_value(1.)
+                c = f_grad_shared(*batch)[0]
+                if numpy.isnan(c) or numpy.isinf(c):
+                    raise FloatingPointError('NaN detected in cost')       # the reference drops into pdb (:1274-1276)
+                f_update(0.)
+                if dispFreq and uidx % dispFreq == 0:
+                    print('Epoch', eidx, 'Update', uidx, 'Train cost', c)
+                if valid_batches is not None and validFreq > 0 and uidx % validFreq == 0:
+                    use_noise.set_value(0.)
+                    valid_err = self.pred_probs(valid_batches, f_log_probs)[0]
+                    history_errs.append([eidx, uidx, float(c), float(valid_err)])
+                    if best_p is None or valid_err <= numpy.array(history_errs)[:, 3].min():
+                        best_p = common.unzip(tparams)
+                        bad_counter = 0
+                        if save_model_dir:
+                            numpy.savez(os.path.join(save_model_dir, 'model_best_so_far.npz'),
+                                        history_errs=history_errs, **best_p)
+                    elif len(history_errs) > patience and valid_err >= numpy.array(history_errs)[:-patience, 3].min():
+                        bad_counter += 1
+                        if bad_counter > patience:
+                            estop = True
+                            break
+            if estop:
+                break
+        use_noise.set_value(0.)
+        if save_model_dir:
+            numpy.savez(os.path.join(save_model_dir, 'model_current.npz'), history_errs=history_errs, **common.unzip(tparams))
+        return tparams, history_errs
+
     # ---------------------------------------------------------------- beam search driver
     def gen_sample(self, tparams, f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, options,
                    trng=None, k=1, maxlen=30, stochastic=False, restrict_voc=False):

@@ -34,6 +34,9 @@ struct Tile {
     static constexpr int NF4 = BR * BK / 4 / 256;
 
     // rows_total: extent of the "rows" dimension (M or N); K: extent of k.
+    // EDGE = false: K is a multiple of BK and a row-contiguous operand has no partial tile -> no predicates, no
+    // exec-mask branches around the loads (those make hipcc serialise the prefetch with vmcnt(0)).
+    template <bool EDGE = true>
     __device__ static __forceinline__ void gload(float4 (&r)[NF4], const float* __restrict__ X, int ld,
                                                  int r0, int rows_total, int k0, int K, int tid) {
 #pragma unroll
@@ -44,13 +47,15 @@ struct Tile {
                 int row = r0 + rr;
                 row = row < rows_total ? row : rows_total - 1;   // clamp: edge rows are never stored
                 const int k = k0 + 4 * kc;
-                r[i] = (k < K) ? ld4(X + (size_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EDGE) r[i] = (k < K) ? ld4(X + (size_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+                else r[i] = ld4(X + (size_t)row * ld + k);
             } else {
                 constexpr int RCW = BR / 4;
                 const int k = idx / RCW, rc = idx % RCW;
                 const int gk = k0 + k, gr = r0 + 4 * rc;
-                r[i] = (gk < K && gr < rows_total) ? ld4(X + (size_t)gk * ld + gr)
-                                                   : make_float4(0.f, 0.f, 0.f, 0.f);
+                if constexpr (EDGE) r[i] = (gk < K && gr < rows_total) ? ld4(X + (size_t)gk * ld + gr)
+                                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
+                else r[i] = ld4(X + (size_t)gk * ld + gr);
             }
         }
     }
@@ -203,6 +208,166 @@ __global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Version 2 of the main loop: same tiles, operands and epilogue, but no MFMA-free phase at the tile boundary.
+// PMC on version 1 (4096^3): matrix pipe busy 79 %, waves stalled on ISSUE 81 % and on waits only 7 % -- the two
+// co-resident waves of a SIMD advance in lock step, reach their "wait for the global loads, write LDS, barrier,
+// first fragment read" phase together, and the pipe idles.  Here
+//   * global loads run TWO tiles ahead (two register sets), so the LDS write of tile kt+1 needs no wait,
+//   * that write is placed after the MFMAs of k-block 1, the workgroup barrier after k-block 2,
+//   * the first fragments of tile kt+1 are read after the barrier and before the MFMAs of k-block 3,
+// so every wave always has 16 MFMAs queued behind whatever else it issues.
+// Hazards: stage s^1 is written (k-block 1 of iteration kt) only after barrier(kt-1), and its last readers read it
+// before that barrier (their k-block-3 fragments are fetched during k-block 2); stage s^1 is read (k-block 3)
+// only after barrier(kt), which follows every wave's write.
+template <int TM, int TN, bool AT, bool BT, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    using TA = Tile<BM, !AT>;
+    using TB = Tile<BN, BT>;
+    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::ELEMS + TB::ELEMS)];
+    float* sA = smem;
+    float* sB = smem + 2 * TA::ELEMS;
+
+    const int tiles_n = g.N / BN;
+    const int nblk = gridDim.x;
+    const int bid = blockIdx.x;
+    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
+    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
+    const int m0 = (lin / tiles_n) * BM;
+    const int n0 = (lin % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    int kb = 0, ke = g.K;
+    float* Cout = g.C;
+    int ldc = g.ldc;
+    if (g.kslices > 1) {
+        const int per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
+        kb = blockIdx.y * per;
+        ke = kb + per < g.K ? kb + per : g.K;
+        Cout = g.ws + (size_t)blockIdx.y * g.M * g.N;
+        ldc = g.N;
+    }
+    const int nk = ke > kb ? (ke - kb + BK - 1) / BK : 0;
+
+    float4 ra0[TA::NF4], rb0[TB::NF4], ra1[TA::NF4], rb1[TB::NF4];
+    // tile index clamped to the last one: the prefetch is unconditional (no branch around loads, so hipcc keeps
+    // counted vmcnt waits); the redundant tail loads hit L2
+    auto ktile = [&](int t) { return kb + (t < nk ? t : (nk > 0 ? nk - 1 : 0)) * BK; };
+
+    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(0), ke, tid);
+    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(0), ke, tid);
+    TA::sstore(ra0, sA, tid);
+    TB::sstore(rb0, sB, tid);
+    TA::template gload<EDGE>(ra1, g.A, g.lda, m0, g.M, ktile(1), ke, tid);      // tile 1 -> set 1
+    TB::template gload<EDGE>(rb1, g.B, g.ldb, n0, g.N, ktile(1), ke, tid);
+    __syncthreads();
+
+    float a[2][TM][4], b[2][TN][4];
+    auto frags = [&](int set, const float* cA, const float* cB, int kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) TA::frag(a[set][i], cA, wm * 32 * TM + i * 32 + l31, kk, kh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) TB::frag(b[set][j], cB, wn * 32 * TN + j * 32 + l31, kk, kh);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[set][i][q], b[set][j][q], acc[i][j], 0, 0, 0);
+    };
+    frags(0, sA, sB, 0);
+
+    // one tile; `RS` = register set that holds tile kt+1 on entry and receives tile kt+3's... (see call sites)
+#define STATTN_GEMM2_TILE(KT, RA_NEXT, RB_NEXT, RA_FAR, RB_FAR)                                              \
+    {                                                                                                         \
+        const int st = (KT) & 1;                                                                              \
+        const float* cA = sA + st * TA::ELEMS;                                                                \
+        const float* cB = sB + st * TB::ELEMS;                                                                \
+        float* nA = sA + (st ^ 1) * TA::ELEMS;                                                                \
+        float* nB = sB + (st ^ 1) * TB::ELEMS;                                                                \
+        /* k-block 0 */                                                                                       \
+        frags(1, cA, cB, 1);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(0);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        /* k-block 1, then tile KT+1 (already in registers) goes to the other stage */                        \
+        frags(0, cA, cB, 2);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(1);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        TA::sstore(RA_NEXT, nA, tid);                                                                         \
+        TB::sstore(RB_NEXT, nB, tid);                                                                         \
+        /* the freed register set starts fetching tile KT+3?  no: tile KT+2 lives in the FAR set; refill NEXT */\
+        TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);                                    \
+        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid);                                    \
+        /* k-block 2 (its fragments for k-block 3 are fetched BEFORE the barrier) */                          \
+        frags(1, cA, cB, 3);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(0);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __syncthreads();                                                                                      \
+        /* k-block 3, with the first fragments of tile KT+1 already on their way */                           \
+        frags(0, nA, nB, 0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(1);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+
+    // register-set rotation: on entry of tile kt, set (kt+1)&1 ... we keep it simple with a 2-tile unroll:
+    //   tile kt   (even): NEXT = set1 (tile kt+1), after its store set1 is refilled with tile kt+3
+    //   tile kt+1 (odd) : NEXT = set0 (tile kt+2), ...   set0 must then hold tile kt+2: fetched during tile kt-1.
+    // Prologue therefore also fetches tile 2 into set 0 after its LDS store.
+    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(2), ke, tid);
+    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(2), ke, tid);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
+        STATTN_GEMM2_TILE(kt + 1, ra0, rb0, ra1, rb1)
+    }
+    if (kt < nk) STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
+#undef STATTN_GEMM2_TILE
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + j * 32 + l31;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < g.M && g.kslices > 1) {
+                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
+                } else if (row < g.M) {
+                    float v = g.alpha * acc[i][j][r] + bias;
+                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
+                    if (g.act == 1) v = fast_tanh(v);
+                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
+                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
+                    float* c = g.C + (size_t)row * g.ldc + col;
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
+
 // C[i] (+)= alpha * sum_z ws[z][i]   (fixed summation order: deterministic)
 __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __restrict__ C, int ldc, int M, int N,
                                      int slices, float alpha, int accumulate) {
@@ -226,10 +391,30 @@ hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
     const int BM = 64 * TM, BN = 64 * TN;
     const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
     dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1), block(256);
-    if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
-    else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
-    else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, g);
-    else return hipErrorInvalidValue;
+    static const char* v1 = getenv("STATTN_GEMM_V1");
+    if (v1) {
+        if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
+        else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
+        else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, g);
+        else return hipErrorInvalidValue;
+    } else {
+        // predicate-free loads when no tile straddles an edge that is NOT handled by clamping
+        int per = g.K;
+        if (g.kslices > 1) per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
+        const bool edge = (g.K % BK != 0) || (g.kslices > 1 && (size_t)per * (g.kslices - 1) >= (size_t)g.K) ||
+                          (tA && g.M % BM != 0);
+        if (edge) {
+            if (!tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, true>), grid, block, 0, s, g);
+            else if (!tA && tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, true>), grid, block, 0, s, g);
+            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, true>), grid, block, 0, s, g);
+            else return hipErrorInvalidValue;
+        } else {
+            if (!tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, false>), grid, block, 0, s, g);
+            else if (!tA && tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, false>), grid, block, 0, s, g);
+            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, false>), grid, block, 0, s, g);
+            else return hipErrorInvalidValue;
+        }
+    }
     return hipGetLastError();
 }
 
@@ -276,6 +461,10 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     // 128x64 / 64x64 tiles reach 125 / 118 / 114 TFLOP/s, but what decides the decoder's shapes (N = 1024,
     // M = 13312: 3.25 big tiles per CU) is the tail: whole tiles per CU quantise, so the big tile is only used
     // when its per-CU tile count is (nearly) integral; otherwise the 64x64 tile (4 resident blocks per CU).
+    static const char* force = getenv("STATTN_GEMM_TILE");       // probing only
+    if (force && force[0] == '2' && force[1] == '2' && n128) return launch_cfg<2, 2>(s, g, tA, tB);
+    if (force && force[0] == '2' && force[1] == '1') return launch_cfg<2, 1>(s, g, tA, tB);
+    if (force && force[0] == '1') return launch_cfg<1, 1>(s, g, tA, tB);
     if (n128 && g.M > 64) {
         const double per_cu = blocks(128, 128) / 256.0;
         const double q = per_cu / (double)(long)(per_cu + 0.999999);

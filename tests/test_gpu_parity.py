@@ -405,3 +405,52 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
     for bs, bsc in res2:
         assert len(bs) == k and all(len(x) == maxlen and 0 not in x for x in bs)
         assert list(bsc) == sorted(bsc)
+
+
+# ------------------------------------------------------------------ robustness
+def test_changing_batch_shapes_and_relu_like_features(stattn_mod, O):
+    """Consecutive minibatches of different (t, m, T, K) on one handle (device buffers grow and are re-used), and
+    non-negative features like real fc7 / GoogLeNet activations (second input distribution)."""
+    opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1, seed=33)
+    for (B, T, K, t, seed) in [(3, 4, 2, 3, 1), (40, 6, 5, 7, 2), (2, 3, 9, 2, 3), (17, 5, 4, 6, 4)]:
+        batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=seed)
+        for k in ('ctxg', 'ctxl', 'ctxm'):
+            batch[k] = np.abs(batch[k])
+        dec.set_batch(**batch)
+        dec.forward_train()
+        out = dec.get_forward(logits=True)
+        ref = O.build_model_forward(P64, opt, **_f64(batch))
+        for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+            assert np.abs(out[name] - ref[name]).max() < TOL, (B, T, K, t, name)
+        assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL
+        dec.backward(alpha_c=0.5)                      # backward workspaces follow the new shapes too
+        g = dec.get_grad('decoder_Wc')
+        assert np.isfinite(g).all() and np.abs(g).max() > 0
+        # interleave a sampler call on the same handle (separate buffers, same weights)
+        v = 0
+        (pr, _, _, _), ex = dec.f_next(np.array([2], np.int64), batch['ctxg'][v], batch['mask_ctxg'][v], batch['ctxl'][v], None,
+                                       batch['ctxm'][v], None, np.zeros((1, 128), np.float32), np.zeros((1, 128), np.float32), extras=True)
+        (prr, _, _, _), r = O.f_next(P64, opt, np.array([2]), batch['ctxg'][v].astype(np.float64), None, batch['ctxl'][v].astype(np.float64),
+                                     None, batch['ctxm'][v].astype(np.float64), None, np.zeros((1, 128)), np.zeros((1, 128)), extras=True)
+        assert np.abs(ex['logit'] - r['logit']).max() < TOL
+
+
+def test_call_order_errors_are_reported_not_fatal(stattn_mod, O):
+    opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1, seed=34)
+    with pytest.raises(stattn_mod.NativeError, match="no batch staged"):
+        dec.forward_train()
+    batch = O.synthetic_batch(opt, B=2, T=3, K=2, t=3, seed=5)
+    dec.set_batch(**batch)
+    with pytest.raises(stattn_mod.NativeError, match="no forward pass"):
+        dec.backward()
+    dec.forward_train()
+    dec0 = stattn_mod.Decoder(opt, lt_mode=0)
+    dec0.set_params(P); dec0.set_batch(**batch); dec0.forward_train()
+    with pytest.raises(ValueError, match="lt_mode 1"):
+        dec0.backward()
+    with pytest.raises(KeyError):
+        dec.set_param('no_such_param', np.zeros(3, np.float32))
+    with pytest.raises(ValueError):
+        dec.set_param('decoder_U', np.zeros((3, 3), np.float32))
+    with pytest.raises(ValueError):
+        dec.beam_search(batch['ctxg'], batch['mask_ctxg'], batch['ctxl'], batch['ctxm'], k=9)

@@ -1191,7 +1191,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             ms.scale[i] = i < 3 ? alpha_c / T : alpha_c / (T * K);
         }
         ms.count = 4;
-        HIPCHK(h, launch_multi_sum(s, ms));
+        HIPCHK(h, launch_multi_sum(s, ms, cpart));
     } else {
         HIPCHK(h, hipMemsetAsync(lossreg, 0, 4 * sizeof(float), s));
     }
@@ -1306,7 +1306,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         const char* names[5] = {"decoder_cl_att", "decoder_clt_att", "decoder_cg_att", "decoder_cm_att", "decoder_b_sel"};
         ms.count = h->opt.selector ? 5 : 4;
         for (int i = 0; i < ms.count; ++i) { ms.src[i] = srcs[i]; ms.n[i] = ns[i]; ms.dst[i] = G_(names[i]); ms.scale[i] = 1.f; }
-        HIPCHK(h, launch_multi_sum(s, ms));
+        HIPCHK(h, launch_multi_sum(s, ms, cpart));
     }
     HIPCHK(h, launch_colsum(s, dplt, D, (int)(R * T), D, cpart, G_("decoder_blt_att"), 0));
     if (h->opt.selector) {

@@ -86,33 +86,45 @@ __global__ void alpha_reg_kernel(const float* __restrict__ alpha, float* __restr
 // ---------------------------------------------------------------------------------------------
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
-    const int D = a.D;
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (size_t)a.M * D) return;
-    const int b = (int)(idx / D), d = (int)(idx % D);
-    const size_t MD = (size_t)a.M * D;
-    float dh = 0.f;
+    const int D = a.D, nd4 = D >> 2;
+    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;          // one lane = 4 consecutive units of one row
+    if (i4 >= (size_t)a.M * nd4) return;
+    const int b = (int)(i4 / nd4), d = 4 * (int)(i4 % nd4);
+    const size_t idx = (size_t)b * D + d, MD = (size_t)a.M * D;
+    float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!a.last) {
-        dh = a.dh_pass[idx];
-        for (int p = 0; p < a.nU; ++p) dh += a.dhU[(size_t)p * MD + idx];
-        for (int p = 0; p < a.nW; ++p) dh += a.dhW[(size_t)p * MD + idx];
-        if (a.W_sel) dh += a.dselpre[b] * a.W_sel[d];
+        dh = ld4(a.dh_pass + idx);
+        for (int p = 0; p < a.nU; ++p) add4(dh, ld4(a.dhU + (size_t)p * MD + idx));
+        for (int p = 0; p < a.nW; ++p) add4(dh, ld4(a.dhW + (size_t)p * MD + idx));
+        if (a.W_sel) fma4(dh, a.dselpre[b], ld4(a.W_sel + d));
     }
-    dh += a.dhd[idx] * a.d1[idx];                                   // hd = h * d1  (:684-685)
+    add4(dh, mul4(ld4(a.dhd + idx), ld4(a.d1 + idx)));                  // hd = h * d1  (:684-685)
     const float* gt = a.gates + (size_t)b * 4 * D + d;
-    const float gi = gt[0], gf = gt[D], go = gt[2 * D], gg = gt[3 * D];
-    const float cp = a.c_prev[idx], cn = a.c_new[idx], m = a.mask[b];
-    const float tc = fast_tanh(cn);
-    const float dcn = (a.last ? 0.f : a.dc[idx]) + m * dh * go * (1.f - tc * tc);   // h = m o tanh(c) + (1-m) h_ (:456-457)
-    const float dct = m * dcn;                                      // c = m (f c_ + i g) + (1-m) c_   (:453-454)
-    a.dc[idx] = (1.f - m) * dcn + dct * gf;
-    const float* dp = a.dp + (size_t)b * 3 * D;
+    const float4 gi = ld4(gt), gf = ld4(gt + D), go = ld4(gt + 2 * D), gg = ld4(gt + 3 * D);
+    const float4 cp = ld4(a.c_prev + idx), cn = ld4(a.c_new + idx);
+    const float m = a.mask[b];
+    const float4 dcin = a.last ? make_float4(0.f, 0.f, 0.f, 0.f) : ld4(a.dc + idx);
+    const float* dp = a.dp + (size_t)b * 3 * D + d;
+    const float4 dpi = ld4(dp), dpf = ld4(dp + D), dpo = ld4(dp + 2 * D);
+    float4 o_i, o_f, o_o, o_g, o_dc, o_pass;
+#define STATTN_LSTM_BWD_LANE(X)                                                                                  \
+    {                                                                                                            \
+        const float tc = fast_tanh(cn.X);                                                                        \
+        const float dcn = dcin.X + m * dh.X * go.X * (1.f - tc * tc);   /* h = m o tanh(c) + (1-m) h_ (:456-457) */  \
+        const float dct = m * dcn;                                      /* c = m (f c_ + i g) + (1-m) c_ (:453-454) */ \
+        o_dc.X = (1.f - m) * dcn + dct * gf.X;                                                                   \
+        o_i.X = dct * gg.X * gi.X * (1.f - gi.X) * dpi.X;               /* i = sigma(pre_i * dp_i) (:445-448) */ \
+        o_f.X = dct * cp.X * gf.X * (1.f - gf.X) * dpf.X;                                                        \
+        o_o.X = m * dh.X * tc * go.X * (1.f - go.X) * dpo.X;                                                     \
+        o_g.X = dct * gi.X * (1.f - gg.X * gg.X);                                                                \
+        o_pass.X = (1.f - m) * dh.X;                                                                             \
+    }
+    STATTN_LSTM_BWD_LANE(x) STATTN_LSTM_BWD_LANE(y) STATTN_LSTM_BWD_LANE(z) STATTN_LSTM_BWD_LANE(w)
+#undef STATTN_LSTM_BWD_LANE
+    st4(a.dc + idx, o_dc);
     float* o = a.dpre + (size_t)b * 4 * D + d;
-    o[0] = dct * gg * gi * (1.f - gi) * dp[d];                      // i = sigma(pre_i * dp_i) (:445-448)
-    o[D] = dct * cp * gf * (1.f - gf) * dp[D + d];
-    o[2 * D] = m * dh * tc * go * (1.f - go) * dp[2 * D + d];
-    o[3 * D] = dct * gi * (1.f - gg * gg);
-    a.dh_pass_out[idx] = (1.f - m) * dh;
+    st4(o, o_i); st4(o + D, o_f); st4(o + 2 * D, o_o); st4(o + 3 * D, o_g);
+    st4(a.dh_pass_out + idx, o_pass);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -396,21 +408,27 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int rsplit, 
     for (int r = 0; r < rsplit; ++r) acc += part[(size_t)r * N + n];
     dst[n] = accumulate ? dst[n] + acc : acc;
 }
-// several independent full sums in one launch: block i reduces job i (fixed order: deterministic)
-__global__ __launch_bounds__(1024) void multi_sum_kernel(const MultiSumArgs a) {
-    __shared__ float s[16];
-    const float* __restrict__ x = a.src[blockIdx.x];
-    const size_t n = a.n[blockIdx.x];
+// several independent full sums in one launch pair: 32 workgroups per job write partials, a second tiny kernel
+// adds them in a fixed order (deterministic)
+constexpr int MS_BLOCKS = 32;
+__global__ __launch_bounds__(256) void multi_sum_part_kernel(const MultiSumArgs a, float* __restrict__ part) {
+    __shared__ float s[4];
+    const int job = blockIdx.y;
+    const float* __restrict__ x = a.src[job];
+    const size_t n = a.n[job];
     float acc = 0.f;
-    for (size_t i = threadIdx.x; i < n; i += 1024) acc += x[i];
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)MS_BLOCKS * 256) acc += x[i];
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        float r = 0.f;
-        for (int i = 0; i < 16; ++i) r += s[i];
-        a.dst[blockIdx.x][0] = a.scale[blockIdx.x] * r;
-    }
+    if (threadIdx.x == 0) part[job * MS_BLOCKS + blockIdx.x] = s[0] + s[1] + s[2] + s[3];
+}
+__global__ void multi_sum_final_kernel(const MultiSumArgs a, const float* __restrict__ part) {
+    const int job = threadIdx.x;
+    if (job >= a.count) return;
+    float r = 0.f;
+    for (int i = 0; i < MS_BLOCKS; ++i) r += part[job * MS_BLOCKS + i];
+    a.dst[job][0] = a.scale[job] * r;
 }
 // dst[0] (+)= scale * sum(x[0:n])   (single block, deterministic)
 __global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__ x, size_t n, float* __restrict__ dst, float scale, int accumulate) {
@@ -534,7 +552,7 @@ hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* 
     return hipGetLastError();
 }
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)(((size_t)a.M * a.D + 255) / 256)), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)(((size_t)a.M * (a.D / 4) + 255) / 256)), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {
@@ -573,9 +591,10 @@ hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rs, N, dst, accumulate);
     return hipGetLastError();
 }
-hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a) {
+hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part /* >= 12 * 32 floats */) {
     if (a.count <= 0) return hipSuccess;
-    hipLaunchKernelGGL(multi_sum_kernel, dim3(a.count), dim3(1024), 0, s, a);
+    hipLaunchKernelGGL(multi_sum_part_kernel, dim3(MS_BLOCKS, a.count), dim3(256), 0, s, a, part);
+    hipLaunchKernelGGL(multi_sum_final_kernel, dim3(1), dim3(64), 0, s, a, part);
     return hipGetLastError();
 }
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate) {

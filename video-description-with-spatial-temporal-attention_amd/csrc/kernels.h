@@ -221,7 +221,7 @@ int colsum_parts(int rows, int N);
 hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,
                          const float* row_weights = nullptr);
 struct MultiSumArgs { const float* src[12]; size_t n[12]; float* dst[12]; float scale[12]; int count; };
-hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]])
+hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]]); part: >= 384 floats
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
 hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);

@@ -252,6 +252,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam"])
     ap.add_argument("--beam", type=int, default=1, help="decode mode: beam width k of gen_sample (1 = greedy)")
+    ap.add_argument("--h2d", default="none", choices=["none", "sync", "prefetch"],
+                    help="train mode only: also move the minibatch host->device every step (never the headline value): "
+                         "sync = stattn_set_batch from pageable memory, prefetch = pinned arrays + copy stream, overlapped")
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
@@ -292,6 +295,23 @@ def main():
     dec.set_seed(1234 + rank)
     step_fn = dp.DataParallelStep(dec, global_batch=c["B"] * world, alpha_c=0.70602, decay_c=1e-4, clip_c=10.0) \
         if train else dec.forward_train               # config.py: decay_c 1e-4, alpha_c 0.70602, clip_c 10
+    if train and args.h2d != "none":                  # PCIe-inclusive variants, not the headline
+        core = step_fn
+        if args.h2d == "sync":
+            def step_fn():
+                dec.set_batch(**batch)
+                core()
+        else:
+            pinned = {}
+            for k_, v_ in batch.items():
+                pinned[k_] = dec.pinned_empty(v_.shape, v_.dtype)
+                pinned[k_][...] = v_
+            dec.prefetch_batch(**pinned)
+
+            def step_fn():
+                dec.swap_batch()
+                dec.prefetch_batch(**pinned)          # next minibatch streams in while this one is processed
+                core()
 
     def barrier():
         dec.sync()
@@ -366,7 +386,7 @@ def main():
                                        "optimisation step = build_model forward + BPTT backward + gradient all-reduce + clip + Adadelta"
                                        if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
                                        B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),
-                           global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world),
+                           global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world, h2d=args.h2d),
                roofline=roofline, roofline_hbm=roofline_hbm,
                kernel_ms={k: v[0] for k, v in kms.items()})
     if rank == 0:

@@ -135,6 +135,17 @@ int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int 
                      const float* ctxg, const float* mask_ctxg,
                      const float* ctxl, const float* mask_ctxl,
                      const float* ctxm, const float* mask_ctxm, int T, int K);
+/* Double-buffered staging for a training loop (the H2D of ctxl is 218 MB per batch of 64: SURVEY 8f rank 2).
+ * stattn_prefetch_batch copies the NEXT minibatch into the shadow buffer set on a private copy stream and returns
+ * immediately when the host arrays are pinned (stattn_host_alloc); stattn_swap_batch makes it current -- the compute
+ * stream waits on the copy event, the host never blocks.  The arrays must stay untouched until the swap. */
+int stattn_host_alloc(size_t bytes, void** out);   /* pinned host memory for prepare_data's output arrays */
+int stattn_host_free(void* p);
+int stattn_prefetch_batch(stattn_handle* h, const int64_t* x, const float* mask, int t, int m,
+                          const float* ctxg, const float* mask_ctxg,
+                          const float* ctxl, const float* mask_ctxl,
+                          const float* ctxm, const float* mask_ctxm, int T, int K);
+int stattn_swap_batch(stattn_handle* h);
 /* Forward of build_model on the staged batch (asynchronous on the handle's stream):
  * prologue (ff_local/ff_motion, attention pre-projections, init state, x projection),
  * t decoder steps, readout, vocabulary softmax, masked NLL. */

@@ -206,3 +206,41 @@ def test_train_loop_counterpart_learns_and_checkpoints(tmp_path):
     f_grad_shared, f_update = model2.build_train_functions(tparams2, opt, 1e-4, 0.7, 10., return_grads=True)
     rv = f_grad_shared(*batches[0])
     assert len(rv) == 6 + len(O.param_shapes(opt)) and rv[1].shape == (5 * 6, 211) and rv[2].shape == (5, 6, 4, 3)
+
+
+def test_prefetch_swap_pipeline_matches_set_batch_and_overlaps():
+    """Double-buffered staging (stattn_prefetch_batch / stattn_swap_batch) from pinned host arrays: same results as
+    the synchronous set_batch path over several alternating minibatches, with the host running ahead."""
+    import stattn
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**SMALL)
+    P = O.random_params(opt, seed=41, dtype=np.float32)
+    ref_dec = stattn.Decoder(opt, lt_mode=1); ref_dec.set_params(P)
+    dec = stattn.Decoder(opt, lt_mode=1); dec.set_params(P)
+    batches = [O.synthetic_batch(opt, B=b, T=T, K=K, t=t, seed=90 + i)
+               for i, (b, T, K, t) in enumerate([(6, 4, 3, 5), (9, 5, 2, 4), (4, 4, 3, 6), (6, 4, 3, 5)])]
+    keys = ('x', 'mask', 'ctxg', 'mask_ctxg', 'ctxl', 'mask_ctxl', 'ctxm', 'mask_ctxm')
+    pinned = []
+    for b in batches:                       # prepare_data's arrays live in pinned memory
+        pb = {}
+        for k in keys:
+            arr = dec.pinned_empty(b[k].shape, b[k].dtype)
+            arr[...] = b[k]
+            pb[k] = arr
+        pinned.append(pb)
+    dec.prefetch_batch(**pinned[0])
+    for i, b in enumerate(batches):
+        dec.swap_batch()
+        if i + 1 < len(batches):
+            dec.prefetch_batch(**pinned[i + 1])          # overlaps with the step below
+        dec.forward_train(); dec.backward(alpha_c=0.5); dec.update(decay_c=1e-4, clip_c=10.0)
+        ref_dec.set_batch(**b)
+        ref_dec.forward_train(); ref_dec.backward(alpha_c=0.5); ref_dec.update(decay_c=1e-4, clip_c=10.0)
+    a, r = dec.get_params(), ref_dec.get_params()
+    for k in a:
+        if k == 'Wemb':      # embedding scatter uses atomics: summation order may differ run to run
+            np.testing.assert_allclose(a[k], r[k], rtol=1e-5, atol=1e-7)
+        else:
+            np.testing.assert_array_equal(a[k], r[k], err_msg=k)
+    with pytest.raises(stattn.NativeError, match="no prefetched batch"):
+        dec.swap_batch()

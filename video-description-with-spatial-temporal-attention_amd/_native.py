@@ -57,6 +57,10 @@ _SIGNATURES = {
     "stattn_beam_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      _I64, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
+    "stattn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
+    "stattn_host_free": (C.c_int, [C.c_void_p]),
+    "stattn_prefetch_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
+    "stattn_swap_batch": (C.c_int, [_H]),
     "stattn_forward_train": (C.c_int, [_H]),
     "stattn_get_forward": (C.c_int, [_H, _F, _F, _F, _F, _F, _F, _F]),
     "stattn_get_states": (C.c_int, [_H, _F, _F, _F]),
@@ -172,6 +176,9 @@ class Decoder(object):
         if getattr(self, "_h", None) and self._h.value:
             self._lib.stattn_destroy(self._h)
             self._h = _H()
+            for p in getattr(self, "_pinned", []):
+                self._lib.stattn_host_free(C.c_void_p(p))
+            self._pinned = []
 
     def __del__(self):
         try:
@@ -318,6 +325,48 @@ class Decoder(object):
         self._chk(self._lib.stattn_set_batch(self._h, x.ctypes.data_as(_I64), _fp(mask), t, m, _fp(ctxg), _fp(mask_ctxg),
                                              _fp(ctxl), None, _fp(ctxm), None, T, K))
         self._batch = (t, m, T, K)
+
+    def _check_batch(self, x, mask, ctxg, mask_ctxg, ctxl, ctxm):
+        x = _i64(x, "x")
+        if x.ndim != 2:
+            raise ValueError("x must be (t, m)")
+        t, m = x.shape
+        mask = _f32(mask, "mask", (t, m))
+        ctxl = _f32(ctxl, "ctxl")
+        if ctxl.ndim != 4 or ctxl.shape[0] != m or ctxl.shape[3] != self.Fl:
+            raise ValueError("ctxl must be (m, T, K, %d)" % self.Fl)
+        T, K = ctxl.shape[1], ctxl.shape[2]
+        ctxg = _f32(ctxg, "ctxg", (m, T, self.D)); mask_ctxg = _f32(mask_ctxg, "mask_ctxg", (m, T))
+        ctxm = _f32(ctxm, "ctxm", (m, T, self.Fm))
+        return x, mask, ctxg, mask_ctxg, ctxl, ctxm, t, m, T, K
+
+    def prefetch_batch(self, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
+        """Start copying the NEXT minibatch to the shadow buffer set (asynchronous for pinned arrays, see
+        pinned_empty); the arrays must stay alive and unmodified until swap_batch()."""
+        x, mask, ctxg, mask_ctxg, ctxl, ctxm, t, m, T, K = self._check_batch(x, mask, ctxg, mask_ctxg, ctxl, ctxm)
+        self._pending_refs = (x, mask, ctxg, mask_ctxg, ctxl, ctxm)
+        self._chk(self._lib.stattn_prefetch_batch(self._h, x.ctypes.data_as(_I64), _fp(mask), t, m, _fp(ctxg), _fp(mask_ctxg),
+                                                  _fp(ctxl), None, _fp(ctxm), None, T, K))
+        self._pending = (t, m, T, K)
+
+    def swap_batch(self):
+        self._chk(self._lib.stattn_swap_batch(self._h))
+        self._batch = self._pending
+        self._live_refs = getattr(self, "_pending_refs", None)
+
+    def pinned_empty(self, shape, dtype=np.float32):
+        """numpy array over page-locked host memory (hipHostMalloc): H2D copies from it are truly asynchronous."""
+        dtype = np.dtype(dtype)
+        nbytes = int(np.prod(shape)) * dtype.itemsize
+        p = C.c_void_p()
+        rc = self._lib.stattn_host_alloc(nbytes, C.byref(p))
+        if rc != 0:
+            raise NativeError("stattn_host_alloc failed: %s" % self._lib.stattn_last_error(None).decode())
+        buf = (C.c_char * max(nbytes, 1)).from_address(p.value)
+        arr = np.frombuffer(buf, dtype=dtype, count=int(np.prod(shape))).reshape(shape)
+        self._pinned = getattr(self, "_pinned", [])
+        self._pinned.append(p.value)           # freed in close()
+        return arr
 
     def forward_train(self):
         self._chk(self._lib.stattn_forward_train(self._h))

@@ -84,6 +84,15 @@ struct stattn_handle {
     int masks_t = 0, masks_m = 0;        // shape the mask buffers currently hold
     int masks_state = 0;                 // 0 invalid, 1 holds eval (0.5), 2 holds a random draw
 
+    // double-buffered batch staging (prepare_data -> HBM pipeline): set 0 / 1, a copy stream and a ready event
+    int cur_set = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged_ev = nullptr;
+    hipEvent_t free_ev[2] = {nullptr, nullptr};   // "every kernel that read set i has been enqueued before this"
+    bool free_valid[2] = {false, false};
+    bool have_pending = false;
+    int p_t = 0, p_m = 0, p_T = 0, p_K = 0;
+
     // sampler: cached projected video
     const void *ck_g = nullptr, *ck_l = nullptr, *ck_m = nullptr;
     int ck_T = 0, ck_K = 0;
@@ -222,6 +231,11 @@ int getbuf_t(stattn_handle* h, const char* name, size_t n, T** out) {
     *out = static_cast<T*>(p);
     return STATTN_OK;
 }
+// the six input buffers of a minibatch exist twice (sets 0 and 1): one is read by forward / backward while the
+// other receives the next minibatch from pinned host memory on the copy stream
+std::string bset(const stattn_handle* h, const char* name, int set) { return set ? std::string(name) + "#1" : std::string(name); }
+std::string bcur(const stattn_handle* h, const char* name) { return bset(h, name, h->cur_set); }
+
 float* findbuf(stattn_handle* h, const char* name) {
     auto it = h->bufs.find(name);
     return it == h->bufs.end() ? nullptr : static_cast<float*>(it->second.p);
@@ -505,6 +519,10 @@ void stattn_destroy(stattn_handle* h) {
     if (h->d_grads) (void)hipFree(h->d_grads);
     if (h->d_rg2) (void)hipFree(h->d_rg2);
     if (h->d_ru2) (void)hipFree(h->d_ru2);
+    if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
+    if (h->staged_ev) (void)hipEventDestroy(h->staged_ev);
+    if (h->free_ev[0]) (void)hipEventDestroy(h->free_ev[0]);
+    if (h->free_ev[1]) (void)hipEventDestroy(h->free_ev[1]);
     if (h->own_stream && h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
 }
@@ -938,12 +956,12 @@ int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int 
     HIPCHK(h, hipStreamSynchronize(s));
     const int D = h->D;
     int64_t* dx; float *dmask, *G, *mG, *rl, *rm;
-    CHK(getbuf_t(h, "x", (size_t)t * m, &dx));
-    CHK(getbuf_t(h, "mask", (size_t)t * m, &dmask));
-    CHK(getbuf_t(h, "G", (size_t)m * T * D, &G));
-    CHK(getbuf_t(h, "mG", (size_t)m * T, &mG));
-    CHK(getbuf_t(h, "rawl", (size_t)m * T * K * h->Fl, &rl));
-    CHK(getbuf_t(h, "rawm", (size_t)m * T * h->Fm, &rm));
+    CHK(getbuf_t(h, bcur(h, "x").c_str(), (size_t)t * m, &dx));
+    CHK(getbuf_t(h, bcur(h, "mask").c_str(), (size_t)t * m, &dmask));
+    CHK(getbuf_t(h, bcur(h, "G").c_str(), (size_t)m * T * D, &G));
+    CHK(getbuf_t(h, bcur(h, "mG").c_str(), (size_t)m * T, &mG));
+    CHK(getbuf_t(h, bcur(h, "rawl").c_str(), (size_t)m * T * K * h->Fl, &rl));
+    CHK(getbuf_t(h, bcur(h, "rawm").c_str(), (size_t)m * T * h->Fm, &rm));
     HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)t * m * sizeof(int64_t), hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(dmask, mask, (size_t)t * m * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(G, ctxg, (size_t)m * T * D * 4, hipMemcpyHostToDevice, s));
@@ -956,6 +974,69 @@ int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int 
     return STATTN_OK;
 }
 
+// ---- asynchronous staging of the NEXT minibatch (data_engine.prepare_data -> HBM pipeline) ----------------
+int stattn_host_alloc(size_t bytes, void** out) {
+    if (!out) return STATTN_EINVAL;
+    *out = nullptr;
+    hipError_t e = hipHostMalloc(out, bytes ? bytes : 4, hipHostMallocDefault);
+    if (e != hipSuccess) { g_create_error = std::string("hipHostMalloc: ") + hipGetErrorString(e); return STATTN_EHIP; }
+    return STATTN_OK;
+}
+int stattn_host_free(void* p) {
+    if (!p) return STATTN_OK;
+    return hipHostFree(p) == hipSuccess ? STATTN_OK : STATTN_EHIP;
+}
+
+int stattn_prefetch_batch(stattn_handle* h, const int64_t* x, const float* mask, int t, int m,
+                          const float* ctxg, const float* mask_ctxg, const float* ctxl, const float* mask_ctxl,
+                          const float* ctxm, const float* mask_ctxm, int T, int K) {
+    (void)mask_ctxl; (void)mask_ctxm;
+    if (!h || !x || !mask || !ctxg || !mask_ctxg || !ctxl || !ctxm || t <= 0 || m <= 0 || T <= 0 || K <= 0)
+        return fail(h, STATTN_EINVAL, "prefetch_batch: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    if (!h->copy_stream) {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->copy_stream, hipStreamNonBlocking));
+        HIPCHK(h, hipEventCreateWithFlags(&h->staged_ev, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->free_ev[0], hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->free_ev[1], hipEventDisableTiming));
+    }
+    const int set = h->cur_set ^ 1;
+    // the shadow set may still be read by kernels of the step before the last swap (the host runs ahead of the GPU)
+    if (h->free_valid[set]) HIPCHK(h, hipStreamWaitEvent(h->copy_stream, h->free_ev[set], 0));
+    const int D = h->D;
+    int64_t* dx; float *dmask, *G, *mG, *rl, *rm;
+    // (buffer growth may hipFree/hipMalloc: the shadow set is idle by construction -- it was swapped out before)
+    CHK(getbuf_t(h, bset(h, "x", set).c_str(), (size_t)t * m, &dx));
+    CHK(getbuf_t(h, bset(h, "mask", set).c_str(), (size_t)t * m, &dmask));
+    CHK(getbuf_t(h, bset(h, "G", set).c_str(), (size_t)m * T * D, &G));
+    CHK(getbuf_t(h, bset(h, "mG", set).c_str(), (size_t)m * T, &mG));
+    CHK(getbuf_t(h, bset(h, "rawl", set).c_str(), (size_t)m * T * K * h->Fl, &rl));
+    CHK(getbuf_t(h, bset(h, "rawm", set).c_str(), (size_t)m * T * h->Fm, &rm));
+    hipStream_t cs = h->copy_stream;
+    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)t * m * sizeof(int64_t), hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(dmask, mask, (size_t)t * m * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(G, ctxg, (size_t)m * T * D * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(mG, mask_ctxg, (size_t)m * T * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(rl, ctxl, (size_t)m * T * K * h->Fl * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipMemcpyAsync(rm, ctxm, (size_t)m * T * h->Fm * 4, hipMemcpyHostToDevice, cs));
+    HIPCHK(h, hipEventRecord(h->staged_ev, cs));
+    h->p_t = t; h->p_m = m; h->p_T = T; h->p_K = K; h->have_pending = true;
+    return STATTN_OK;
+}
+
+int stattn_swap_batch(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_pending) return fail(h, STATTN_ESTATE, "swap_batch: no prefetched batch (call stattn_prefetch_batch)");
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipStreamWaitEvent(h->stream, h->staged_ev, 0));   // compute stream waits for the copies, the host does not
+    HIPCHK(h, hipEventRecord(h->free_ev[h->cur_set], h->stream));  // old set is free once everything enqueued so far ran
+    h->free_valid[h->cur_set] = true;
+    h->cur_set ^= 1;
+    h->t = h->p_t; h->m = h->p_m; h->T = h->p_T; h->K = h->p_K;
+    h->have_pending = false; h->have_batch = true; h->have_fwd = false; h->have_bwd = false;
+    return STATTN_OK;
+}
+
 int stattn_forward_train(stattn_handle* h) {
     if (!h) return STATTN_EINVAL;
     if (!h->have_batch) return fail(h, STATTN_ESTATE, "forward_train: no batch staged (call stattn_set_batch)");
@@ -965,13 +1046,13 @@ int stattn_forward_train(stattn_handle* h) {
     hipStream_t s = h->stream;
     const size_t R = (size_t)t * m;
 
-    int64_t* dx = (int64_t*)h->bufs["x"].p;
-    float* dmask = findbuf(h, "mask");
-    float* mG = findbuf(h, "mG");
-    float* rawl = findbuf(h, "rawl");
-    float* rawm = findbuf(h, "rawm");
+    int64_t* dx = (int64_t*)h->bufs[bcur(h, "x")].p;
+    float* dmask = findbuf(h, bcur(h, "mask").c_str());
+    float* mG = findbuf(h, bcur(h, "mG").c_str());
+    float* rawl = findbuf(h, bcur(h, "rawl").c_str());
+    float* rawm = findbuf(h, bcur(h, "rawm").c_str());
     CtxPtrs c{};
-    c.G = findbuf(h, "G");
+    c.G = findbuf(h, bcur(h, "G").c_str());
     float *mean, *emb, *xproj, *hs, *cs, *hd, *ctx, *csum, *sel, *al, *ag, *am, *alt, *CL, *gates, *sproj, *preh,
           *eg, *em, *elt, *plt, *z1, *a1, *tz, *lg, *pr, *nll, *cost, *dp, *d1, *d2;
     CHK(getbuf_t(h, "L", (size_t)m * T * K * D, &c.L));
@@ -1113,8 +1194,8 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     auto G_ = [&](const char* n) { return h->d_grads + h->params[h->pindex[n]].off; };
 
     // forward tensors
-    int64_t* dx = (int64_t*)h->bufs["x"].p;
-    float *dmask = findbuf(h, "mask"), *Gc = findbuf(h, "G"), *rawl = findbuf(h, "rawl"), *rawm = findbuf(h, "rawm"),
+    int64_t* dx = (int64_t*)h->bufs[bcur(h, "x")].p;
+    float *dmask = findbuf(h, bcur(h, "mask").c_str()), *Gc = findbuf(h, bcur(h, "G").c_str()), *rawl = findbuf(h, bcur(h, "rawl").c_str()), *rawm = findbuf(h, bcur(h, "rawm").c_str()),
           *L = findbuf(h, "L"), *Mo = findbuf(h, "Mo"), *PG = findbuf(h, "PG"), *PL = findbuf(h, "PL"), *PM = findbuf(h, "PM"),
           *LW = findbuf(h, "LW"), *mean = findbuf(h, "mean"), *emb = findbuf(h, "emb"), *hs = findbuf(h, "hs"),
           *cs = findbuf(h, "cs"), *hd = findbuf(h, "hd"), *ctx = findbuf(h, "ctx"), *csum = findbuf(h, "csum"),

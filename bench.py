@@ -69,14 +69,14 @@ def synthetic_batch(c, seed):
                 ctxm=rng.standard_normal((B, T, c["F"])).astype(np.float32), mask_ctxm=np.ones((B, T), np.float32))
 
 
-def fast_params(options, seed):
+def fast_params(shapes, seed):
     """Random-init weights of the architecture with the reference's init *scales* (0.01 N(0,1); the
     orthogonal blocks are replaced by N(0,1)/sqrt(n), same spectrum scale) -- avoids a dozen 1024^2
-    SVDs per rank at start-up.  The product's init_params reproduces the exact reference init."""
-    from oracle.stattn_oracle import param_shapes      # shape table only (bench is allowed to use oracle/)
+    SVDs per rank at start-up.  `shapes`: name -> shape from the library (Decoder.param_shapes(), dict
+    order of init_params).  The product's init_params reproduces the exact reference init."""
     rng = np.random.RandomState(seed)
     P = {}
-    for k, shp in param_shapes(options).items():
+    for k, shp in shapes.items():
         if len(shp) == 2 and shp[0] == shp[1]:
             P[k] = (rng.standard_normal(shp) / np.sqrt(shp[0])).astype(np.float32)
         elif k == "decoder_U":
@@ -278,11 +278,11 @@ def main():
     from stattn import dp
     c = CONFIGS[args.config]
     options = make_options(c)
-    params = fast_params(options, 1234)               # same seed on every rank: replicas start identical
     # the library runs on a torch stream so that torch.distributed's collective is ordered with its kernels
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode)
+    params = fast_params(dec.param_shapes(), 1234)    # same seed on every rank: replicas start identical
     dec.set_params(params)
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
     if args.mode == "decode":

@@ -1,7 +1,7 @@
 import sys, time; sys.path.insert(0,'.')
 import numpy as np, stattn, bench
-c = bench.CONFIGS['c1']; opt = bench.make_options(c); P = bench.fast_params(opt, 1)
-dec = stattn.Decoder(opt); dec.set_params(P)
+c = bench.CONFIGS['c1']; opt = bench.make_options(c)
+dec = stattn.Decoder(opt); P = bench.fast_params(dec.param_shapes(), 1); dec.set_params(P)
 b = bench.synthetic_batch(c, 3)
 g,l,m,gm = b['ctxg'][0], b['ctxl'][0], b['ctxm'][0], b['mask_ctxg'][0]
 _, h0, c0 = dec.f_init(g, gm)

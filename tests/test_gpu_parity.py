@@ -454,3 +454,30 @@ def test_call_order_errors_are_reported_not_fatal(stattn_mod, O):
         dec.set_param('decoder_U', np.zeros((3, 3), np.float32))
     with pytest.raises(ValueError):
         dec.beam_search(batch['ctxg'], batch['mask_ctxg'], batch['ctxl'], batch['ctxm'], k=9)
+
+
+def test_next_sample_is_a_multinomial_draw_and_seedable(stattn_mod, O):
+    """f_next's second output = multinomial(next_probs).argmax(1) (model_attention.py:841): drawn with the library's
+    own generator (not Theano's MRG stream).  Reproducible after set_seed, distributed like the probabilities."""
+    opt, P, P64, dec = _decoder(stattn_mod, O, SMALL, 1, seed=44)
+    P2 = dict(P); P2['ff_logit_b'] = P['ff_logit_b'].copy(); P2['ff_logit_b'][:3] += 4.0      # three dominant words
+    dec.set_params(P2)
+    b = O.synthetic_batch(opt, B=1, T=4, K=3, t=3, seed=6)
+    g, l, m, gm = b['ctxg'][0], b['ctxl'][0], b['ctxm'][0], b['mask_ctxg'][0]
+    x = np.full(64, 5, np.int64); h = np.zeros((64, 128), np.float32); c = np.zeros((64, 128), np.float32)
+    dec.set_seed(7)
+    p, s1, _, _ = dec.f_next(x, g, gm, l, None, m, None, h, c)
+    dec.set_seed(7)
+    _, s2, _, _ = dec.f_next(x, g, gm, l, None, m, None, h, c)
+    np.testing.assert_array_equal(s1, s2)
+    draws = np.concatenate([dec.f_next(x, g, gm, l, None, m, None, h, c)[1] for _ in range(40)])
+    assert draws.min() >= 0 and draws.max() < 211
+    top = p[0].argsort()[::-1][:3]
+    freq = np.array([(draws == w).mean() for w in top])
+    np.testing.assert_allclose(freq, p[0][top], atol=0.04)          # 2560 draws
+    # stochastic gen_sample runs through the same path
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P2)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, g, gm, l, None, m, None, opt, None, 1, maxlen=6, stochastic=True)
+    assert 1 <= len(s) <= 6 and sc > 0

@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
 
     float a[2][TM][4], b[2][TN][4];
     auto frags = [&](int set, const float* cA, const float* cB, int kk) {
+        if (g.abl == 2) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[set][i], cA, wm * 32 * TM + i * 32 + l31, kk, kh);
 #pragma unroll
@@ -309,11 +310,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(1);                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        TA::sstore(RA_NEXT, nA, tid);                                                                         \
-        TB::sstore(RB_NEXT, nB, tid);                                                                         \
+        if (!g.abl) { TA::sstore(RA_NEXT, nA, tid);                                                           \
+        TB::sstore(RB_NEXT, nB, tid); }                                                                       \
         /* the freed register set starts fetching tile KT+3?  no: tile KT+2 lives in the FAR set; refill NEXT */\
-        TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);                                    \
-        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid);                                    \
+        if (!g.abl) { TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);       \
+        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid); }                   \
         /* k-block 2 (its fragments for k-block 3 are fetched BEFORE the barrier) */                          \
         frags(1, cA, cB, 3);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -431,6 +432,8 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     g.kslices = 1;
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
+    static const char* abl = getenv("STATTN_GEMM_ABL");          // ablation probes only (results are wrong)
+    g.abl = abl ? atoi(abl) : 0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
     if (tB && g.K % 4 != 0) return hipErrorInvalidValue;

@@ -30,6 +30,7 @@ struct GemmArgs {
     float* ws; size_t ws_floats;
     int kbeg, kend, kslices;           // internal
     int xcd_remap;                     // internal: XCD-aware tile order on/off
+    int abl;                           // internal: ablation probe (0 in the product path)
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);

@@ -244,3 +244,65 @@ def test_prefetch_swap_pipeline_matches_set_batch_and_overlaps():
             np.testing.assert_array_equal(a[k], r[k], err_msg=k)
     with pytest.raises(stattn.NativeError, match="no prefetched batch"):
         dec.swap_batch()
+
+
+def test_full_size_c2_properties_and_row_subset_parity():
+    """BASELINE.json configs[1] at FULL size (batch 64, T=26, K=8, feat 4096, hidden 1024, E=512, vocab 12000,
+    30 steps).  The float64 oracle is affordable for a 2-row subset (rows are independent in the forward pass);
+    the rest is checked through size-independent properties: softmax normalisation, masked steps freeze the state,
+    and linearity of the gradient over row shards (the data-parallel exactness rule)."""
+    import stattn
+    from oracle import stattn_oracle as O
+    opt = O.default_options()
+    dec = stattn.Decoder(opt, lt_mode=1)
+    rng = np.random.RandomState(3)
+    P = OrderedDict()
+    for k, shp in dec.param_shapes().items():
+        if len(shp) == 2:
+            P[k] = (rng.standard_normal(shp) / np.sqrt(shp[0])).astype(np.float32) if shp[0] == shp[1] or k == 'decoder_U' \
+                else (0.02 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            P[k] = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+    dec.set_params(P)
+    batch = O.synthetic_batch(opt, B=64, T=26, K=8, t=30, seed=77)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    st = dec.get_states()
+    # (1) parity of a 2-row subset against the float64 oracle
+    rows = [5, 41]
+    sub = {k: np.ascontiguousarray(v[:, rows] if k in ('x', 'mask') else v[rows]) for k, v in batch.items()}
+    sub64 = {k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in sub.items()}
+    ref = O.build_model_forward(O.cast_params(P, np.float64), opt, **sub64)
+    t, V = 30, 12000
+    lg = out['logit'].reshape(t, 64, V)[:, rows]
+    assert np.abs(lg - ref['logit']).max() < 1e-4
+    for a in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[a][:, rows] - ref[a]).max() < 1e-4, a
+    np.testing.assert_allclose(out['cost'][rows], ref['cost'], rtol=1e-4)
+    # (2) normalisation and mask freezing at full size
+    np.testing.assert_allclose(out['probs'].sum(1), 1.0, atol=2e-5)
+    np.testing.assert_allclose(out['alphal'].sum(-1), 1.0, atol=1e-5)
+    np.testing.assert_allclose(out['alphalt'].sum(-1), 1.0, atol=1e-5)
+    for b in range(64):
+        ln = int(batch['mask'][:, b].sum())
+        if ln < t:
+            np.testing.assert_array_equal(st['h'][ln - 1, b], st['h'][-1, b])
+    # (3) gradient linearity over row shards: g(all 64 rows) == g(rows 0..23) + g(rows 24..63) at fixed nll_scale
+    alpha_c = 0.70602
+    dec.backward(nll_scale=1.0 / 64, alpha_c=alpha_c)
+    names = ['decoder_U', 'decoder_Wc', 'decoder_Wcl_att', 'decoder_Wclt_att', 'ff_local_W', 'ff_logit_W', 'decoder_Ul_att',
+             'decoder_W_sel', 'ff_state_W', 'decoder_Wdl_att', 'ff_motion_W', 'decoder_blt_att']
+    full = {k: dec.get_grad(k).astype(np.float64) for k in names}
+    assert all(np.isfinite(v).all() for v in full.values())
+    acc = {k: np.zeros_like(v) for k, v in full.items()}
+    for lo, hi in ((0, 24), (24, 64)):
+        shard = {k: np.ascontiguousarray(v[:, lo:hi] if k in ('x', 'mask') else v[lo:hi]) for k, v in batch.items()}
+        dec.set_batch(**shard)
+        dec.forward_train()
+        dec.backward(nll_scale=1.0 / 64, alpha_c=alpha_c)
+        for k in names:
+            acc[k] += dec.get_grad(k)
+    for k in names:
+        scale = np.abs(full[k]).max()
+        assert np.abs(acc[k] - full[k]).max() <= 2e-4 * scale + 1e-7, (k, np.abs(acc[k] - full[k]).max(), scale)

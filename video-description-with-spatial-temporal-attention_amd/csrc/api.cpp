@@ -530,6 +530,7 @@ void stattn_destroy(stattn_handle* h) {
 int stattn_sync(stattn_handle* h) {
     if (!h) return STATTN_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->stream));
+    gemm_clock_dump();   // no-op unless STATTN_GEMM_CLK is set (tools)
     return STATTN_OK;
 }
 

@@ -17,7 +17,9 @@
 #include "kernels.h"
 #include "devmath.h"
 
+#include <cstdio>
 #include <cstdlib>
+#include <vector>
 
 namespace stattn {
 
@@ -239,6 +241,9 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
+    if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
+        g.clk[0] = __builtin_readcyclecounter(); g.clk[1] = __builtin_amdgcn_s_memrealtime();
+    }
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -341,6 +346,9 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     }
     if (kt < nk) STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
 #undef STATTN_GEMM2_TILE
+    if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
+        g.clk[2] = __builtin_readcyclecounter(); g.clk[3] = __builtin_amdgcn_s_memrealtime();
+    }
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -427,9 +435,44 @@ void gemm_defaults(GemmArgs& g) {
     g.rowgroup = 1;
 }
 
+// Clock probe (STATTN_GEMM_CLK=1, tools only): block 0 of every GEMM launch records the shader cycle counter and the
+// 100 MHz wall clock at its start and end; gemm_clock_dump() prints shape, block-0 duration and the implied shader
+// clock for every launch since the last dump.
+namespace {
+struct ClkRec { int M, N, K, tA, tB; };
+constexpr int CLK_SLOTS = 4096;
+long long* g_clk_dev = nullptr;
+std::vector<ClkRec>* g_clk_rec = nullptr;
+}  // namespace
+
+void gemm_clock_dump() {
+    if (!g_clk_dev || !g_clk_rec || g_clk_rec->empty()) return;
+    (void)hipDeviceSynchronize();
+    std::vector<long long> c(4 * g_clk_rec->size());
+    if (hipMemcpy(c.data(), g_clk_dev, c.size() * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return;
+    for (size_t i = 0; i < g_clk_rec->size(); ++i) {
+        const ClkRec& r = (*g_clk_rec)[i];
+        const double us = (double)(c[4 * i + 3] - c[4 * i + 1]) / 100.0;
+        fprintf(stderr, "[stattn gemm clk] %c%c M=%6d N=%6d K=%6d  block0 %8.1f us  %5.0f MHz\n", r.tA ? 'T' : 'N',
+                r.tB ? 'T' : 'N', r.M, r.N, r.K, us, us > 0 ? (double)(c[4 * i + 2] - c[4 * i]) / us : 0.0);
+    }
+    g_clk_rec->clear();
+}
+
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
     g.kslices = 1;
+    static const char* clk = getenv("STATTN_GEMM_CLK");
+    if (clk) {
+        if (!g_clk_dev) {
+            if (hipMalloc(&g_clk_dev, CLK_SLOTS * 4 * sizeof(long long)) != hipSuccess) g_clk_dev = nullptr;
+            g_clk_rec = new std::vector<ClkRec>();
+        }
+        if (g_clk_dev && g_clk_rec->size() < CLK_SLOTS) {
+            g.clk = g_clk_dev + 4 * g_clk_rec->size();
+            g_clk_rec->push_back(ClkRec{g.M, g.N, g.K, tA, tB});
+        }
+    }
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
     static const char* abl = getenv("STATTN_GEMM_ABL");          // ablation probes only (results are wrong)

@@ -31,9 +31,11 @@ struct GemmArgs {
     int kbeg, kend, kslices;           // internal
     int xcd_remap;                     // internal: XCD-aware tile order on/off
     int abl;                           // internal: ablation probe (0 in the product path)
+    long long* clk;                    // internal: clock probe slot {cycles0, wall0, cycles1, wall1} written by block 0 (null in the product path)
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);
+void gemm_clock_dump();   // tools only (STATTN_GEMM_CLK=1)
 
 // ----------------------------------------------------------------------------
 // Register-streaming "skinny" grouped GEMM (skinny.hip) for M <= a few hundred rows:

@@ -177,8 +177,8 @@ int stattn_reset_optimizer(stattn_handle* h);
  *      building blocks in isolation; not part of the reference surface) ------------- */
 /* C[M,N] = act(alpha * op(A).op(B) + bias[n] + add[m,n]);  host pointers.
  * transA: A given as [K,M]; transB: B given as [N,K]; act: 0 none, 1 tanh.
- * Runs the LDS-tiled fp32 MFMA kernel (kind=0) or the register-streaming skinny
- * kernel (kind=1).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
+ * Runs the LDS-tiled fp32 MFMA kernel (kind=0), the register-streaming skinny
+ * kernel (kind=1) or the bf16-MFMA kernel (kind=2: no transA, alpha = 1, K % 8 == 0).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
 int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K,
                     float alpha, const float* A, const float* B, const float* bias,
                     const float* add, int act, float* C);
@@ -186,6 +186,10 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
  * average milliseconds per launch measured with HIP events on the handle's stream. */
 int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K,
                          int iters, float* ms_per_launch);
+/* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
+ * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,
+ * 11 / 21 / 22 / 42 = workgroup tile (64*TM) x (64*TN) -- the LDS tile size sweep of BASELINE configs[3]. */
+int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch);
 /* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
  * 1 / 2 / 4 = ablations (loads only / MFMAs only / no reduction), see tools/skinny_probe.py. */
 int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   _F, _F, _F, _F, C.c_int, _F]),
     "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "stattn_dbg_time_gemm_bf16": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_time_skinny": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_set_profiling": (C.c_int, [_H, C.c_int]),
     "stattn_get_kernel_ms": (C.c_int, [_H, C.c_int, _F, C.POINTER(C.c_int)]),
@@ -428,6 +429,11 @@ class Decoder(object):
     def time_gemm(self, M, N, K, iters=20, transA=False, transB=False):
         ms = C.c_float()
         self._chk(self._lib.stattn_dbg_time_gemm(self._h, int(transA), int(transB), M, N, K, iters, C.byref(ms)))
+        return ms.value
+
+    def time_gemm_bf16(self, M, N, K, tile=0, iters=20):
+        ms = C.c_float()
+        self._chk(self._lib.stattn_dbg_time_gemm_bf16(self._h, M, N, K, int(tile), iters, C.byref(ms)))
         return ms.value
 
     def time_skinny(self, M, N, K, nseg=1, variant=0, iters=50):

@@ -1509,6 +1509,22 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         g.act = act;
         hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);
         if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else if (kind == 2) {
+        // bf16-MFMA kernel: operands rounded to bf16 on the device, B kept k-contiguous ([N][K])
+        if (transA || alpha != 1.f || K % 8 != 0) return fail(h, STATTN_EINVAL, "bf16 kernel: no transA, alpha must be 1, K % 8 == 0");
+        uint16_t *bA, *bB;
+        CHK(getbuf_t(h, "dbg_bA", (size_t)M * K, &bA));
+        CHK(getbuf_t(h, "dbg_bB", (size_t)K * N, &bB));
+        HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
+        if (transB) HIPCHK(h, launch_cvt_bf16(s, dB, bB, (size_t)K * N));
+        else HIPCHK(h, launch_cvt_bf16_t(s, dB, N, bB, K, K, N));
+        GemmBfArgs g{};
+        g.A = bA; g.lda = K; g.B = bB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        g.bias = bias ? dbias : nullptr;
+        if (add) { g.add = dadd; g.ldadd = N; }
+        g.act = act; g.rowgroup = 1;
+        hipError_t e = launch_gemm_bf16(s, g);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
     } else {
         if (transA || transB) return fail(h, STATTN_EINVAL, "skinny kernel has no transposed variants");
         SkArgs a{};
@@ -1553,6 +1569,40 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
     HIPCHK(h, hipEventRecord(a, s));
     for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+    HIPCHK(h, hipEventRecord(b, s));
+    HIPCHK(h, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(h, STATTN_EINVAL, "dbg_time_gemm_bf16: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB;
+    uint16_t *bA, *bB, *bC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_bA", (size_t)M * K, &bA));
+    CHK(getbuf_t(h, "dbg_bB", (size_t)K * N, &bB));
+    CHK(getbuf_t(h, "dbg_bC", (size_t)M * N, &bC));
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N, 11, 2));
+    HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
+    HIPCHK(h, launch_cvt_bf16(s, dB, bB, (size_t)K * N));
+    GemmBfArgs g{};
+    g.A = bA; g.lda = K; g.B = bB; g.ldb = K; g.Cb = bC; g.ldcb = N; g.M = M; g.N = N; g.K = K; g.rowgroup = 1; g.tile = tile;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = launch_gemm_bf16(s, g);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_time_gemm_bf16: %s", hipGetErrorString(e));
+    }
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+    HIPCHK(h, hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm_bf16(s, g));
     HIPCHK(h, hipEventRecord(b, s));
     HIPCHK(h, hipEventSynchronize(b));
     float ms = 0.f;

@@ -1,0 +1,264 @@
+// bf16-MFMA GEMM for gfx950 (v_mfma_f32_32x32x16_bf16, fp32 accumulation) -- the "bf16 MFMA path" of
+// BASELINE.json configs[3] (MSR-VTT shape).  Used only when the handle was created with precision = bf16:
+// the once-per-batch context projections (model_attention.py:664-667, 322-326), the x projection (:334-335) and the
+// batched readout (:687-705) take bf16 operands; everything recurrent stays fp32.
+//
+//   C[M,N] = epi(A[M,K] . B[N,K]^T)        A and B are both k-contiguous (weights are kept pre-transposed)
+//   epi(v)[m,n] = act(v + bias[n] + add[m,n] + rowadd[m / rowgroup, n]);  written as fp32 (C) and/or bf16 (Cb)
+//
+// Same schedule as the fp32 kernel (gemm.hip, MainLoop): 4 waves as 2x2, two LDS stages, global loads two tiles
+// ahead in registers, LDS write after k-block 1, barrier after k-block 2, next tile's first fragments before k-block 3.
+// BK = 64 bf16 = 128 B per row; LDS rows are padded to 144 B so the 16 lanes of a ds_read_b128 group land on 16
+// distinct 4-bank slots (36 dwords stride, as in the fp32 tile).  A lane's fragment is 8 consecutive k of its
+// row: k = 16 kk + 8 (lane >> 5) + j.
+#include "kernels.h"
+#include "devmath.h"
+
+#include <cstdlib>
+
+namespace stattn {
+
+namespace {
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));     // 16-byte chunk = 8 bf16 (HIP's uint4 struct defeats SROA here: the staging arrays ended up in scratch)
+
+constexpr int BKB = 64;             // k per tile (bf16 elements)
+constexpr int ROWB = BKB + 8;       // padded LDS row, in bf16 elements (144 bytes)
+constexpr int NXCD = 8;
+
+__device__ __forceinline__ uint16_t f2bf(float f) {     // round to nearest even (inputs are finite)
+    uint32_t u = __builtin_bit_cast(uint32_t, f);
+    u += 0x7fffu + ((u >> 16) & 1u);
+    return (uint16_t)(u >> 16);
+}
+
+template <int BR>
+struct TileB {
+    static constexpr int ELEMS = BR * ROWB;             // bf16 elements per stage
+    static constexpr int NCH = BR * 8 / 256;            // 16-byte chunks per thread
+    template <bool EDGE>
+    __device__ static __forceinline__ void gload(u32x4 (&r)[NCH], const uint16_t* __restrict__ X, int ld, int r0,
+                                                 int rows_total, int k0, int K, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            const int rr = idx >> 3, ch = idx & 7;
+            int row = r0 + rr;
+            row = row < rows_total ? row : rows_total - 1;          // clamp: edge rows are never stored
+            const int k = k0 + 8 * ch;
+            const u32x4* p = reinterpret_cast<const u32x4*>(X + (size_t)row * ld + k);
+            if constexpr (EDGE) r[i] = (k < K) ? *p : u32x4{0u, 0u, 0u, 0u};
+            else r[i] = *p;
+        }
+    }
+    __device__ static __forceinline__ void sstore(const u32x4 (&r)[NCH], uint16_t* s, int tid) {
+#pragma unroll
+        for (int i = 0; i < NCH; ++i) {
+            const int idx = tid + i * 256;
+            *reinterpret_cast<u32x4*>(s + (idx >> 3) * ROWB + 8 * (idx & 7)) = r[i];
+        }
+    }
+    __device__ static __forceinline__ bf16x8 frag(const uint16_t* s, int row, int kk, int kh) {
+        return *reinterpret_cast<const bf16x8*>(s + row * ROWB + kk * 16 + 8 * kh);
+    }
+};
+
+template <int TM, int TN, bool EDGE>
+__global__ __launch_bounds__(256, (TM * TN > 4) ? 1 : 2) void gemm_bf16_kernel(const GemmBfArgs g) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    using TA = TileB<BM>;
+    using TB = TileB<BN>;
+    __shared__ __attribute__((aligned(16))) uint16_t smem[2 * (TA::ELEMS + TB::ELEMS)];
+    uint16_t* sA = smem;
+    uint16_t* sB = smem + 2 * TA::ELEMS;
+
+    const int tiles_n = g.N / BN;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
+    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
+    const int m0 = (lin / tiles_n) * BM;
+    const int n0 = (lin % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int K = g.K;
+    const int nk = (K + BKB - 1) / BKB;
+    u32x4 ra0[TA::NCH], rb0[TB::NCH], ra1[TA::NCH], rb1[TB::NCH];
+    auto ktile = [&](int t) { return (t < nk ? t : nk - 1) * BKB; };   // clamped: the prefetch is unconditional
+
+    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(0), K, tid);
+    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(0), K, tid);
+    TA::sstore(ra0, sA, tid);
+    TB::sstore(rb0, sB, tid);
+    TA::template gload<EDGE>(ra1, g.A, g.lda, m0, g.M, ktile(1), K, tid);
+    TB::template gload<EDGE>(rb1, g.B, g.ldb, n0, g.N, ktile(1), K, tid);
+    __syncthreads();
+
+    bf16x8 a[2][TM], b[2][TN];
+    auto frags = [&](int set, const uint16_t* cA, const uint16_t* cB, int kk) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i) a[set][i] = TA::frag(cA, wm * 32 * TM + i * 32 + l31, kk, kh);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) b[set][j] = TB::frag(cB, wn * 32 * TN + j * 32 + l31, kk, kh);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int j = 0; j < TN; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
+    };
+    frags(0, sA, sB, 0);
+
+#define STATTN_BF16_TILE(KT, RA_NEXT, RB_NEXT)                                                             \
+    {                                                                                                         \
+        const int st = (KT) & 1;                                                                              \
+        const uint16_t* cA = sA + st * TA::ELEMS;                                                             \
+        const uint16_t* cB = sB + st * TB::ELEMS;                                                             \
+        uint16_t* nA = sA + (st ^ 1) * TA::ELEMS;                                                             \
+        uint16_t* nB = sB + (st ^ 1) * TB::ELEMS;                                                             \
+        frags(1, cA, cB, 1);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(0);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        frags(0, cA, cB, 2);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(1);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        TA::sstore(RA_NEXT, nA, tid);                                                                         \
+        TB::sstore(RB_NEXT, nB, tid);                                                                         \
+        TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), K, tid);                      \
+        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), K, tid);                      \
+        frags(1, cA, cB, 3);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(0);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        __syncthreads();                                                                                      \
+        frags(0, nA, nB, 0);                                                                                  \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        mfmas(1);                                                                                             \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+    }
+
+    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(2), K, tid);
+    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(2), K, tid);
+    int kt = 0;
+    for (; kt + 1 < nk; kt += 2) {
+        STATTN_BF16_TILE(kt, ra1, rb1)
+        STATTN_BF16_TILE(kt + 1, ra0, rb0)
+    }
+    if (kt < nk) STATTN_BF16_TILE(kt, ra1, rb1)
+#undef STATTN_BF16_TILE
+
+    // epilogue.  32x32 C/D map (dtype independent): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = n0 + wn * 32 * TN + j * 32 + l31;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < g.M) {
+                    float v = acc[i][j][r] + bias;
+                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
+                    if (g.act == 1) v = fast_tanh(v);
+                    if (g.C) g.C[(size_t)row * g.ldc + col] = v;
+                    if (g.Cb) g.Cb[(size_t)row * g.ldcb + col] = f2bf(v);
+                }
+            }
+        }
+    }
+}
+
+// dst[i] = bf16(src[i]), 8 elements per thread (n % 8 == 0, both 16-byte aligned)
+__global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const float4 x = ld4(src + 8 * i), y = ld4(src + 8 * i + 4);
+        uint4 o;
+        o.x = f2bf(x.x) | ((uint32_t)f2bf(x.y) << 16);
+        o.y = f2bf(x.z) | ((uint32_t)f2bf(x.w) << 16);
+        o.z = f2bf(y.x) | ((uint32_t)f2bf(y.y) << 16);
+        o.w = f2bf(y.z) | ((uint32_t)f2bf(y.w) << 16);
+        *reinterpret_cast<uint4*>(dst + 8 * i) = o;
+    }
+}
+
+// dst[n][k] = bf16(src[k][n])   (weights W[K][N] fp32 -> k-contiguous bf16 rows); 32x32 tiles through LDS
+__global__ __launch_bounds__(256) void cvt_bf16_t_kernel(const float* __restrict__ src, int lds_, uint16_t* __restrict__ dst,
+                                                         int ldd, int K, int N) {
+    __shared__ float tile[32][33];
+    const int k0 = blockIdx.y * 32, n0 = blockIdx.x * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int k = k0 + r, n = n0 + tx;
+        tile[r][tx] = (k < K && n < N) ? src[(size_t)k * lds_ + n] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = ty; r < 32; r += 8) {
+        const int n = n0 + r, k = k0 + tx;
+        if (n < N && k < K) dst[(size_t)n * ldd + k] = f2bf(tile[tx][r]);
+    }
+}
+
+template <int TM, int TN>
+hipError_t launch_tile(hipStream_t s, const GemmBfArgs& g) {
+    const int BM = 64 * TM, BN = 64 * TN;
+    const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
+    if (g.K % BKB != 0) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, true>), dim3(tiles), dim3(256), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, false>), dim3(tiles), dim3(256), 0, s, g);
+    return hipGetLastError();
+}
+
+}  // namespace
+
+hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
+    GemmBfArgs g = gin;
+    if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
+    if (g.N % 64 != 0 || g.K % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0) return hipErrorInvalidValue;
+    if (g.rowgroup < 1) g.rowgroup = 1;
+    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    g.xcd_remap = noremap ? 0 : 1;
+    // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 42 forces one for the sweep
+    static const char* force = getenv("STATTN_BF16_TILE");
+    const int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
+    if (tile == 11) return launch_tile<1, 1>(s, g);
+    if (tile == 21) return launch_tile<2, 1>(s, g);
+    if (tile == 22 && g.N % 128 == 0) return launch_tile<2, 2>(s, g);
+    if (tile == 42 && g.N % 128 == 0) return launch_tile<4, 2>(s, g);
+    if (tile) return hipErrorInvalidValue;
+    const long t22 = (long)((g.M + 127) / 128) * (g.N / 128);
+    if (g.N % 128 == 0 && t22 >= 512) return launch_tile<2, 2>(s, g);
+    return launch_tile<1, 1>(s, g);
+}
+
+hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n) {
+    if (n == 0) return hipSuccess;
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    int nb = (int)((n8 + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(cvt_bf16_kernel, dim3(nb), dim3(256), 0, s, src, dst, n8);
+    return hipGetLastError();
+}
+
+hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N) {
+    if (K <= 0 || N <= 0) return hipSuccess;
+    hipLaunchKernelGGL(cvt_bf16_t_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, src, ld_src, dst, ld_dst, K, N);
+    return hipGetLastError();
+}
+
+}  // namespace stattn

@@ -38,6 +38,28 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool trans
 void gemm_clock_dump();   // tools only (STATTN_GEMM_CLK=1)
 
 // ----------------------------------------------------------------------------
+// bf16-MFMA GEMM (gemm_bf16.hip), precision = bf16 handles only:  C = epi(A[M,K] . B[N,K]^T), both operands bf16
+// and k-contiguous, fp32 accumulation; epi = act(v + bias[n] + add[m,n] + rowadd[m / rowgroup, n]) written as fp32
+// (C) and/or bf16 (Cb).  N % 64 == 0, K % 8 == 0, lda / ldb % 8 == 0.
+// ----------------------------------------------------------------------------
+struct GemmBfArgs {
+    const uint16_t* A; int lda;
+    const uint16_t* B; int ldb;
+    float* C; int ldc;                 // fp32 output or null
+    uint16_t* Cb; int ldcb;            // bf16 output or null
+    int M, N, K;
+    const float* bias;
+    const float* add; int ldadd;
+    const float* rowadd; int ldrow; int rowgroup;
+    int act;                           // 0 none, 1 tanh
+    int tile;                          // 0 = choose; 11 / 21 / 22 / 42 = (64*TM) x (64*TN) workgroup tile (sweep tool)
+    int xcd_remap;                     // internal
+};
+hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
+hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n);               // n % 8 == 0
+hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N);  // dst[n][k] = src[k][n]
+
+// ----------------------------------------------------------------------------
 // Register-streaming "skinny" grouped GEMM (skinny.hip) for M <= a few hundred rows:
 // the weight matrix streams HBM/L2 -> VGPR exactly once per 16*mt rows, no LDS staging.
 // One launch computes several independent output segments; each segment sums up to three

@@ -39,11 +39,14 @@ CONFIGS = {
     # configs[0] "MSVD tiny"
     "c1": dict(B=4, T=26, K=8, F=4096, D=512, E=512, V=12000, t=30),
     # configs[4] "Long-context beam search": 32 videos, T=80, K=32, beam 5 (feat / hidden / vocab from configs[1])
+    # configs[3] "MSR-VTT-shape stress": T=40, K=16 regions, feat=2048, hidden=1024 (run with --precision bf16 --mode forward)
+    "c4": dict(B=64, T=40, K=16, F=2048, D=1024, E=512, V=12000, t=30),
     "c5": dict(B=32, T=80, K=32, F=4096, D=1024, E=512, V=12000, t=30),
     "smoke": dict(B=8, T=6, K=4, F=128, D=128, E=64, V=500, t=5),
 }
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
 MFMA_F32_PEAK_TF = 157.3   # fp32-input MFMA dense peak
+MFMA_BF16_PEAK_TF = 2500.0 # bf16 MFMA dense peak (no sparsity)
 
 
 def make_options(c):
@@ -256,6 +259,8 @@ def main():
                     help="train mode only: also move the minibatch host->device every step (never the headline value): "
                          "sync = stattn_set_batch from pageable memory, prefetch = pinned arrays + copy stream, overlapped")
     ap.add_argument("--lt-mode", type=int, default=None)
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="bf16: the bf16-MFMA forward/decode path of BASELINE configs[3] (not the headline; no training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
     args = ap.parse_args()
@@ -281,7 +286,9 @@ def main():
     # the library runs on a torch stream so that torch.distributed's collective is ordered with its kernels
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
-    dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode)
+    if args.precision == "bf16" and args.mode == "train":
+        raise SystemExit("--precision bf16 is a forward/decode path: use --mode forward, decode or beam")
+    dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode, precision=args.precision)
     params = fast_params(dec.param_shapes(), 1234)    # same seed on every rank: replicas start identical
     dec.set_params(params)
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
@@ -354,22 +361,27 @@ def main():
     nn_flops = sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in nn_shapes)
     g_ms, g_n = kms["gemm_nn"]
     per_fwd = g_n / 3.0
-    roofline = dict(kernel="gemm_kernel<TM,TN,false,false> (all NN launches of one forward pass, %d per pass)" % round(per_fwd),
+    bf16 = args.precision == "bf16"
+    mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
+    roofline = dict(kernel=("gemm_bf16_kernel<TM,TN> (all launches of one forward pass, %d per pass)" if bf16 else
+                            "gemm_kernel<TM,TN,false,false> (all NN launches of one forward pass, %d per pass)") % round(per_fwd),
                     bound="mfma", achieved=(nn_flops / per_fwd) / (g_ms * 1e-3) / 1e12 if g_ms else None,
-                    peak=MFMA_F32_PEAK_TF, unit="TFLOP/s", frac=None, traffic=None,
+                    peak=mfma_peak, unit="TFLOP/s", frac=None, traffic=None,
                     flops_per_launch=nn_flops / max(per_fwd, 1), ms_per_launch=g_ms)
     if roofline["achieved"]:
-        roofline["frac"] = roofline["achieved"] / MFMA_F32_PEAK_TF
+        roofline["frac"] = roofline["achieved"] / mfma_peak
     # (2) the HBM-bound attention kernel (one launch per decoder step)
     nslab = 3 if dec.lt_mode == 1 else 2              # PL, L (and LW in lt_mode 1)
-    sp_bytes = B * T * D * 4.0 * (nslab * K + 3)      # + PG, PM reads and the CL write
+    slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
+    sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
     sp_ms = kms["spatial"][0]
-    roofline_hbm = dict(kernel="spatial_kernel", bound="hbm", achieved=sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms else None,
+    roofline_hbm = dict(kernel="spatial_bf16_kernel" if bf16 else "spatial_kernel", bound="hbm",
+                        achieved=sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms else None,
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
                         bytes_per_launch=sp_bytes, ms_per_launch=sp_ms)
     if roofline_hbm["achieved"]:
         roofline_hbm["frac"] = roofline_hbm["achieved"] / HBM_PEAK_GBS
-    if args.config == "c2" and dec.lt_mode == 1:
+    if args.config == "c2" and dec.lt_mode == 1 and not bf16:
         # HBM-side bytes per launch from rocprofv3 PMC passes of this very command (collected offline, separate
         # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_c_pmc_*.csv
         roofline["traffic"] = 393.3e6          # mean over the 10 NN launches: 361.3 MB fetched + 32.0 MB written
@@ -380,9 +392,9 @@ def main():
 
     out = dict(metric="decoder steps/sec (batch x timestep)", value=value, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
-               config=dict(workload="%s %s: %s, batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, caption length %d, lt_mode=%d"
-                                    % (args.config, args.mode,
+               scaling="weak", vs_baseline=None, dtype="bf16" if bf16 else "f32", data="synthetic",
+               config=dict(workload="%s %s%s: %s, batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, caption length %d, lt_mode=%d"
+                                    % (args.config, args.mode, " (bf16-MFMA projections/readout, bf16 region tensors, fp32 recurrence)" if bf16 else "",
                                        "optimisation step = build_model forward + BPTT backward + gradient all-reduce + clip + Adadelta"
                                        if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
                                        B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),

@@ -58,7 +58,15 @@ typedef struct stattn_options {
                            0 = one MFMA GEMM per step, the reference's order;
                            1 = L.Wclt pre-projected once per batch, alpha-weighted
                                sum per step (same maths, different summation order) */
-    int32_t reserved[5];
+    int32_t precision;  /* 0 = fp32 everywhere (the parity configuration);
+                           1 = bf16-MFMA path (BASELINE configs[3]): the once-per-batch context
+                               projections, the x projection and the readout GEMMs take bf16
+                               operands with fp32 accumulation, and the projected region tensors
+                               L / PL / LW are stored in bf16 (the per-step attention kernel reads
+                               half the bytes).  Recurrent matmuls, softmaxes and the LSTM stay
+                               fp32.  Forward / decode only (stattn_backward refuses), lt_mode 1.
+                               Accuracy: ~1e-3 on attention weights, ~2e-2 on logits.            */
+    int32_t reserved[4];
 } stattn_options;
 
 /* ---- lifecycle ---------------------------------------------------------------- */
@@ -188,7 +196,7 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
                          int iters, float* ms_per_launch);
 /* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
  * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,
- * 11 / 21 / 22 / 42 = workgroup tile (64*TM) x (64*TN) -- the LDS tile size sweep of BASELINE configs[3]. */
+ * 11 / 21 / 22 = workgroup tile (64*TM) x (64*TN) -- the LDS tile size sweep of BASELINE configs[3]. */
 int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch);
 /* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
  * 1 / 2 / 4 = ablations (loads only / MFMAs only / no reduction), see tools/skinny_probe.py. */

@@ -52,3 +52,100 @@ def test_bf16_gemm_identity_and_rejects_bad_shapes(dec):
         dec.gemm(np.ones((8, 12), np.float32), np.ones((12, 64), np.float32), kind=2)    # K % 8 != 0
     with pytest.raises(ValueError):
         dec.gemm(np.ones((8, 16), np.float32), np.ones((16, 32), np.float32), kind=2)    # N % 64 != 0
+
+
+# ------------------------------------------------------------------ the decoder on the bf16 path
+# Tolerances of the bf16 configuration (bf16 cannot meet 1e-4): attention weights 2e-3,
+# logits 3e-2 absolute, against the float64 oracle on the SAME fp32 weights and inputs.
+TOL_ALPHA, TOL_LOGIT = 2e-3, 3e-2
+MEDIUM = dict(dim=256, dim_word=128, n_words=1000, ctxg_dim=256, ctxl_dim=512, ctxm_dim=256, ctxglm_dim=256)
+
+
+def _f64(batch):
+    return {k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()}
+
+
+def _pair(dims, seed, **kw):
+    import stattn
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**{**dims, **kw})
+    P = O.random_params(opt, seed=seed, dtype=np.float32)
+    dec = stattn.Decoder(opt, precision="bf16")
+    dec.set_params(P)
+    return O, opt, P, O.cast_params(P, np.float64), dec
+
+
+@pytest.mark.parametrize("dims,B,T,K,t,kw", [(SMALL, 5, 5, 4, 6, {}), (MEDIUM, 9, 26, 8, 7, {}),
+                                             (SMALL, 6, 4, 3, 5, dict(ctx2out=False, prev2out=False, selector=False))])
+def test_bf16_forward_within_bf16_tolerance(dims, B, T, K, t, kw):
+    O, opt, P, P64, dec = _pair(dims, 6, **kw)
+    batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=31)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    ref = O.build_model_forward(P64, opt, **_f64(batch))
+    errs = {}
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        errs[name] = np.abs(out[name] - ref[name]).max()
+        assert errs[name] < TOL_ALPHA, (name, errs[name])
+        np.testing.assert_allclose(out[name].sum(-1), 1.0, atol=1e-5)            # still exact softmaxes
+    errs['logit'] = np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max()
+    assert errs['logit'] < TOL_LOGIT, errs
+    # the bf16 path is not the fp32 path in disguise: the error is visibly above the fp32 bar on the bigger case
+    if dims is MEDIUM:
+        assert errs['logit'] > 1e-4, errs
+    np.testing.assert_allclose(out['cost'], ref['cost'], rtol=2e-2, atol=2e-2)
+
+
+def test_bf16_c4_msrvtt_shape():
+    """configs[3]: T=40, K=16 regions, feat=2048, hidden=1024 on the bf16 MFMA path."""
+    dims = dict(dim=1024, dim_word=512, n_words=3000, ctxg_dim=1024, ctxl_dim=2048, ctxm_dim=2048, ctxglm_dim=1024)
+    O, opt, P, P64, dec = _pair(dims, 21)
+    batch = O.synthetic_batch(opt, B=3, T=40, K=16, t=4, seed=60)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    ref = O.build_model_forward(P64, opt, **_f64(batch))
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name] - ref[name]).max() < TOL_ALPHA, name
+    assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL_LOGIT
+
+
+def test_bf16_sampler_and_beam_search_agree_with_fp32_captions():
+    """f_init / f_next / beam search run on the bf16-projected context: probabilities stay within tolerance of the
+    oracle's, and the device beam search returns the same hypotheses as the host loop over the same handle."""
+    import stattn
+    O, opt, P, P64, dec = _pair(SMALL, 15)
+    b = O.synthetic_batch(opt, B=4, T=5, K=4, t=3, seed=70)
+    g, gm, l, m = b['ctxg'][0], b['mask_ctxg'][0], b['ctxl'][0], b['ctxm'][0]
+    _, h0, c0 = dec.f_init(g, gm)
+    _, hr, cr = O.f_init(P64, opt, g.astype(np.float64), gm.astype(np.float64))
+    assert np.abs(h0 - hr).max() < 1e-4                       # f_init takes no bf16 GEMM
+    (p, _, h1, c1), ex = dec.f_next(np.array([-1]), g, gm, l, None, m, None, h0[None], c0[None], extras=True)
+    (pr, _, h1r, c1r), r = O.f_next(P64, opt, np.array([-1]), g.astype(np.float64), gm, l.astype(np.float64), None,
+                                    m.astype(np.float64), None, hr[None], cr[None], extras=True)
+    assert np.abs(ex['alphal'] - r['alphal']).max() < TOL_ALPHA and np.abs(ex['logit'] - r['logit']).max() < TOL_LOGIT
+    assert np.abs(p - pr).max() < 5e-3
+    model = stattn.Attention()
+    opt_b = dict(opt, stattn_precision='bf16')
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt_b, None, None)
+    res = model.gen_sample_batch(tparams, opt_b, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=3, maxlen=7)
+    for v in range(4):
+        args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+        s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt_b, None, 3, maxlen=7)
+        assert res[v][0] == s
+        np.testing.assert_allclose(res[v][1], np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)
+
+
+def test_bf16_handle_refuses_backward_and_lt_mode_0():
+    import stattn
+    O, opt, P, P64, dec = _pair(SMALL, 3)
+    dec.set_batch(**O.synthetic_batch(opt, B=2, T=3, K=2, t=3, seed=1))
+    dec.forward_train()
+    with pytest.raises(ValueError):
+        dec.backward()
+    with pytest.raises(ValueError):
+        stattn.Decoder(opt, lt_mode=0, precision="bf16")
+    with pytest.raises(ValueError):
+        stattn.Decoder(opt, precision="fp16")

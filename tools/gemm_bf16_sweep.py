@@ -14,7 +14,7 @@ SHAPES = [  # C4: B=64, T=40, K=16, F=2048, D=1024
     ("square 4096", 4096, 4096, 4096),
     ("square 8192", 8192, 8192, 8192),
 ]
-TILES = [(11, "64x64"), (21, "128x64"), (22, "128x128"), (42, "256x128"), (0, "auto")]
+TILES = [(11, "64x64"), (21, "128x64"), (22, "128x128"), (0, "auto")]
 
 
 def main():

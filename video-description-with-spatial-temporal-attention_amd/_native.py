@@ -25,7 +25,7 @@ def library_path():
 class _Options(C.Structure):
     _fields_ = [(n, C.c_int32) for n in
                 ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim",
-                 "selector", "use_dropout", "prev2out", "ctx2out", "lt_mode")] + [("reserved", C.c_int32 * 5)]
+                 "selector", "use_dropout", "prev2out", "ctx2out", "lt_mode", "precision")] + [("reserved", C.c_int32 * 4)]
 
 
 _F = C.POINTER(C.c_float)
@@ -126,7 +126,7 @@ KERNEL_CLASSES = ("spatial", "hproj", "lt_gemm", "temporal", "lstm", "prologue",
 class Decoder(object):
     """One native decoder instance = one GPU + one stream (stattn_handle)."""
 
-    def __init__(self, options, device=0, stream=None, lt_mode=None):
+    def __init__(self, options, device=0, stream=None, lt_mode=None, precision=None):
         lib = load_library()
         self._lib = lib
         self._h = _H()
@@ -146,6 +146,13 @@ class Decoder(object):
             lt_mode = int(os.environ.get("STATTN_LT_MODE", options.get("lt_mode", 1)))
         o.lt_mode = int(lt_mode)
         self.lt_mode = int(lt_mode)
+        # 'fp32' (default, the parity configuration) or 'bf16' (bf16-MFMA forward/decode path, BASELINE configs[3])
+        if precision is None:
+            precision = os.environ.get("STATTN_PRECISION", options.get("stattn_precision", "fp32"))
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        o.precision = 1 if precision == "bf16" else 0
+        self.precision = precision
         self.options = dict(options)
         rc = lib.stattn_create(C.byref(o), int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))
         if rc != 0:

@@ -280,8 +280,85 @@ hipError_t gemm_nn(stattn_handle* h, const GemmArgs& g) {
 // recomputes on every call in the reference, model_attention.py:782-785 + 322-326).
 struct CtxPtrs { float *G, *L, *Mo, *PG, *PL, *PM, *LW; };
 
+// ---- bf16 path (precision = 1) ----------------------------------------------------------------------
+// k-contiguous bf16 shadows ([N][K]) of the weight matrices the bf16 GEMMs read.  Rebuilt from the fp32 master
+// copy at every use (once per minibatch / once per decoded video: ~35 M elements, tens of microseconds), so they can
+// never go stale whichever way the parameters were written (set_param, update, RCCL broadcast into the flat buffer).
+struct BfWeights { uint16_t *ff_local, *ff_motion, *Wcg, *Wcl, *Wcm, *Wclt, *W, *Wl1, *Wl2, *Wo; };
+
+int bf16_weights(stattn_handle* h, BfWeights* b, bool readout) {
+    const int D = h->D, E = h->E, Vp = h->Vp;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    struct Item { const char* name; const float* src; int K, N; uint16_t** dst; bool ro; };
+    const Item items[] = {
+        {"bw_ff_local", w.ff_local_W, h->Fl, D, &b->ff_local, false}, {"bw_ff_motion", w.ff_motion_W, h->Fm, D, &b->ff_motion, false},
+        {"bw_Wcg", w.Wcg, D, D, &b->Wcg, false}, {"bw_Wcl", w.Wcl, D, D, &b->Wcl, false},
+        {"bw_Wcm", w.Wcm, D, D, &b->Wcm, false}, {"bw_Wclt", w.Wclt, D, D, &b->Wclt, false},
+        {"bw_W", w.W, E, 4 * D, &b->W, true}, {"bw_Wl1", w.Wl1, D, E, &b->Wl1, true},
+        {"bw_Wl2", w.Wl2, D, E, &b->Wl2, true}, {"bw_Wo", w.Wo, E, Vp, &b->Wo, true},
+    };
+    for (const Item& it : items) {
+        if (it.ro != readout || !it.src) continue;      // absent parameter (ff_logit_ctxglm without ctx2out)
+        CHK(getbuf_t(h, it.name, (size_t)it.K * it.N, it.dst));
+        HIPCHK(h, launch_cvt_bf16_t(s, it.src, it.N, *it.dst, it.K, it.K, it.N));
+    }
+    return STATTN_OK;
+}
+
+hipError_t gemm_bf(stattn_handle* h, const GemmBfArgs& g) {
+    Prof pr(h, KC_GEMM_NN);
+    return launch_gemm_bf16(h->stream, g);
+}
+GemmBfArgs bf_args(const uint16_t* A, int lda, const uint16_t* B, int M, int N, int Kd) {
+    GemmBfArgs g{};
+    g.A = A; g.lda = lda; g.B = B; g.ldb = Kd; g.M = M; g.N = N; g.K = Kd; g.rowgroup = 1;
+    return g;
+}
+
+// project_context with bf16 operands: L / PL / LW are written as bf16 INTO the (fp32-sized) buffers of CtxPtrs
+int project_context_bf16(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
+                         const CtxPtrs& c) {
+    const int D = h->D;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    Prof pr(h, KC_PROLOGUE);
+    BfWeights bw{};
+    CHK(bf16_weights(h, &bw, false));
+    const size_t nl = (size_t)nv * T * K, nf = (size_t)nv * T;
+    uint16_t *xl, *xm, *xg, *mo;
+    CHK(getbuf_t(h, "bx_ctxl", nl * h->Fl, &xl));
+    CHK(getbuf_t(h, "bx_ctxm", nf * h->Fm, &xm));
+    CHK(getbuf_t(h, "bx_ctxg", nf * D, &xg));
+    CHK(getbuf_t(h, "bx_Mo", nf * D, &mo));
+    HIPCHK(h, launch_cvt_bf16(s, ctxl, xl, nl * h->Fl));
+    HIPCHK(h, launch_cvt_bf16(s, ctxm, xm, nf * h->Fm));
+    HIPCHK(h, launch_cvt_bf16(s, ctxg, xg, nf * D));
+    uint16_t* Lb = reinterpret_cast<uint16_t*>(c.L);
+    GemmBfArgs g = bf_args(xl, h->Fl, bw.ff_local, (int)nl, D, h->Fl);       // L = tanh(ctxl . ff_local_W + b)
+    g.bias = w.ff_local_b; g.act = 1; g.Cb = Lb; g.ldcb = D;
+    HIPCHK(h, gemm_bf(h, g));
+    g = bf_args(xm, h->Fm, bw.ff_motion, (int)nf, D, h->Fm);                  // M = tanh(ctxm . ff_motion_W + b)
+    g.bias = w.ff_motion_b; g.act = 1; g.C = c.Mo; g.ldc = D; g.Cb = mo; g.ldcb = D;
+    HIPCHK(h, gemm_bf(h, g));
+    g = bf_args(xg, D, bw.Wcg, (int)nf, D, D);                                // pctxg_
+    g.bias = w.bg; g.C = c.PG; g.ldc = D;
+    HIPCHK(h, gemm_bf(h, g));
+    g = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                                // pctxl_
+    g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
+    HIPCHK(h, gemm_bf(h, g));
+    g = bf_args(mo, D, bw.Wcm, (int)nf, D, D);                                // pctxm_
+    g.bias = w.bm; g.C = c.PM; g.ldc = D;
+    HIPCHK(h, gemm_bf(h, g));
+    g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                               // LW = L . Wclt
+    g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
+    HIPCHK(h, gemm_bf(h, g));
+    return STATTN_OK;
+}
+
 int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
                     const CtxPtrs& c) {
+    if (h->opt.precision == 1) return project_context_bf16(h, nv, T, K, ctxg, ctxl, ctxm, c);
     const int D = h->D;
     const Weights& w = h->w;
     Prof pr(h, KC_PROLOGUE);
@@ -371,6 +448,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         Prof pr(h, KC_SPATIAL);
         SpatialArgs a{};
         a.PL = io.c.PL; a.L = io.c.L; a.LW = h->opt.lt_mode == 1 ? io.c.LW : nullptr;
+        a.bf16 = h->opt.precision == 1;
         a.PG = io.c.PG; a.PM = io.c.PM; a.vid = io.vid;
         a.sproj = io.sproj; a.ldsp = 4 * D;
         a.Ul = w.Ul; a.cl = w.cl; a.Ug = w.Ug; a.cg = w.cg; a.Um = w.Um; a.cm = w.cm;
@@ -472,6 +550,8 @@ int stattn_create(const stattn_options* o, int device, void* stream, stattn_hand
     if (!o->use_dropout)
         return fail(nullptr, STATTN_EINVAL, "use_dropout must be true: the reference's False branch is broken (model_attention.py:479-481)");
     if (o->lt_mode != 0 && o->lt_mode != 1) return fail(nullptr, STATTN_EINVAL, "lt_mode must be 0 or 1");
+    if (o->precision != 0 && o->precision != 1) return fail(nullptr, STATTN_EINVAL, "precision must be 0 (fp32) or 1 (bf16)");
+    if (o->precision == 1 && o->lt_mode != 1) return fail(nullptr, STATTN_EINVAL, "the bf16 path needs lt_mode 1");
 
     int ndev = 0;
     hipError_t e = hipGetDeviceCount(&ndev);
@@ -1093,16 +1173,27 @@ int stattn_forward_train(stattn_handle* h) {
     CHK(prepare_masks(h, t, m, &dp, &d1, &d2));
 
     // ---- prologue, once per batch
+    BfWeights bw{};
+    uint16_t* bemb = nullptr;
     CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
     {
         Prof pp(h, KC_PROLOGUE);
         CHK(init_state(h, m, T, c.G, mG, mean, hs, cs));
         HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, (int)R, E, V, m));      // emb shifted one step (:613-617)
-        GemmArgs g;
-        gemm_defaults(g);                                                   // x_ = emb.W + b (:334-335)
-        g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
-        g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
-        HIPCHK(h, gemm_nn(h, g));
+        if (h->opt.precision == 1) {
+            CHK(bf16_weights(h, &bw, true));
+            CHK(getbuf_t(h, "bx_emb", R * E, &bemb));
+            HIPCHK(h, launch_cvt_bf16(s, emb, bemb, R * E));
+            GemmBfArgs g = bf_args(bemb, E, bw.W, (int)R, 4 * D, E);       // x_ = emb.W + b (:334-335)
+            g.bias = w.b; g.C = xproj; g.ldc = 4 * D;
+            HIPCHK(h, gemm_bf(h, g));
+        } else {
+            GemmArgs g;
+            gemm_defaults(g);                                               // x_ = emb.W + b (:334-335)
+            g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
+            g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
+            HIPCHK(h, gemm_nn(h, g));
+        }
     }
 
     // ---- the scan over caption positions (:495-512)
@@ -1123,7 +1214,29 @@ int stattn_forward_train(stattn_handle* h) {
     }
 
     // ---- readout over all (t*m) rows at once (:684-705), softmax and masked NLL (:708-715)
-    {
+    if (h->opt.precision == 1) {   // same three GEMMs on the bf16 MFMA kernel; activations rounded to bf16 on the way in
+        Prof pr_(h, KC_READOUT);
+        uint16_t *bhd, *bctx, *ba1;
+        CHK(getbuf_t(h, "bx_hd", R * D, &bhd));
+        CHK(getbuf_t(h, "bx_ctx", R * D, &bctx));
+        CHK(getbuf_t(h, "bx_a1", R * E, &ba1));
+        HIPCHK(h, launch_cvt_bf16(s, hd, bhd, R * D));
+        GemmBfArgs g = bf_args(bhd, D, bw.Wl1, (int)R, E, D);
+        g.bias = w.bl1;
+        if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
+        if (h->opt.ctx2out) { g.C = z1; g.ldc = E; }
+        else { g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E; }
+        HIPCHK(h, gemm_bf(h, g));
+        if (h->opt.ctx2out) {
+            HIPCHK(h, launch_cvt_bf16(s, ctx, bctx, R * D));
+            g = bf_args(bctx, D, bw.Wl2, (int)R, E, D);
+            g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E;
+            HIPCHK(h, gemm_bf(h, g));
+        }
+        g = bf_args(ba1, E, bw.Wo, (int)R, Vp, E);
+        g.bias = w.bo; g.C = lg; g.ldc = Vp;
+        HIPCHK(h, gemm_bf(h, g));
+    } else {
         Prof pr_(h, KC_READOUT);
         GemmArgs g;
         gemm_defaults(g);      // z1 = (h*d1).Wl1 + bl1 [+ emb]
@@ -1187,6 +1300,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (!h) return STATTN_EINVAL;
     if (!h->have_fwd) return fail(h, STATTN_ESTATE, "backward: no forward pass has run on the staged batch");
     if (h->opt.lt_mode != 1) return fail(h, STATTN_EINVAL, "backward is implemented for lt_mode 1 only");
+    if (h->opt.precision != 0) return fail(h, STATTN_EINVAL, "backward needs an fp32 handle: the bf16 path is forward / decode only");
     HIPCHK(h, hipSetDevice(h->device));
     const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp, Fl = h->Fl, Fm = h->Fm;
     const Weights& w = h->w;

@@ -125,6 +125,120 @@ __global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
     }
 }
 
+// ---- bf16 storage variant (precision = bf16 handles): PL / L / LW are bf16, 8 values per 16-byte load, all
+// arithmetic in fp32.  Halves the HBM traffic of the step's dominant kernel.  NT threads cover D / 8 lanes.
+__device__ __forceinline__ void bf8_to_f32(const uint4 v, float (&f)[8]) {
+    f[0] = __uint_as_float(v.x << 16); f[1] = __uint_as_float(v.x & 0xffff0000u);
+    f[2] = __uint_as_float(v.y << 16); f[3] = __uint_as_float(v.y & 0xffff0000u);
+    f[4] = __uint_as_float(v.z << 16); f[5] = __uint_as_float(v.z & 0xffff0000u);
+    f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+__device__ __forceinline__ uint4 ld16(const uint16_t* p) { return *reinterpret_cast<const uint4*>(p); }
+
+template <int N, int NW>
+__device__ __forceinline__ void block_sum_w(float (&v)[N], float* s_red /*[NW][N]*/, int tid) {
+    const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        const float r = wave_sum(v[i]);
+        if (lane == 0) s_red[w * N + i] = r;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < N; ++i) {
+        float t = 0.f;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) t += s_red[q * N + i];
+        v[i] = t;
+    }
+    __syncthreads();
+}
+
+template <int NT>
+__global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ float s_red[NW * 10];
+    __shared__ float s_e[KMAX];
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int v = a.vid ? a.vid[b] : b;
+    const int tid = threadIdx.x;
+    const size_t slab = ((size_t)v * T + t) * K * D;
+    const uint16_t* __restrict__ PL = reinterpret_cast<const uint16_t*>(a.PL) + slab;
+    const uint16_t* __restrict__ L = reinterpret_cast<const uint16_t*>(a.L) + slab;
+    const uint16_t* __restrict__ LW = reinterpret_cast<const uint16_t*>(a.LW) + slab;
+    const float* __restrict__ sl = a.sproj + (size_t)b * a.ldsp;
+    const int nd8 = D >> 3;
+
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float p[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) p[i] = 0.f;
+        for (int d8 = tid; d8 < nd8; d8 += NT) {
+            uint4 x[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) x[kk] = ld16(PL + (size_t)min(k0 + kk, K - 1) * D + 8 * d8);
+            const float4 s0 = ld4(sl + 8 * d8), s1 = ld4(sl + 8 * d8 + 4);
+            const float4 u0 = ld4(a.Ul + 8 * d8), u1 = ld4(a.Ul + 8 * d8 + 4);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                float f[8];
+                bf8_to_f32(x[kk], f);
+                p[kk] += dot4_tanh(make_float4(f[0], f[1], f[2], f[3]), s0, u0) +
+                         dot4_tanh(make_float4(f[4], f[5], f[6], f[7]), s1, u1);
+            }
+            if (k0 == 0) {      // frame scores: PG / PM stay fp32 (they are K times smaller)
+                const size_t fo = ((size_t)v * T + t) * D + 8 * d8;
+                p[8] += dot4_tanh(ld4(a.PG + fo), ld4(sl + D + 8 * d8), ld4(a.Ug + 8 * d8)) +
+                        dot4_tanh(ld4(a.PG + fo + 4), ld4(sl + D + 8 * d8 + 4), ld4(a.Ug + 8 * d8 + 4));
+                p[9] += dot4_tanh(ld4(a.PM + fo), ld4(sl + 2 * D + 8 * d8), ld4(a.Um + 8 * d8)) +
+                        dot4_tanh(ld4(a.PM + fo + 4), ld4(sl + 2 * D + 8 * d8 + 4), ld4(a.Um + 8 * d8 + 4));
+            }
+        }
+        block_sum_w<10, NW>(p, s_red, tid);
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+    }
+    __syncthreads();
+
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_e[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += __expf(s_e[k] - mx);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    if (tid < K) {
+        const float al = __expf(s_e[tid] - mx) * inv;
+        a.alphal[(size_t)bt * K + tid] = al;
+        s_e[tid] = al;
+    }
+    __syncthreads();
+
+    float pe[1] = {0.f};
+    for (int d8 = tid; d8 < nd8; d8 += NT) {
+        float c[8], w[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) { c[q] = 0.f; w[q] = 0.f; }
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float al = s_e[k];
+            float f[8], q8[8];
+            bf8_to_f32(ld16(L + (size_t)k * D + 8 * d8), f);
+            bf8_to_f32(ld16(LW + (size_t)k * D + 8 * d8), q8);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) { c[q] += al * f[q]; w[q] += al * q8[q]; }
+        }
+        st4(a.CL + (size_t)bt * D + 8 * d8, make_float4(c[0], c[1], c[2], c[3]));
+        st4(a.CL + (size_t)bt * D + 8 * d8 + 4, make_float4(c[4], c[5], c[6], c[7]));
+        const float4 b0 = ld4(a.blt + 8 * d8), b1 = ld4(a.blt + 8 * d8 + 4);
+        pe[0] += dot4_tanh(make_float4(w[0] + b0.x, w[1] + b0.y, w[2] + b0.z, w[3] + b0.w), ld4(sl + 3 * D + 8 * d8), ld4(a.Ult + 8 * d8)) +
+                 dot4_tanh(make_float4(w[4] + b1.x, w[5] + b1.y, w[6] + b1.z, w[7] + b1.w), ld4(sl + 3 * D + 8 * d8 + 4), ld4(a.Ult + 8 * d8 + 4));
+    }
+    block_sum_w<1, NW>(pe, s_red, tid);
+    if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+}
+
 // one wave per row: out[r] = dot(P[r,:], U) + c
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P, int ldp,
                                                      const float* __restrict__ U, const float* __restrict__ c,
@@ -220,6 +334,12 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
     if (a.M <= 0) return hipSuccess;
     if (a.K > KMAX || a.K < 1 || a.D % 4 != 0) return hipErrorInvalidValue;
+    if (a.bf16) {
+        if (a.D % 8 != 0 || !a.LW) return hipErrorInvalidValue;
+        if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }

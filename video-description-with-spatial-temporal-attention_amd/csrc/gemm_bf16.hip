@@ -4,7 +4,7 @@
 // batched readout (:687-705) take bf16 operands; everything recurrent stays fp32.
 //
 //   C[M,N] = epi(A[M,K] . B[N,K]^T)        A and B are both k-contiguous (weights are kept pre-transposed)
-//   epi(v)[m,n] = act(v + bias[n] + add[m,n] + rowadd[m / rowgroup, n]);  written as fp32 (C) and/or bf16 (Cb)
+//   epi(v)[m,n] = act(v + bias[n] + add[m,n] + rowadd[m / rowgroup, n]) * mul[m,n];  written as fp32 (C) and/or bf16 (Cb)
 //
 // Same schedule as the fp32 kernel (gemm.hip, MainLoop): 4 waves as 2x2, two LDS stages, global loads two tiles
 // ahead in registers, LDS write after k-block 1, barrier after k-block 2, next tile's first fragments before k-block 3.
@@ -65,7 +65,7 @@ struct TileB {
 };
 
 template <int TM, int TN, bool EDGE>
-__global__ __launch_bounds__(256, (TM * TN > 4) ? 1 : 2) void gemm_bf16_kernel(const GemmBfArgs g) {
+__global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = TileB<BM>;
     using TB = TileB<BN>;
@@ -175,6 +175,7 @@ __global__ __launch_bounds__(256, (TM * TN > 4) ? 1 : 2) void gemm_bf16_kernel(c
                     if (g.add) v += g.add[(size_t)row * g.ldadd + col];
                     if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
                     if (g.act == 1) v = fast_tanh(v);
+                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
                     if (g.C) g.C[(size_t)row * g.ldc + col] = v;
                     if (g.Cb) g.Cb[(size_t)row * g.ldcb + col] = f2bf(v);
                 }
@@ -233,13 +234,12 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (g.rowgroup < 1) g.rowgroup = 1;
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
-    // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 42 forces one for the sweep
+    // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 forces one for the sweep
     static const char* force = getenv("STATTN_BF16_TILE");
     const int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
     if (tile == 11) return launch_tile<1, 1>(s, g);
     if (tile == 21) return launch_tile<2, 1>(s, g);
     if (tile == 22 && g.N % 128 == 0) return launch_tile<2, 2>(s, g);
-    if (tile == 42 && g.N % 128 == 0) return launch_tile<4, 2>(s, g);
     if (tile) return hipErrorInvalidValue;
     const long t22 = (long)((g.M + 127) / 128) * (g.N / 128);
     if (g.N % 128 == 0 && t22 >= 512) return launch_tile<2, 2>(s, g);

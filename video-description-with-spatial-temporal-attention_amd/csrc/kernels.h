@@ -52,7 +52,8 @@ struct GemmBfArgs {
     const float* add; int ldadd;
     const float* rowadd; int ldrow; int rowgroup;
     int act;                           // 0 none, 1 tanh
-    int tile;                          // 0 = choose; 11 / 21 / 22 / 42 = (64*TM) x (64*TN) workgroup tile (sweep tool)
+    const float* mul; int ldmul;       // [M,N] multiplier applied after act (dropout mask), or null
+    int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) workgroup tile (sweep tool)
     int xcd_remap;                     // internal
 };
 hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
@@ -117,6 +118,7 @@ hipError_t launch_lstm(hipStream_t s, const LstmArgs& a);
 struct SpatialArgs {
     // per-video projected context, video index = vid[b] (null => b)
     const float* PL; const float* L; const float* LW;   // [nvid,T,K,D]; LW null in lt_mode 0
+    int bf16;                                           // PL / L / LW hold bf16 (precision = bf16 handles; lt_mode 1)
     const float* PG; const float* PM;                   // [nvid,T,D]
     const int* vid;
     // state projections of this step: sproj[b] = [sl | sg | sm | slt], row stride ldsp

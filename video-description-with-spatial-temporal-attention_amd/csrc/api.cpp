@@ -1371,6 +1371,14 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         return launch_gemm(s, g, tA, tB);
     };
 
+    // bias gradients (column sums) are collected and run as ONE batched launch pair at the end of the pass: their
+    // sources stay untouched until then
+    ColsumBatch csb{};
+    float* cspart;
+    CHK(getbuf_t(h, "b_cspart", COLSUM_BATCH_PART_FLOATS, &cspart));
+#define CSADD(X, LD, ROWS, N, DST, ACC, RW)                                                                      \
+    do { if (!colsum_batch_add(csb, X, LD, ROWS, N, DST, ACC, RW)) return fail(h, STATTN_EINVAL, "backward: colsum batch overflow"); } while (0)
+
     HIPCHK(h, hipMemsetAsync(h->d_grads, 0, h->nflat * sizeof(float), s));
 
     // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
@@ -1395,16 +1403,16 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // ---- softmax / NLL and readout (:687-715), all (t*m) rows at once
     HIPCHK(h, launch_dlogit(s, pr, Vp, dx, dmask, nll_scale, lg, Vp, (int)R, V, Vp));           // dlogit overwrites logits
     HIPCHK(h, gemm(true, false, a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R, 0));         // dWo = a^T dlogit
-    HIPCHK(h, launch_colsum(s, lg, Vp, (int)R, Vp, cpart, G_("ff_logit_b"), 0));
+    CSADD(lg, Vp, (int)R, Vp, G_("ff_logit_b"), 0, nullptr);
     HIPCHK(h, gemm(false, true, lg, Vp, w.Wo, Vp, da, E, (int)R, E, Vp, 0));                     // da = dlogit Wo^T
     HIPCHK(h, launch_tanh_bwd(s, da, tz, d2, da, R * E));                                        // dz (in place)
     float* dz = da;
     HIPCHK(h, gemm(true, false, hd, D, dz, E, G_("ff_logit_lstm_W"), E, D, E, (int)R, 0));
-    HIPCHK(h, launch_colsum(s, dz, E, (int)R, E, cpart, G_("ff_logit_lstm_b"), 0));
+    CSADD(dz, E, (int)R, E, G_("ff_logit_lstm_b"), 0, nullptr);
     HIPCHK(h, gemm(false, true, dz, E, w.Wl1, E, dhd, D, (int)R, D, E, 0));                      // dhd = dz Wl1^T
     if (h->opt.ctx2out) {
         HIPCHK(h, gemm(true, false, ctx, D, dz, E, G_("ff_logit_ctxglm_W"), E, D, E, (int)R, 0));
-        HIPCHK(h, launch_colsum(s, dz, E, (int)R, E, cpart, G_("ff_logit_ctxglm_b"), 0));
+        CSADD(dz, E, (int)R, E, G_("ff_logit_ctxglm_b"), 0, nullptr);
         HIPCHK(h, gemm(false, true, dz, E, w.Wl2, E, dctx_r, D, (int)R, D, E, 0));
     }
 
@@ -1477,9 +1485,9 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, KZ1, dhWP, KZ2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
                                 dph0, dpc0, m, D));
     HIPCHK(h, gemm(true, false, mean, D, dph0, D, G_("ff_state_W"), D, D, D, m, 0));
-    HIPCHK(h, launch_colsum(s, dph0, D, m, D, cpart, G_("ff_state_b"), 0));
+    CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
     HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
-    HIPCHK(h, launch_colsum(s, dpc0, D, m, D, cpart, G_("ff_memory_b"), 0));
+    CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
 
     // ---- deferred context gradients
     {
@@ -1491,10 +1499,10 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         a.pUl = pUl; a.pUlt = pUlt; a.pUg = pUg; a.pUm = pUm; a.S = t; a.M = m; a.T = T; a.K = K; a.D = D;
         HIPCHK(h, launch_ctxgrad(s, a));
     }
-    HIPCHK(h, launch_colsum(s, pUl, D, (int)MT, D, cpart, G_("decoder_Ul_att"), 0));
-    HIPCHK(h, launch_colsum(s, pUlt, D, (int)MT, D, cpart, G_("decoder_Ult_att"), 0));
-    HIPCHK(h, launch_colsum(s, pUg, D, (int)MT, D, cpart, G_("decoder_Ug_att"), 0));
-    HIPCHK(h, launch_colsum(s, pUm, D, (int)MT, D, cpart, G_("decoder_Um_att"), 0));
+    CSADD(pUl, D, (int)MT, D, G_("decoder_Ul_att"), 0, nullptr);
+    CSADD(pUlt, D, (int)MT, D, G_("decoder_Ult_att"), 0, nullptr);
+    CSADD(pUg, D, (int)MT, D, G_("decoder_Ug_att"), 0, nullptr);
+    CSADD(pUm, D, (int)MT, D, G_("decoder_Um_att"), 0, nullptr);
     {   // scalar biases of the four attention scorers (+ the selector bias): full sums, one launch
         MultiSumArgs ms{};
         const float* srcs[5] = {del, delt, deg, dem, dselpre};
@@ -1504,27 +1512,27 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         for (int i = 0; i < ms.count; ++i) { ms.src[i] = srcs[i]; ms.n[i] = ns[i]; ms.dst[i] = G_(names[i]); ms.scale[i] = 1.f; }
         HIPCHK(h, launch_multi_sum(s, ms, cpart));
     }
-    HIPCHK(h, launch_colsum(s, dplt, D, (int)(R * T), D, cpart, G_("decoder_blt_att"), 0));
+    CSADD(dsproj + 3 * (size_t)D, 4 * D, (int)R, D, G_("decoder_blt_att"), 0, nullptr);   // sum_{s,b,t} dplt = sum_{s,b} dslt (reduce_T already summed over t)
     if (h->opt.selector) {
-        HIPCHK(h, launch_colsum(s, hs, D, (int)R, D, cpart, G_("decoder_W_sel"), 0, dselpre));   // h_prev^T . dselpre
+        CSADD(hs, D, (int)R, D, G_("decoder_W_sel"), 0, dselpre);   // h_prev^T . dselpre
     }
     // attention pre-projections (:322-326) and the hoisted L.Wclt
     HIPCHK(h, gemm(true, false, L, D, dPL, D, G_("decoder_Wcl_att"), D, D, D, (int)MTK, 0));
-    HIPCHK(h, launch_colsum(s, dPL, D, (int)MTK, D, cpart, G_("decoder_bl_att"), 0));
+    CSADD(dPL, D, (int)MTK, D, G_("decoder_bl_att"), 0, nullptr);
     HIPCHK(h, gemm(true, false, L, D, dLW, D, G_("decoder_Wclt_att"), D, D, D, (int)MTK, 0));
     HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
     HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
     HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));                                  // L = tanh(ff_local) (:664-665)
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
-    HIPCHK(h, launch_colsum(s, dL, D, (int)MTK, D, cpart, G_("ff_local_b"), 0));
+    CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);
     HIPCHK(h, gemm(true, false, Gc, D, dPG, D, G_("decoder_Wcg_att"), D, D, D, (int)MT, 0));
-    HIPCHK(h, launch_colsum(s, dPG, D, (int)MT, D, cpart, G_("decoder_bg_att"), 0));
+    CSADD(dPG, D, (int)MT, D, G_("decoder_bg_att"), 0, nullptr);
     HIPCHK(h, gemm(true, false, Mo, D, dPM, D, G_("decoder_Wcm_att"), D, D, D, (int)MT, 0));
-    HIPCHK(h, launch_colsum(s, dPM, D, (int)MT, D, cpart, G_("decoder_bm_att"), 0));
+    CSADD(dPM, D, (int)MT, D, G_("decoder_bm_att"), 0, nullptr);
     HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
     HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));                                // M = tanh(ff_motion) (:666-667)
     HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
-    HIPCHK(h, launch_colsum(s, dMo, D, (int)MT, D, cpart, G_("ff_motion_b"), 0));
+    CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
     // recurrent weights: one batched TN GEMM over all (t*m) rows each
     HIPCHK(h, gemm(true, false, hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R, 0));
     HIPCHK(h, gemm(true, false, ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R, 0));
@@ -1534,10 +1542,12 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, gemm(true, false, hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), D, D, D, (int)R, 0));
     }
     HIPCHK(h, gemm(true, false, emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R, 0));
-    HIPCHK(h, launch_colsum(s, dpre, 4 * D, (int)R, 4 * D, cpart, G_("decoder_b"), 0));
+    CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
     // embedding: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
     HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, 0, h->opt.prev2out ? dz : nullptr, E));
     HIPCHK(h, launch_embed_bwd(s, dx, demb, G_("Wemb"), (int)R, E, V, m));
+    HIPCHK(h, launch_colsum_batch(s, csb, cspart));
+#undef CSADD
     h->have_bwd = true;
     return STATTN_OK;
 }

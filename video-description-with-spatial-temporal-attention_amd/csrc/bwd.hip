@@ -408,6 +408,55 @@ __global__ void colsum_final_kernel(const float* __restrict__ part, int rsplit, 
     for (int r = 0; r < rsplit; ++r) acc += part[(size_t)r * N + n];
     dst[n] = accumulate ? dst[n] + acc : acc;
 }
+// the same for many matrices at once: bias gradients are ~17 such sums per backward pass, most of them far too
+// small to fill the chip or to amortise a launch on their own.  256 columns (64 lanes x float4) per workgroup.
+__global__ __launch_bounds__(256) void colsum_batch_part_kernel(const ColsumBatch b, float* __restrict__ part) {
+    __shared__ float4 s[4][64];
+    int ji = 0;
+    while (ji + 1 < b.n && (int)blockIdx.x >= b.j[ji + 1].blk0) ++ji;
+    const ColsumJob& j = b.j[ji];
+    const int local = blockIdx.x - j.blk0;
+    const int ncb = (j.N + 255) / 256;
+    const int cb = local % ncb, slice = local / ncb;
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+    const int n = cb * 256 + 4 * lane;
+    const int per = (j.rows + j.rs - 1) / j.rs;
+    const int r0 = slice * per, r1 = min(j.rows, r0 + per);
+    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (n < j.N) {
+        const float* __restrict__ X = j.X + n;
+        if (j.rw) {
+            for (int r = r0 + w; r < r1; r += 4) fma4(acc, j.rw[r], ld4(X + (size_t)r * j.ldx));
+        } else {
+            int r = r0 + w;
+            for (; r + 12 < r1; r += 16) {     // four independent loads in flight per lane
+                const float4 x0 = ld4(X + (size_t)r * j.ldx), x1 = ld4(X + (size_t)(r + 4) * j.ldx);
+                const float4 x2 = ld4(X + (size_t)(r + 8) * j.ldx), x3 = ld4(X + (size_t)(r + 12) * j.ldx);
+                add4(acc, x0); add4(acc, x1); add4(acc, x2); add4(acc, x3);
+            }
+            for (; r < r1; r += 4) add4(acc, ld4(X + (size_t)r * j.ldx));
+        }
+    }
+    s[w][lane] = acc;
+    __syncthreads();
+    if (w == 0 && n < j.N) {
+        float4 t = s[0][lane];
+        add4(t, s[1][lane]); add4(t, s[2][lane]); add4(t, s[3][lane]);
+        st4(part + j.part0 + (size_t)slice * j.N + n, t);
+    }
+}
+__global__ __launch_bounds__(256) void colsum_batch_final_kernel(const ColsumBatch b, const float* __restrict__ part) {
+    int ji = 0;
+    while (ji + 1 < b.n && (int)blockIdx.x >= b.j[ji + 1].fblk0) ++ji;
+    const ColsumJob& j = b.j[ji];
+    const int n = (blockIdx.x - j.fblk0) * 256 + threadIdx.x;
+    if (n >= j.N) return;
+    const float* __restrict__ p = part + j.part0 + n;
+    float acc = 0.f;
+#pragma unroll 8
+    for (int r = 0; r < j.rs; ++r) acc += p[(size_t)r * j.N];
+    j.dst[n] = j.accumulate ? j.dst[n] + acc : acc;
+}
 // several independent full sums in one launch pair: 32 workgroups per job write partials, a second tiny kernel
 // adds them in a fixed order (deterministic)
 constexpr int MS_BLOCKS = 32;
@@ -589,6 +638,28 @@ hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N
     const int rs = colsum_parts(rows, N);
     hipLaunchKernelGGL(colsum_part_kernel, dim3((N + 63) / 64, rs), dim3(256), 0, s, X, ldx, rows, N, part, rs, row_weights);
     hipLaunchKernelGGL(colsum_final_kernel, dim3((N + 255) / 256), dim3(256), 0, s, part, rs, N, dst, accumulate);
+    return hipGetLastError();
+}
+bool colsum_batch_add(ColsumBatch& b, const float* X, int ldx, int rows, int N, float* dst, int accumulate, const float* rw) {
+    if (rows <= 0 || N <= 0) return true;
+    if (b.n >= 24 || N % 4 != 0 || ldx % 4 != 0) return false;
+    ColsumJob& j = b.j[b.n];
+    const int ncb = (N + 255) / 256;
+    int rs = rows / 32;                       // >= 32 rows per slice (8 per wave)
+    if (rs > 512 / ncb) rs = 512 / ncb;
+    if (rs < 1) rs = 1;
+    j.X = X; j.rw = rw; j.dst = dst; j.ldx = ldx; j.rows = rows; j.N = N; j.rs = rs; j.accumulate = accumulate;
+    j.blk0 = b.nblk; j.fblk0 = b.nfblk;
+    j.part0 = b.n ? b.j[b.n - 1].part0 + b.j[b.n - 1].rs * b.j[b.n - 1].N : 0;
+    if ((size_t)j.part0 + (size_t)rs * N > COLSUM_BATCH_PART_FLOATS) return false;
+    b.nblk += ncb * rs; b.nfblk += ncb;
+    ++b.n;
+    return true;
+}
+hipError_t launch_colsum_batch(hipStream_t s, const ColsumBatch& b, float* part) {
+    if (b.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(colsum_batch_part_kernel, dim3(b.nblk), dim3(256), 0, s, b, part);
+    hipLaunchKernelGGL(colsum_batch_final_kernel, dim3(b.nfblk), dim3(256), 0, s, b, part);
     return hipGetLastError();
 }
 hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part /* >= 12 * 32 floats */) {

@@ -247,6 +247,14 @@ hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a);
 int colsum_parts(int rows, int N);
 hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,
                          const float* row_weights = nullptr);
+// Batched column sums (bias gradients): up to 24 independent jobs dst[n] (+)= sum_r rw[r] * X[r, n] in one launch pair.
+// Each job is cut into row slices whose partials land in `part`, a second kernel adds them in slice order
+// (deterministic).  N % 4 == 0, ldx % 4 == 0, X 16-byte aligned.  `part` must hold 24 * 131072 floats.
+struct ColsumJob { const float* X; const float* rw; float* dst; int ldx, rows, N, rs, accumulate, blk0, fblk0, part0; };
+struct ColsumBatch { ColsumJob j[24]; int n; int nblk, nfblk; };
+bool colsum_batch_add(ColsumBatch& b, const float* X, int ldx, int rows, int N, float* dst, int accumulate, const float* rw = nullptr);
+hipError_t launch_colsum_batch(hipStream_t s, const ColsumBatch& b, float* part);
+constexpr size_t COLSUM_BATCH_PART_FLOATS = (size_t)24 * 131072;
 struct MultiSumArgs { const float* src[12]; size_t n[12]; float* dst[12]; float scale[12]; int count; };
 hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]]); part: >= 384 floats
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);

@@ -375,7 +375,7 @@ def main():
     slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
     sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
     sp_ms = kms["spatial"][0]
-    roofline_hbm = dict(kernel="spatial_bf16_kernel" if bf16 else "spatial_kernel", bound="hbm",
+    roofline_hbm = dict(kernel="spatial_bf16_kernel" if bf16 else ("spatial2_kernel<128>" if D % 1024 == 0 else "spatial_kernel"), bound="hbm",
                         achieved=sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms else None,
                         peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
                         bytes_per_launch=sp_bytes, ms_per_launch=sp_ms)

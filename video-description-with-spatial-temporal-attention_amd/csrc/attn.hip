@@ -17,6 +17,8 @@
 #include "kernels.h"
 #include "devmath.h"
 
+#include <cstdlib>
+
 namespace stattn {
 
 namespace {
@@ -152,6 +154,96 @@ __device__ __forceinline__ void block_sum_w(float (&v)[N], float* s_red /*[NW][N
         v[i] = t;
     }
     __syncthreads();
+}
+
+// fp32 variant with NT threads per workgroup and TWO d4 columns per thread (both sets of loads in flight together).
+// Purpose: spatial_kernel needs 75 VGPRs -> 6 workgroups of 256 per CU -> 1536 resident for the 1664 (b,t) items of
+// configs[1]: an 8 % second round.  128-thread workgroups are all resident at once.
+template <int NT>
+__global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
+    constexpr int NW = NT / 64;
+    __shared__ float s_red[NW * 10];
+    __shared__ float s_e[KMAX];
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int v = a.vid ? a.vid[b] : b;
+    const int tid = threadIdx.x;
+    const size_t slab = ((size_t)v * T + t) * K * D;
+    const float* __restrict__ PL = a.PL + slab;
+    const float* __restrict__ L = a.L + slab;
+    const float* __restrict__ sl = a.sproj + (size_t)b * a.ldsp;
+    const int nd4 = D >> 2;
+
+    for (int k0 = 0; k0 < K; k0 += 8) {
+        float p[10];
+#pragma unroll
+        for (int i = 0; i < 10; ++i) p[i] = 0.f;
+        for (int da = tid; da < nd4; da += 2 * NT) {
+            const int db = da + NT < nd4 ? da + NT : da;          // second column (clamped: weight 0 below)
+            const float wb = da + NT < nd4 ? 1.f : 0.f;
+            float4 xa[8], xb[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) {
+                const size_t ro = (size_t)min(k0 + kk, K - 1) * D;
+                xa[kk] = ld4(PL + ro + 4 * da);
+                xb[kk] = ld4(PL + ro + 4 * db);
+            }
+            const float4 sa = ld4(sl + 4 * da), ua = ld4(a.Ul + 4 * da);
+            const float4 sb = ld4(sl + 4 * db), ub = ld4(a.Ul + 4 * db);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) p[kk] += dot4_tanh(xa[kk], sa, ua) + wb * dot4_tanh(xb[kk], sb, ub);
+            if (k0 == 0) {
+                const size_t fa = ((size_t)v * T + t) * D + 4 * da, fb = ((size_t)v * T + t) * D + 4 * db;
+                p[8] += dot4_tanh(ld4(a.PG + fa), ld4(sl + D + 4 * da), ld4(a.Ug + 4 * da)) +
+                        wb * dot4_tanh(ld4(a.PG + fb), ld4(sl + D + 4 * db), ld4(a.Ug + 4 * db));
+                p[9] += dot4_tanh(ld4(a.PM + fa), ld4(sl + 2 * D + 4 * da), ld4(a.Um + 4 * da)) +
+                        wb * dot4_tanh(ld4(a.PM + fb), ld4(sl + 2 * D + 4 * db), ld4(a.Um + 4 * db));
+            }
+        }
+        block_sum_w<10, NW>(p, s_red, tid);
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+    }
+    __syncthreads();
+    float mx = -INFINITY;
+    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_e[k]);
+    float sum = 0.f;
+    for (int k = 0; k < K; ++k) sum += __expf(s_e[k] - mx);
+    const float inv = 1.0f / sum;
+    __syncthreads();
+    if (tid < K) {
+        const float al = __expf(s_e[tid] - mx) * inv;
+        a.alphal[(size_t)bt * K + tid] = al;
+        s_e[tid] = al;
+    }
+    __syncthreads();
+
+    float pe[1] = {0.f};
+    const float* __restrict__ LW = a.LW ? a.LW + slab : nullptr;
+    for (int d4 = tid; d4 < nd4; d4 += NT) {
+        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+            const float al = s_e[k];
+            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
+            c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
+            if (LW) {
+                const float4 q4 = ld4(LW + (size_t)k * D + 4 * d4);
+                w4.x += al * q4.x; w4.y += al * q4.y; w4.z += al * q4.z; w4.w += al * q4.w;
+            }
+        }
+        st4(a.CL + (size_t)bt * D + 4 * d4, c4);
+        if (LW) {
+            const float4 bl = ld4(a.blt + 4 * d4);
+            w4.x += bl.x; w4.y += bl.y; w4.z += bl.z; w4.w += bl.w;
+            pe[0] += dot4_tanh(w4, ld4(sl + 3 * D + 4 * d4), ld4(a.Ult + 4 * d4));
+        }
+    }
+    if (LW) {
+        block_sum_w<1, NW>(pe, s_red, tid);
+        if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+    }
 }
 
 template <int NT>
@@ -340,7 +432,11 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
         else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T), dim3(256), 0, s, a);
         return hipGetLastError();
     }
-    hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    // D a multiple of 1024: 128-thread workgroups with two columns per thread (all items of configs[1] resident at
+    // once: 36 us instead of 41 us per launch there); otherwise the 256-thread kernel, one column per thread
+    static const char* v1 = getenv("STATTN_SPATIAL1");          // A/B switch for tools
+    if (a.D % 1024 == 0 && !v1) hipLaunchKernelGGL(spatial2_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
+    else hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

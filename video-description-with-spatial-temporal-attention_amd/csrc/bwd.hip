@@ -87,7 +87,7 @@ __global__ void alpha_reg_kernel(const float* __restrict__ alpha, float* __restr
 
 __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
     const int D = a.D, nd4 = D >> 2;
-    const size_t i4 = (size_t)blockIdx.x * 256 + threadIdx.x;          // one lane = 4 consecutive units of one row
+    const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;   // one lane = 4 consecutive units of one row
     if (i4 >= (size_t)a.M * nd4) return;
     const int b = (int)(i4 / nd4), d = 4 * (int)(i4 % nd4);
     const size_t idx = (size_t)b * D + d, MD = (size_t)a.M * D;
@@ -601,7 +601,10 @@ hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* 
     return hipGetLastError();
 }
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
-    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)(((size_t)a.M * (a.D / 4) + 255) / 256)), dim3(256), 0, s, a);
+    // small batches: one wave per workgroup so that M * D / 4 lanes spread over all CUs (64 x 1024: 256 workgroups)
+    const size_t n = (size_t)a.M * (a.D / 4);
+    const unsigned bs = n >= (size_t)256 * 1024 ? 256u : 64u;
+    hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {

@@ -98,6 +98,10 @@ struct stattn_handle {
     int ck_T = 0, ck_K = 0;
     double ck_fp = 0.0;
     bool ck_valid = false;
+    // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
+    // ~15 us); sn_m / sn_dp / sn_vid remember that the constant step inputs (video index, eval dropout) are in place
+    void* pin_io = nullptr; size_t pin_io_bytes = 0;
+    int sn_m = -1; const void* sn_dp = nullptr; const void* sn_vid = nullptr;
     uint64_t host_rng = 0x853c49e6748fea9bull;
     // batched beam search: staged raw features
     const void *bk_g = nullptr, *bk_l = nullptr, *bk_m = nullptr;
@@ -595,6 +599,7 @@ void stattn_destroy(stattn_handle* h) {
     for (auto& kv : h->bufs) kv.second.release();
     for (auto& e : h->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->pin_io) (void)hipHostFree(h->pin_io);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_grads) (void)hipFree(h->d_grads);
     if (h->d_rg2) (void)hipFree(h->d_rg2);
@@ -766,11 +771,22 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
     // --- step buffers
     int64_t *dx, *dargmax; int* vid;
     float *hp, *cp, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *ho, *co, *hd, *a1, *lg, *pr;
-    CHK(getbuf_t(h, "sn_x", (size_t)m, &dx));
+    // inputs {h | c | x} and outputs {h' | c' | probs} are each one device block mirrored by one pinned host block
+    const size_t in_floats = (size_t)2 * m * D + 2 * (size_t)m;                 // x: m int64 = 2m floats, 8-byte aligned
+    const size_t out_floats = (size_t)2 * m * D + (size_t)m * Vp;
+    float *d_in, *d_out;
+    CHK(getbuf_t(h, "sn_in", in_floats, &d_in));
+    CHK(getbuf_t(h, "sn_out", out_floats, &d_out));
+    hp = d_in; cp = d_in + (size_t)m * D; dx = reinterpret_cast<int64_t*>(d_in + (size_t)2 * m * D);
+    if ((in_floats + out_floats) * 4 > h->pin_io_bytes) {
+        if (h->pin_io) { (void)hipHostFree(h->pin_io); h->pin_io = nullptr; h->pin_io_bytes = 0; }
+        HIPCHK(h, hipHostMalloc(&h->pin_io, (in_floats + out_floats) * 4, hipHostMallocDefault));
+        h->pin_io_bytes = (in_floats + out_floats) * 4;
+    }
+    float* p_in = static_cast<float*>(h->pin_io);
+    float* p_out = p_in + in_floats;
     CHK(getbuf_t(h, "sn_argmax", (size_t)m, &dargmax));
     CHK(getbuf_t(h, "sn_vid", (size_t)m, &vid));
-    CHK(getbuf_t(h, "sn_hp", (size_t)m * D, &hp));
-    CHK(getbuf_t(h, "sn_cp", (size_t)m * D, &cp));
     CHK(getbuf_t(h, "sn_emb", (size_t)m * E, &emb));
     CHK(getbuf_t(h, "sn_sproj", (size_t)m * 4 * D, &sproj));
     CHK(getbuf_t(h, "sn_preh", (size_t)m * 4 * D, &preh));
@@ -785,18 +801,21 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
     CHK(getbuf_t(h, "sn_am", (size_t)m * T, &am));
     CHK(getbuf_t(h, "sn_alt", (size_t)m * T, &alt));
     CHK(getbuf_t(h, "sn_ctx", (size_t)m * D, &ctx));
-    CHK(getbuf_t(h, "sn_ho", (size_t)m * D, &ho));
-    CHK(getbuf_t(h, "sn_co", (size_t)m * D, &co));
+    ho = d_out; co = d_out + (size_t)m * D;
     CHK(getbuf_t(h, "sn_hd", (size_t)m * D, &hd));
     CHK(getbuf_t(h, "sn_a1", (size_t)m * E, &a1));
     CHK(getbuf_t(h, "sn_lg", (size_t)m * Vp, &lg));
-    CHK(getbuf_t(h, "sn_pr", (size_t)m * Vp, &pr));
+    pr = d_out + (size_t)2 * m * D;
 
-    HIPCHK(h, hipMemcpyAsync(dx, x, (size_t)m * sizeof(int64_t), hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(hp, h_in, (size_t)m * D * sizeof(float), hipMemcpyHostToDevice, s));
-    HIPCHK(h, hipMemcpyAsync(cp, c_in, (size_t)m * D * sizeof(float), hipMemcpyHostToDevice, s));
-    HIPCHK(h, launch_iota(s, vid, m, 0));                       // every hypothesis attends to video 0 (:786-788)
-    HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)m * 3 * D));     // sampler runs with use_noise = 0 (:469-472)
+    memcpy(p_in, h_in, (size_t)m * D * sizeof(float));
+    memcpy(p_in + (size_t)m * D, c_in, (size_t)m * D * sizeof(float));
+    memcpy(p_in + (size_t)2 * m * D, x, (size_t)m * sizeof(int64_t));
+    HIPCHK(h, hipMemcpyAsync(d_in, p_in, in_floats * 4, hipMemcpyHostToDevice, s));
+    if (h->sn_m != m || h->sn_dp != dp || h->sn_vid != vid) {   // constant across the calls of a decode loop
+        HIPCHK(h, launch_iota(s, vid, m, 0));                   // every hypothesis attends to video 0 (:786-788)
+        HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)m * 3 * D)); // sampler runs with use_noise = 0 (:469-472)
+        h->sn_m = m; h->sn_dp = dp; h->sn_vid = vid;
+    }
     HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, m, E, V, 0));    // :803-804
 
     StepIO io{};
@@ -829,15 +848,18 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
         HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, dargmax, m, V));   // :840
     }
 
-    if (out_probs) HIPCHK(h, hipMemcpy2DAsync(out_probs, (size_t)V * 4, pr, (size_t)Vp * 4, (size_t)V * 4, m, hipMemcpyDeviceToHost, s));
+    // {h' | c' | probs} in one transfer to pinned memory; rows of probs are unpadded on the way to the caller
+    HIPCHK(h, hipMemcpyAsync(p_out, d_out, (out_probs ? out_floats : (size_t)2 * m * D) * 4, hipMemcpyDeviceToHost, s));
     if (out_logits) HIPCHK(h, hipMemcpy2DAsync(out_logits, (size_t)V * 4, lg, (size_t)Vp * 4, (size_t)V * 4, m, hipMemcpyDeviceToHost, s));
-    if (out_h) HIPCHK(h, hipMemcpyAsync(out_h, ho, (size_t)m * D * 4, hipMemcpyDeviceToHost, s));
-    if (out_c) HIPCHK(h, hipMemcpyAsync(out_c, co, (size_t)m * D * 4, hipMemcpyDeviceToHost, s));
     if (out_alphal) HIPCHK(h, hipMemcpyAsync(out_alphal, al, (size_t)m * T * K * 4, hipMemcpyDeviceToHost, s));
     if (out_alphag) HIPCHK(h, hipMemcpyAsync(out_alphag, ag, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
     if (out_alpham) HIPCHK(h, hipMemcpyAsync(out_alpham, am, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
     if (out_alphalt) HIPCHK(h, hipMemcpyAsync(out_alphalt, alt, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    if (out_h) memcpy(out_h, p_out, (size_t)m * D * 4);
+    if (out_c) memcpy(out_c, p_out + (size_t)m * D, (size_t)m * D * 4);
+    if (out_probs)
+        for (int r = 0; r < m; ++r) memcpy(out_probs + (size_t)r * V, p_out + (size_t)2 * m * D + (size_t)r * Vp, (size_t)V * 4);
 
     if (out_sample) {
         // next_sample = multinomial(next_probs).argmax(1) (:841): inverse-CDF draw with the library's own
@@ -848,7 +870,14 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
                 const double u = (double)(h->host_rng >> 11) * (1.0 / 9007199254740992.0);
                 double acc = 0.0; int64_t pick = V - 1;
                 const float* p = out_probs + (size_t)r * V;
-                for (int j = 0; j < V; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
+                int j = 0;
+                for (; j + 64 <= V; j += 64) {          // whole chunks first (the inner sum vectorises), then the hit chunk
+                    float cs = 0.f;
+                    for (int q = 0; q < 64; ++q) cs += p[j + q];
+                    if (u < acc + (double)cs) break;
+                    acc += (double)cs;
+                }
+                for (; j < V; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
                 out_sample[r] = pick;
             }
         } else {

@@ -384,9 +384,9 @@ def main():
     if args.config == "c2" and dec.lt_mode == 1 and not bf16:
         # HBM-side bytes per launch from rocprofv3 PMC passes of this very command (collected offline, separate
         # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_c_pmc_*.csv
-        roofline["traffic"] = 393.3e6          # mean over the 10 NN launches: 361.3 MB fetched + 32.0 MB written
-        roofline_hbm["traffic"] = 193.1e6      # 186.1 MB fetched + 7.0 MB written (algorithmic: 184.0 MB)
-        roofline["traffic_source"] = roofline_hbm["traffic_source"] = "rocprofv3 --pmc, profiles/r01_c_pmc_forward_*.csv"
+        roofline["traffic"] = 435.5e6          # mean over the 10 NN launches: 403.6 MB fetched + 32.0 MB written
+        roofline_hbm["traffic"] = 193.0e6      # 186.0 MB fetched + 7.0 MB written (algorithmic: 184.0 MB)
+        roofline["traffic_source"] = roofline_hbm["traffic_source"] = "rocprofv3 --pmc, profiles/r01_g_pmc_forward_*.csv"
     if args.kernel_breakdown and rank == 0:
         print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)
 

@@ -941,6 +941,9 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     CHK(getbuf_t(h, "bs_fin_score", (size_t)M, &fin_score));
     CHK(getbuf_t(h, "bs_score0", (size_t)M, &score[0])); CHK(getbuf_t(h, "bs_score1", (size_t)M, &score[1]));
     CHK(getbuf_t(h, "bs_next_w", (size_t)M, &next_w));
+    float* tk_cost; int* tk_idx;
+    CHK(getbuf_t(h, "bs_tk_cost", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_cost));
+    CHK(getbuf_t(h, "bs_tk_idx", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_idx));
     CHK(getbuf_t(h, "bs_hp", (size_t)M * D, &hp)); CHK(getbuf_t(h, "bs_cp", (size_t)M * D, &cp));
     CHK(getbuf_t(h, "bs_ho", (size_t)M * D, &ho)); CHK(getbuf_t(h, "bs_co", (size_t)M * D, &co));
     CHK(getbuf_t(h, "bs_hd", (size_t)M * D, &hd)); CHK(getbuf_t(h, "bs_emb", (size_t)M * E, &emb));
@@ -1010,7 +1013,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.tok_in = tok[st & 1]; ba.tok_out = tok[(st & 1) ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
-        HIPCHK(h, launch_beam_topk(s, ba));
+        HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         HIPCHK(h, launch_beam_update(s, ba));
         steps_run = st + 1;
         if (!suppress_eos && (st & 7) == 7 && st + 1 < L0) {       // early exit once every video has finished

@@ -5,7 +5,7 @@
 // list surgery (model_attention.py:921-985) -- ~0.5 ms of numpy per word at k = 5, V = 12k, more than
 // the whole decoder step on the GPU.  Here the same bookkeeping runs on the device for many videos at
 // once (one workgroup per video), so a decode step is a fixed kernel sequence with no host round trip:
-//   beam_topk_kernel    the (k - dead_k) smallest candidate costs of a video           (:921-928)
+//   beam_topk_part/merge the (k - dead_k) smallest candidate costs of a video: per vocabulary slice, then merged (:921-928)
 //   beam_update_kernel  new hypotheses, finished ones (word 0) retired, h/c gathered    (:939-985)
 #include "kernels.h"
 #include "devmath.h"
@@ -16,63 +16,112 @@ namespace {
 
 constexpr int KB = 8;   // maximum beam width
 
-__global__ __launch_bounds__(256) void beam_topk_kernel(const BeamArgs a) {
-    __shared__ float s_cost[4];
-    __shared__ int s_idx[4];
-    __shared__ int s_owner[4];
-    const int v = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int k = a.k, V = a.V;
-    const int live = a.live_k[v], dead = a.dead_k[v];
-    const int n = live > 0 ? k - dead : 0;                    // how many candidates survive (:923)
-    if (tid == 0) a.nsel[v] = n;
-    if (n <= 0) return;
-    // thread-local sorted list of its KB best (cost ascending; ties: lower flat index first)
-    float lc[KB]; int li[KB];
-#pragma unroll
-    for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
-    for (int j = 0; j < live; ++j) {
-        const float hs = a.hyp_score[v * k + j];
-        const float* __restrict__ p = a.probs + (size_t)(v * k + j) * a.ldp;
-        for (int wd = tid; wd < V; wd += 256) {
-            float pr = p[wd];
-            if (a.suppress_eos && wd == 0) pr = 0.f;
-            const float c = hs - logf(pr);                    // hyp_scores[:,None] - log(next_p)  (:921), float32
-            const int flat = j * V + wd;
-            if (c < lc[KB - 1] || (c == lc[KB - 1] && flat < li[KB - 1])) {
-                lc[KB - 1] = c; li[KB - 1] = flat;
-#pragma unroll
-                for (int i = KB - 1; i > 0; --i) {            // one bubble pass keeps the list sorted
-                    const bool sw = lc[i] < lc[i - 1] || (lc[i] == lc[i - 1] && li[i] < li[i - 1]);
-                    if (sw) { const float tc = lc[i]; lc[i] = lc[i - 1]; lc[i - 1] = tc; const int ti = li[i]; li[i] = li[i - 1]; li[i - 1] = ti; }
-                }
-            }
-        }
-    }
-    // n rounds of a workgroup-wide arg-min over the list heads; the winner pops its head
+// ordering of candidates: cost ascending, ties by the lower flat index (what a stable argsort of the flat cost
+// array yields, :921-923)
+__device__ __forceinline__ bool cand_less(float c0, int i0, float c1, int i1) { return c0 < c1 || (c0 == c1 && i0 < i1); }
+
+// n rounds of a workgroup-wide arg-min over per-thread sorted lists (lc/li ascending, KB long): round r's winner is
+// reported through res_c/res_i[r] (thread 0) and popped from its owner's list
+__device__ __forceinline__ void block_select(float (&lc)[KB], int (&li)[KB], int n, float* s_cost, int* s_idx, int* s_owner,
+                                             float* res_c, int* res_i) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     for (int r = 0; r < n; ++r) {
         float c = lc[0]; int idx = li[0]; int owner = tid;
 #pragma unroll
         for (int o = 32; o > 0; o >>= 1) {
             const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
-            if (oc < c || (oc == c && oi < idx)) { c = oc; idx = oi; owner = oo; }
+            if (cand_less(oc, oi, c, idx)) { c = oc; idx = oi; owner = oo; }
         }
         if (lane == 0) { s_cost[w] = c; s_idx[w] = idx; s_owner[w] = owner; }
         __syncthreads();
         c = s_cost[0]; idx = s_idx[0]; owner = s_owner[0];
 #pragma unroll
         for (int i = 1; i < 4; ++i)
-            if (s_cost[i] < c || (s_cost[i] == c && s_idx[i] < idx)) { c = s_cost[i]; idx = s_idx[i]; owner = s_owner[i]; }
-        if (tid == 0) {
-            a.sel_cost[v * k + r] = c;
-            a.sel_ti[v * k + r] = idx / V;                    // trans_indices = ranks_flat // voc_size (:926)
-            a.sel_wi[v * k + r] = idx % V;                    // word_indices  = ranks_flat %  voc_size (:927)
-        }
+            if (cand_less(s_cost[i], s_idx[i], c, idx)) { c = s_cost[i]; idx = s_idx[i]; owner = s_owner[i]; }
+        if (tid == 0) { res_c[r] = c; res_i[r] = idx; }
         if (tid == owner) {
 #pragma unroll
             for (int i = 0; i < KB - 1; ++i) { lc[i] = lc[i + 1]; li[i] = li[i + 1]; }
             lc[KB - 1] = INFINITY; li[KB - 1] = 0x7fffffff;
         }
         __syncthreads();
+    }
+}
+
+__device__ __forceinline__ void list_insert(float (&lc)[KB], int (&li)[KB], float c, int flat) {
+    if (cand_less(c, flat, lc[KB - 1], li[KB - 1])) {
+        lc[KB - 1] = c; li[KB - 1] = flat;
+#pragma unroll
+        for (int i = KB - 1; i > 0; --i) {            // one bubble pass keeps the list sorted
+            const bool sw = cand_less(lc[i], li[i], lc[i - 1], li[i - 1]);
+            if (sw) { const float tc = lc[i]; lc[i] = lc[i - 1]; lc[i - 1] = tc; const int ti = li[i]; li[i] = li[i - 1]; li[i - 1] = ti; }
+        }
+    }
+}
+
+// Stage 1: workgroup (video v, slice sp) finds the n best candidates among the words of its slice, for all live
+// hypotheses of the video.  One workgroup per video walked its 60 k candidates as a chain of dependent loads
+// (243 us per word at k = 5, V = 12 k -- two thirds of the whole decode step); slices cut that to a few loads per
+// thread.  Any member of the global top n is in the top n of its slice, so stage 2 sees every winner.
+__global__ __launch_bounds__(256) void beam_topk_part_kernel(const BeamArgs a, int nsplit, float* __restrict__ pcost,
+                                                             int* __restrict__ pidx) {
+    __shared__ float s_cost[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_owner[4];
+    __shared__ float res_c[KB];
+    __shared__ int res_i[KB];
+    const int v = blockIdx.x, sp = blockIdx.y, tid = threadIdx.x;
+    const int k = a.k, V = a.V;
+    const int live = a.live_k[v], dead = a.dead_k[v];
+    const int n = live > 0 ? k - dead : 0;                    // how many candidates survive (:923)
+    float* oc = pcost + ((size_t)v * nsplit + sp) * KB;
+    int* oi = pidx + ((size_t)v * nsplit + sp) * KB;
+    if (tid < KB) { res_c[tid] = INFINITY; res_i[tid] = 0x7fffffff; }
+    __syncthreads();
+    if (n > 0) {
+        const int chunk = ((V + nsplit - 1) / nsplit + 3) & ~3;
+        const int w0 = sp * chunk, w1 = min(V, w0 + chunk);
+        float lc[KB]; int li[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+        for (int j = 0; j < live; ++j) {
+            const float hs = a.hyp_score[v * k + j];
+            const float* __restrict__ p = a.probs + (size_t)(v * k + j) * a.ldp;
+            for (int wd = w0 + tid; wd < w1; wd += 256) {
+                float pr = p[wd];
+                if (a.suppress_eos && wd == 0) pr = 0.f;
+                list_insert(lc, li, hs - logf(pr), j * V + wd);   // hyp_scores[:,None] - log(next_p)  (:921), float32
+            }
+        }
+        block_select(lc, li, n, s_cost, s_idx, s_owner, res_c, res_i);
+    }
+    if (tid < KB) { oc[tid] = res_c[tid]; oi[tid] = res_i[tid]; }
+}
+
+// Stage 2: one workgroup per video merges the nsplit * KB slice winners (<= 256) and writes the selection
+__global__ __launch_bounds__(256) void beam_topk_merge_kernel(const BeamArgs a, int nsplit, const float* __restrict__ pcost,
+                                                              const int* __restrict__ pidx) {
+    __shared__ float s_cost[4];
+    __shared__ int s_idx[4];
+    __shared__ int s_owner[4];
+    __shared__ float res_c[KB];
+    __shared__ int res_i[KB];
+    const int v = blockIdx.x, tid = threadIdx.x;
+    const int k = a.k, V = a.V;
+    const int live = a.live_k[v], dead = a.dead_k[v];
+    const int n = live > 0 ? k - dead : 0;
+    if (tid == 0) a.nsel[v] = n;
+    if (n <= 0) return;
+    float lc[KB]; int li[KB];
+#pragma unroll
+    for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+    if (tid < nsplit * KB) { lc[0] = pcost[(size_t)v * nsplit * KB + tid]; li[0] = pidx[(size_t)v * nsplit * KB + tid]; }
+    block_select(lc, li, n, s_cost, s_idx, s_owner, res_c, res_i);
+    if (tid < n) {
+        const int idx = res_i[tid];
+        a.sel_cost[v * k + tid] = res_c[tid];
+        a.sel_ti[v * k + tid] = idx / V;                      // trans_indices = ranks_flat // voc_size (:926)
+        a.sel_wi[v * k + tid] = idx % V;                      // word_indices  = ranks_flat %  voc_size (:927)
     }
 }
 
@@ -125,9 +174,17 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
 
 }  // namespace
 
-hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a) {
+int beam_topk_splits(int nvid) {          // slices of the vocabulary per video: ~512 workgroups in all, <= 256 / KB
+    int ns = 512 / (nvid > 0 ? nvid : 1);
+    if (ns > 256 / KB) ns = 256 / KB;
+    if (ns < 1) ns = 1;
+    return ns;
+}
+hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx) {
     if (a.k > KB || a.k < 1) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_topk_kernel, dim3(a.nvid), dim3(256), 0, s, a);
+    const int ns = beam_topk_splits(a.nvid);
+    hipLaunchKernelGGL(beam_topk_part_kernel, dim3(a.nvid, ns), dim3(256), 0, s, a, ns, part_cost, part_idx);
+    hipLaunchKernelGGL(beam_topk_merge_kernel, dim3(a.nvid), dim3(256), 0, s, a, ns, part_cost, part_idx);
     return hipGetLastError();
 }
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a) {

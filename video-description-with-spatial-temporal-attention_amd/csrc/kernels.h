@@ -283,7 +283,9 @@ struct BeamArgs {
     const float* h_step; const float* c_step;       // [nvid*k, D] state after this step
     float* h_next; float* c_next;       // [nvid*k, D] state gathered for the next step
 };
-hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a);
+int beam_topk_splits(int nvid);
+// part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch
+hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx);
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);
 
 }  // namespace stattn

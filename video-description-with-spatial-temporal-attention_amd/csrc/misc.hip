@@ -87,6 +87,59 @@ __global__ __launch_bounds__(256) void softmax_nll_kernel(const float* __restric
     }
 }
 
+// Same, with the row held in registers (one pass over the logits instead of three dependent ones) when
+// V <= NT * MAXV: 256 threads x 48 values for the (t*m)-row training softmax, 1024 threads x 16 for the few rows of a
+// decode step, where the kernel is a chain of load latencies rather than bandwidth.
+template <int NT, int MAXV>
+__global__ __launch_bounds__(NT) void softmax_nll_reg_kernel(const float* __restrict__ logits, int ldl,
+                                                             float* __restrict__ probs, int ldp,
+                                                             const int64_t* __restrict__ x, float* __restrict__ nll,
+                                                             int64_t* __restrict__ argmax, int V) {
+    constexpr int NW = NT / 64;
+    __shared__ float s_f[NW];
+    __shared__ int s_i[NW];
+    const int r = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const float* __restrict__ lg = logits + (size_t)r * ldl;
+    float v[MAXV];
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { const int j = tid + i * NT; v[i] = j < V ? lg[j] : -INFINITY; }
+    float mx = -INFINITY; int mi = 0;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) if (v[i] > mx) { mx = v[i]; mi = tid + i * NT; }     // ascending j: first maximum wins
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const float ov = __shfl_xor(mx, o, 64); const int oi = __shfl_xor(mi, o, 64);
+        if (ov > mx || (ov == mx && oi < mi)) { mx = ov; mi = oi; }
+    }
+    if (lane == 0) { s_f[w] = mx; s_i[w] = mi; }
+    __syncthreads();
+    mx = s_f[0]; mi = s_i[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) if (s_f[i] > mx || (s_f[i] == mx && s_i[i] < mi)) { mx = s_f[i]; mi = s_i[i]; }
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { v[i] = __expf(v[i] - mx); sum += v[i]; }            // exp(-inf) = 0 for the padding
+    sum = wave_sum(sum);
+    if (lane == 0) s_f[w] = sum;
+    __syncthreads();
+    sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NW; ++i) sum += s_f[i];
+    const float inv = 1.0f / sum;
+    float* __restrict__ pr = probs + (size_t)r * ldp;
+#pragma unroll
+    for (int i = 0; i < MAXV; ++i) { const int j = tid + i * NT; if (j < V) pr[j] = v[i] * inv; }
+    if (tid == 0) {
+        if (argmax) argmax[r] = mi;
+        if (nll) {
+            int64_t xi = x[r];
+            xi = xi < 0 ? 0 : (xi >= V ? V - 1 : xi);
+            nll[r] = -logf(__expf(lg[xi] - mx) * inv + 1e-8f);
+        }
+    }
+}
+
 // cost[b] = sum_t mask[t,b] * nll[t,b]     (:714-715)
 __global__ void cost_kernel(const float* __restrict__ nll, const float* __restrict__ mask,
                             float* __restrict__ cost, int t, int m) {
@@ -148,7 +201,12 @@ hipError_t launch_embed(hipStream_t s, const int64_t* x, const float* Wemb, floa
 hipError_t launch_softmax_nll(hipStream_t s, const float* logits, int ldl, float* probs, int ldp,
                               const int64_t* x, float* nll, int64_t* argmax, int rows, int V) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(softmax_nll_kernel, dim3(rows), dim3(256), 0, s, logits, ldl, probs, ldp, x, nll, argmax, V);
+    if (rows <= 256 && V <= 1024 * 16)
+        hipLaunchKernelGGL((softmax_nll_reg_kernel<1024, 16>), dim3(rows), dim3(1024), 0, s, logits, ldl, probs, ldp, x, nll, argmax, V);
+    else if (V <= 256 * 48)
+        hipLaunchKernelGGL((softmax_nll_reg_kernel<256, 48>), dim3(rows), dim3(256), 0, s, logits, ldl, probs, ldp, x, nll, argmax, V);
+    else
+        hipLaunchKernelGGL(softmax_nll_kernel, dim3(rows), dim3(256), 0, s, logits, ldl, probs, ldp, x, nll, argmax, V);
     return hipGetLastError();
 }
 hipError_t launch_cost(hipStream_t s, const float* nll, const float* mask, float* cost, int t, int m) {

@@ -194,6 +194,9 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
  * average milliseconds per launch measured with HIP events on the handle's stream. */
 int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K,
                          int iters, float* ms_per_launch);
+/* Debug counters.  which = 0: hipGraph replays (two decoded words each) in the last stattn_beam_search
+ * -- 0 means the word sequence was launched eagerly (capture refused, profiling on, STATTN_BEAM_NOGRAPH). */
+long stattn_dbg_counter(const stattn_handle* h, int which);
 /* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
  * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,
  * 11 / 21 / 22 = workgroup tile (64*TM) x (64*TN) -- the LDS tile size sweep of BASELINE configs[3]. */

@@ -386,6 +386,8 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
     b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=70)
     res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
     assert len(res) == nvid
+    # the per-word kernel sequence ran as hipGraph replays (two words per replay), not as eager launches
+    assert 0 < tparams.decoder.beam_graph_replays() <= (maxlen + 1) // 2
     n_eos = 0
     for v in range(nvid):
         args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   _F, _F, _F, _F, C.c_int, _F]),
     "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "stattn_dbg_counter": (C.c_long, [_H, C.c_int]),
     "stattn_dbg_time_gemm_bf16": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_time_skinny": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_set_profiling": (C.c_int, [_H, C.c_int]),
@@ -437,6 +438,10 @@ class Decoder(object):
         ms = C.c_float()
         self._chk(self._lib.stattn_dbg_time_gemm(self._h, int(transA), int(transB), M, N, K, iters, C.byref(ms)))
         return ms.value
+
+    def beam_graph_replays(self):
+        """hipGraph replays (two words each) in the last beam_search; 0 = the kernels were launched eagerly."""
+        return int(self._lib.stattn_dbg_counter(self._h, 0))
 
     def time_gemm_bf16(self, M, N, K, tile=0, iters=20):
         ms = C.c_float()

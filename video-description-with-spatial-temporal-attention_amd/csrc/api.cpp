@@ -8,6 +8,7 @@
 
 #include <cmath>
 #include <cstdarg>
+#include <cstdint>
 #include <cstdio>
 #include <cstring>
 #include <map>
@@ -97,6 +98,10 @@ struct stattn_handle {
     const void *ck_g = nullptr, *ck_l = nullptr, *ck_m = nullptr;
     int ck_T = 0, ck_K = 0;
     double ck_fp = 0.0;
+    // beam search: the captured two-word graph is kept while every pointer and shape it baked in is unchanged
+    hipGraphExec_t beam_gexec = nullptr;
+    std::vector<uintptr_t> beam_gsig;
+    long beam_graph_replays = 0;        // replays in the last stattn_beam_search (0 = eager launches)
     bool ck_valid = false;
     // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
     // ~15 us); sn_m / sn_dp / sn_vid remember that the constant step inputs (video index, eval dropout) are in place
@@ -599,6 +604,7 @@ void stattn_destroy(stattn_handle* h) {
     for (auto& kv : h->bufs) kv.second.release();
     for (auto& e : h->ev_used) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : h->ev_pool) (void)hipEventDestroy(e);
+    if (h->beam_gexec) (void)hipGraphExecDestroy(h->beam_gexec);
     if (h->pin_io) (void)hipHostFree(h->pin_io);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_grads) (void)hipFree(h->d_grads);
@@ -941,6 +947,8 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     CHK(getbuf_t(h, "bs_fin_score", (size_t)M, &fin_score));
     CHK(getbuf_t(h, "bs_score0", (size_t)M, &score[0])); CHK(getbuf_t(h, "bs_score1", (size_t)M, &score[1]));
     CHK(getbuf_t(h, "bs_next_w", (size_t)M, &next_w));
+    int* d_step;
+    CHK(getbuf_t(h, "bs_step", (size_t)1, &d_step));
     float* tk_cost; int* tk_idx;
     CHK(getbuf_t(h, "bs_tk_cost", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_cost));
     CHK(getbuf_t(h, "bs_tk_idx", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_idx));
@@ -974,8 +982,9 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     HIPCHK(h, hipMemcpy2DAsync(cp, (size_t)k * D * 4, c0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)M * 3 * D));
 
-    int steps_run = 0;
-    for (int st = 0; st < L0; ++st) {
+    // one decoded word = a fixed sequence of 15 kernel launches whose arguments depend on the word index only through
+    // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
+    auto enqueue_word = [&](int parity) -> int {
         HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0));
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid;
@@ -1006,25 +1015,77 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
             HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
         }
         BeamArgs ba{};
-        ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = st;
+        ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = d_step;
         ba.suppress_eos = suppress_eos;
-        ba.live_k = live_k; ba.dead_k = dead_k; ba.hyp_score = score[st & 1]; ba.hyp_score_out = score[(st & 1) ^ 1];
+        ba.live_k = live_k; ba.dead_k = dead_k; ba.hyp_score = score[parity]; ba.hyp_score_out = score[parity ^ 1];
         ba.nsel = nsel; ba.sel_ti = sel_ti; ba.sel_wi = sel_wi; ba.sel_cost = sel_cost;
-        ba.tok_in = tok[st & 1]; ba.tok_out = tok[(st & 1) ^ 1];
+        ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
         HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         HIPCHK(h, launch_beam_update(s, ba));
-        steps_run = st + 1;
-        if (!suppress_eos && (st & 7) == 7 && st + 1 < L0) {       // early exit once every video has finished
+        return STATTN_OK;
+    };
+    HIPCHK(h, hipMemsetAsync(d_step, 0, sizeof(int), s));
+
+    // The launch-bound inner loop is captured once as a hipGraph of TWO words (even + odd parity) and replayed; the
+    // host only comes back every 8 words to see whether every video has finished.  Falls back to eager launches if
+    // the capture is refused (or STATTN_BEAM_NOGRAPH is set, for A/B runs).
+    hipGraphExec_t gexec = nullptr;
+    static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
+    h->beam_graph_replays = 0;
+    // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos,
+                                  (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
+    for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
+                          (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k, (const void*)nsel,
+                          (const void*)sel_ti, (const void*)sel_wi, (const void*)sel_cost, (const void*)tok[0], (const void*)tok[1],
+                          (const void*)fin_tok, (const void*)fin_len, (const void*)fin_score, (const void*)score[0],
+                          (const void*)score[1], (const void*)next_w, (const void*)hp, (const void*)cp, (const void*)ho,
+                          (const void*)co, (const void*)hd, (const void*)emb, (const void*)sproj, (const void*)preh, (const void*)dp,
+                          (const void*)al, (const void*)CL, (const void*)eg, (const void*)em, (const void*)elt, (const void*)plt,
+                          (const void*)ag, (const void*)am, (const void*)alt, (const void*)ctx, (const void*)a1, (const void*)lg,
+                          (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx})
+        sig.push_back((uintptr_t)q);
+    if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
+        gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is
+    } else if (!nograph && !h->profiling && L0 >= 2) {
+        if (h->beam_gexec) { (void)hipGraphExecDestroy(h->beam_gexec); h->beam_gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int r0 = enqueue_word(0), r1 = r0 == STATTN_OK ? enqueue_word(1) : r0;
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            ok = r0 == STATTN_OK && r1 == STATTN_OK && e == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) { gexec = nullptr; (void)hipGetLastError(); }
+        else { h->beam_gexec = gexec; h->beam_gsig = sig; }
+    }
+    int steps_run = 0;
+    int rc_loop = STATTN_OK;
+    for (int st = 0; st < L0;) {
+        if (gexec && st + 2 <= L0) {
+            if (hipGraphLaunch(gexec, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
+            st += 2;
+            ++h->beam_graph_replays;
+        } else {
+            rc_loop = enqueue_word(st & 1);
+            if (rc_loop != STATTN_OK) break;
+            st += 1;
+        }
+        steps_run = st;
+        if (!suppress_eos && (st & 7) == 0 && st < L0) {           // early exit once every video has finished
             std::vector<int> lv(nvid);
-            HIPCHK(h, hipMemcpyAsync(lv.data(), live_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
-            HIPCHK(h, hipStreamSynchronize(s));
+            if (hipMemcpyAsync(lv.data(), live_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: live-count readback failed"); break; }
             bool any = false;
             for (int x : lv) any = any || x > 0;
             if (!any) break;
         }
     }
+    if (rc_loop != STATTN_OK) return rc_loop;
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
         std::vector<int> lv(nvid), dv(nvid), ftok((size_t)M * L0), flen(M), ltok((size_t)M * L0);
@@ -1766,6 +1827,12 @@ int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, i
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *ms_per_launch = ms / iters;
     return STATTN_OK;
+}
+
+long stattn_dbg_counter(const stattn_handle* h, int which) {
+    if (!h) return -1;
+    if (which == 0) return h->beam_graph_replays;
+    return -1;
 }
 
 int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters, float* ms_per_launch) {

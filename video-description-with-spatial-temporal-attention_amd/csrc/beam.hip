@@ -129,7 +129,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
     __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
     __shared__ int s_n;
     const int v = blockIdx.x, tid = threadIdx.x;
-    const int k = a.k, D = a.D, L = a.maxlen, step = a.step;
+    const int k = a.k, D = a.D, L = a.maxlen, step = *a.step;
     if (tid == 0) {
         const int n = a.nsel[v];
         int dead = a.dead_k[v], nl = 0;
@@ -187,8 +187,12 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
     hipLaunchKernelGGL(beam_topk_merge_kernel, dim3(a.nvid), dim3(256), 0, s, a, ns, part_cost, part_idx);
     return hipGetLastError();
 }
+__global__ void beam_step_inc_kernel(int* step) { *step += 1; }
+
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a) {
     hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a);
+    // every workgroup of the update reads *step at its start: the increment is its own (stream-ordered) launch
+    hipLaunchKernelGGL(beam_step_inc_kernel, dim3(1), dim3(1), 0, s, a.step);
     return hipGetLastError();
 }
 

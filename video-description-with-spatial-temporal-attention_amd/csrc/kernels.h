@@ -273,7 +273,8 @@ hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, 
 // ----------------------------------------------------------------------------
 struct BeamArgs {
     const float* probs; int ldp;        // [nvid*k, ldp] next-word probabilities of this step
-    int V, k, D, maxlen, nvid, step, suppress_eos;
+    int V, k, D, maxlen, nvid, suppress_eos;
+    int* step;                          // device counter: index of the word being decoded (so a captured graph replays unchanged)
     int* live_k; int* dead_k;           // [nvid]
     const float* hyp_score; float* hyp_score_out;   // [nvid*k] scores of the live hypotheses (in / out)
     int* nsel; int* sel_ti; int* sel_wi; float* sel_cost;   // [nvid], [nvid*k] x3
@@ -286,6 +287,6 @@ struct BeamArgs {
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch
 hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx);
-hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);   // also advances *a.step (a trailing one-thread kernel)
 
 }  // namespace stattn

@@ -54,3 +54,37 @@ def test_shapes_beyond_the_kernel_limits_are_refused():
         with pytest.raises((ValueError, stattn.NativeError)):
             dec.set_batch(**batch)
             dec.forward_train()
+
+
+def test_large_odd_vocabulary_takes_the_multi_pass_softmax():
+    """V = 20011 (> 256 x 48 register-resident values, not a multiple of anything): logits, probabilities, cost, the
+    sampler's probabilities and the device beam search against the oracle."""
+    import stattn
+    from oracle import stattn_oracle as O
+    dims = dict(DIMS, n_words=20011)
+    opt = O.default_options(**dims)
+    P = O.random_params(opt, seed=77, dtype=np.float32)
+    P64 = O.cast_params(P, np.float64)
+    dec = stattn.Decoder(opt)
+    dec.set_params(P)
+    batch = O.synthetic_batch(opt, B=300, T=3, K=2, t=2, seed=9)          # 600 rows: the 256-thread softmax variants
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    b64 = {k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()}
+    ref = O.build_model_forward(P64, opt, **b64)
+    assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < 1e-4
+    assert np.abs(out['probs'] - ref['probs']).max() < 1e-5
+    np.testing.assert_allclose(out['probs'].sum(-1), 1.0, atol=1e-4)
+    np.testing.assert_allclose(out['cost'], ref['cost'], rtol=1e-4, atol=1e-4)
+    model = stattn.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    v = 0
+    args = (batch['ctxg'][v], batch['mask_ctxg'][v], batch['ctxl'][v], batch['mask_ctxl'][v], batch['ctxm'][v], batch['mask_ctxm'][v])
+    s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 3, maxlen=5)
+    res = model.gen_sample_batch(tparams, opt, batch['ctxg'][:2], batch['mask_ctxg'][:2], batch['ctxl'][:2], batch['ctxm'][:2], k=3, maxlen=5)
+    assert res[0][0] == s
+    a64 = tuple(np.asarray(a, np.float64) for a in args)
+    sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=3, maxlen=5)
+    assert s[int(np.argmin(sc))] == sr[int(np.argmin(scr))]

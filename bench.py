@@ -173,7 +173,7 @@ def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
     rowsteps = nsteps[0] * world
     out = dict(metric="decoder steps/sec (batch x timestep)", value=rowsteps / dt, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               scaling="weak", vs_baseline=None, dtype="bf16" if args.precision == "bf16" else "f32", data="synthetic",
                config=dict(workload="%s decode: gen_sample(k=%d, maxlen=%d, <eos> suppressed) over %d videos per GPU through "
                                     "f_init/f_next with host arrays per call, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
                                     % (args.config, args.beam, t, c["B"], c["T"], c["K"], c["F"], c["D"], c["E"], V, dec.lt_mode),
@@ -235,7 +235,7 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
     rowsteps = c["B"] * (1 + k * (t - 1)) * args.steps * world
     out = dict(metric="decoder steps/sec (batch x timestep)", value=rowsteps / dt, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="f32", data="synthetic",
+               scaling="weak", vs_baseline=None, dtype="bf16" if args.precision == "bf16" else "f32", data="synthetic",
                config=dict(workload="%s beam: batched device-side beam search, %d videos x beam %d, maxlen %d, <eos> suppressed, "
                                     "T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
                                     % (args.config, c["B"], k, t, c["T"], c["K"], c["F"], c["D"], c["E"], c["V"], dec.lt_mode),

@@ -199,7 +199,8 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
 long stattn_dbg_counter(const stattn_handle* h, int which);
 /* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
  * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,
- * 11 / 21 / 22 = workgroup tile (64*TM) x (64*TN) -- the LDS tile size sweep of BASELINE configs[3]. */
+ * 11 / 21 / 22 = register-staged workgroup tile (64*TM) x (64*TN), 84 = 256 x 128 with direct global->LDS
+ * staging (edge-free shapes only) -- the LDS tile size sweep of BASELINE configs[3]. */
 int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch);
 /* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
  * 1 / 2 / 4 = ablations (loads only / MFMAs only / no reduction), see tools/skinny_probe.py. */

@@ -184,6 +184,148 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Direct global -> LDS variant (global_load_lds_dwordx4) for the large projections: 256 x 128 x 64 tile, 8 waves as
+// 4 x 2 (each still a 64 x 64 sub-tile), THREE LDS stages, loads two tiles ahead, no staging registers, no ds_write.
+//   * The DMA writes LDS linearly (wave-uniform base + lane * 16 B), so rows are unpadded 128 B = 8 chunks of 16 B
+//     and chunk c of row r lives at chunk c ^ ((r >> 1) & 7): the swizzle goes into the per-lane GLOBAL address and
+//     into the fragment read, and the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots.
+//   * The DMA is issued from inline asm: with the builtin, hipcc's wait-count pass puts vmcnt(0) in front of the next
+//     ds_read while a DMA is in flight; waits are explicit (vmcnt(6) = the six loads of the newest tile may still fly).
+//   * Only for shapes without edges: M % 256 == 0, N % 128 == 0, K % 64 == 0 (the DMA cannot zero-fill).
+#pragma clang diagnostic push
+#pragma clang diagnostic ignored "-Winline-asm"     // m0 is clobbered on purpose: it carries the LDS destination of the DMA
+__device__ __forceinline__ void glds16(const void* gptr, unsigned lds_byte_addr) {
+    asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" :: "v"(gptr), "s"(lds_byte_addr) : "memory", "m0");
+}
+#pragma clang diagnostic pop
+__device__ __forceinline__ bf16x8 frag_swz(const uint16_t* s, int row, int kk, int kh) {
+    return *reinterpret_cast<const bf16x8*>(s + row * BKB + 8 * ((2 * kk + kh) ^ ((row >> 1) & 7)));
+}
+
+__global__ __launch_bounds__(512, 1) void gemm_bf16_glds_kernel(const GemmBfArgs g) {
+    constexpr int BM = 256, BN = 128, NST = 3;
+    constexpr int A_ELEMS = BM * BKB, B_ELEMS = BN * BKB, STAGE = A_ELEMS + B_ELEMS;      // bf16 elements
+    __shared__ __attribute__((aligned(16))) uint16_t smem[NST * STAGE];                   // 3 x 48 KiB
+    const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) uint16_t*)smem;
+
+    const int tiles_n = g.N / BN;
+    const int nblk = gridDim.x, bid = blockIdx.x;
+    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
+    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
+    const int m0 = (lin / tiles_n) * BM;
+    const int n0 = (lin % tiles_n) * BN;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;                     // 4 x 2 waves, 64 x 64 each
+    const int l31 = lane & 31, kh = lane >> 5;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // per-lane source addresses of k-tile 0: A = 2048 chunks (4 per thread), B = 1024 (2 per thread); chunk idx lands at
+    // LDS byte idx * 16 of its tile, so the global side reads logical chunk (idx & 7) ^ ((row >> 1) & 7) of row idx >> 3
+    const uint16_t* pa[4];
+    const uint16_t* pb[2];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int idx = tid + i * 512, rr = idx >> 3, lc = (idx & 7) ^ ((rr >> 1) & 7);
+        pa[i] = g.A + (size_t)(m0 + rr) * g.lda + 8 * lc;
+    }
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int idx = tid + i * 512, rr = idx >> 3, lc = (idx & 7) ^ ((rr >> 1) & 7);
+        pb[i] = g.B + (size_t)(n0 + rr) * g.ldb + 8 * lc;
+    }
+    const int nk = g.K / BKB;
+    auto issue = [&](int kt) {
+        const unsigned st = lds0 + (unsigned)((kt % NST) * STAGE) * 2u + (unsigned)wave * 1024u;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) glds16(pa[i] + (size_t)kt * BKB, st + i * 8192u);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) glds16(pb[i] + (size_t)kt * BKB, st + A_ELEMS * 2u + i * 8192u);
+    };
+
+    bf16x8 a[2][2], b[2][2];
+    auto frags = [&](int set, const uint16_t* cA, const uint16_t* cB, int kk) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[set][i] = frag_swz(cA, wm * 64 + i * 32 + l31, kk, kh);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) b[set][j] = frag_swz(cB, wn * 64 + j * 32 + l31, kk, kh);
+    };
+    auto mfmas = [&](int set) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[set][i], b[set][j], acc[i][j], 0, 0, 0);
+    };
+
+    issue(0);
+    if (nk > 1) issue(1);
+    if (nk > 1) asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+    frags(0, smem, smem + A_ELEMS, 0);
+
+    for (int kt = 0; kt < nk; ++kt) {
+        const uint16_t* cA = smem + (kt % NST) * STAGE;
+        const uint16_t* cB = cA + A_ELEMS;
+        const uint16_t* nA = smem + ((kt + 1) % NST) * STAGE;
+        const uint16_t* nB = nA + A_ELEMS;
+        const bool more2 = kt + 2 < nk;
+        if (more2) issue(kt + 2);               // its stage was last read in iteration kt-1, before that iteration's barrier
+        __builtin_amdgcn_sched_barrier(0);
+        frags(1, cA, cB, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(0, cA, cB, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+        frags(1, cA, cB, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(0);
+        __builtin_amdgcn_sched_barrier(0);
+        // tile kt+1 has landed (this wave's share) -- the six loads of tile kt+2 may still be in flight -- and this
+        // wave's reads of stage kt are complete
+        if (more2) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        __builtin_amdgcn_sched_barrier(0);
+        frags(0, nA, nB, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int col = n0 + wn * 64 + j * 32 + l31;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                float v = acc[i][j][r] + bias;
+                if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+                if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
+                if (g.act == 1) v = fast_tanh(v);
+                if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
+                if (g.C) g.C[(size_t)row * g.ldc + col] = v;
+                if (g.Cb) g.Cb[(size_t)row * g.ldcb + col] = f2bf(v);
+            }
+        }
+    }
+}
+
 // dst[i] = bf16(src[i]), 8 elements per thread (n % 8 == 0, both 16-byte aligned)
 __global__ __launch_bounds__(256) void cvt_bf16_kernel(const float* __restrict__ src, uint16_t* __restrict__ dst, size_t n8) {
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
@@ -234,13 +376,25 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (g.rowgroup < 1) g.rowgroup = 1;
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
-    // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 forces one for the sweep
+    // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 84 forces one for the sweep
     static const char* force = getenv("STATTN_BF16_TILE");
-    const int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
+    const bool glds_ok = g.M % 256 == 0 && g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB;
+    int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
+    if (!g.tile && tile == 84 && !glds_ok) tile = 0;          // forced through the environment: only where it applies
+    if (tile == 84) {        // 256 x 128, 8 waves, direct-to-LDS staging
+        if (!glds_ok) return hipErrorInvalidValue;
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
+        return hipGetLastError();
+    }
     if (tile == 11) return launch_tile<1, 1>(s, g);
     if (tile == 21) return launch_tile<2, 1>(s, g);
     if (tile == 22 && g.N % 128 == 0) return launch_tile<2, 2>(s, g);
     if (tile) return hipErrorInvalidValue;
+    // large edge-free problems: the direct-to-LDS 256 x 128 kernel (881 vs 724 TFLOP/s on the MSR-VTT ff_local shape)
+    if (glds_ok && (long)(g.M / 256) * (g.N / 128) >= 256) {
+        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
+        return hipGetLastError();
+    }
     const long t22 = (long)((g.M + 127) / 128) * (g.N / 128);
     if (g.N % 128 == 0 && t22 >= 512) return launch_tile<2, 2>(s, g);
     return launch_tile<1, 1>(s, g);

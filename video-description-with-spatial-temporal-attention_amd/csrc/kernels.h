@@ -53,7 +53,7 @@ struct GemmBfArgs {
     const float* rowadd; int ldrow; int rowgroup;
     int act;                           // 0 none, 1 tanh
     const float* mul; int ldmul;       // [M,N] multiplier applied after act (dropout mask), or null
-    int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) workgroup tile (sweep tool)
+    int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) register-staged tile, 84 = 256 x 128 direct-to-LDS (sweep tool)
     int xcd_remap;                     // internal
 };
 hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);

@@ -25,7 +25,8 @@ def dec():
 
 @pytest.mark.parametrize("M,N,K,transB", [(64, 64, 64, False), (200, 128, 96, False), (333, 192, 1000, True),
                                           (128, 256, 72, True), (1000, 1024, 520, False),
-                                          (512, 256, 192, False), (1024, 1024, 512, True), (256, 128, 128, False)])
+                                          (512, 256, 192, False), (1024, 1024, 512, True), (256, 128, 128, False),
+                                          (300, 256, 128, False), (1000, 128, 640, True)])
 def test_bf16_gemm_matches_float64_on_rounded_operands(dec, M, N, K, transB):
     rng = np.random.RandomState(M + N + K)
     A = rng.standard_normal((M, K)).astype(np.float32)

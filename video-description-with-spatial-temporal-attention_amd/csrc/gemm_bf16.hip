@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
 //     into the fragment read, and the 16 lanes of a ds_read_b128 group hit 16 distinct 4-bank slots.
 //   * The DMA is issued from inline asm: with the builtin, hipcc's wait-count pass puts vmcnt(0) in front of the next
 //     ds_read while a DMA is in flight; waits are explicit (vmcnt(6) = the six loads of the newest tile may still fly).
-//   * Only for shapes without edges: M % 256 == 0, N % 128 == 0, K % 64 == 0 (the DMA cannot zero-fill).
+//   * N % 128 == 0 and K % 64 == 0 (the DMA cannot zero-fill); rows past M are clamped on the way in and skipped on the way out.
 #pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"     // m0 is clobbered on purpose: it carries the LDS destination of the DMA
 __device__ __forceinline__ void glds16(const void* gptr, unsigned lds_byte_addr) {
@@ -203,6 +203,7 @@ __device__ __forceinline__ bf16x8 frag_swz(const uint16_t* s, int row, int kk, i
     return *reinterpret_cast<const bf16x8*>(s + row * BKB + 8 * ((2 * kk + kh) ^ ((row >> 1) & 7)));
 }
 
+template <bool MEDGE>      // MEDGE: M is not a multiple of 256 (rows clamped on the way in, skipped on the way out)
 __global__ __launch_bounds__(512, 1) void gemm_bf16_glds_kernel(const GemmBfArgs g) {
     constexpr int BM = 256, BN = 128, NST = 3;
     constexpr int A_ELEMS = BM * BKB, B_ELEMS = BN * BKB, STAGE = A_ELEMS + B_ELEMS;      // bf16 elements
@@ -235,7 +236,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_glds_kernel(const GemmBfArgs
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
         const int idx = tid + i * 512, rr = idx >> 3, lc = (idx & 7) ^ ((rr >> 1) & 7);
-        pa[i] = g.A + (size_t)(m0 + rr) * g.lda + 8 * lc;
+        const int row = (!MEDGE || m0 + rr < g.M) ? m0 + rr : g.M - 1;   // rows past M: re-read the last one, never stored
+        pa[i] = g.A + (size_t)row * g.lda + 8 * lc;
     }
 #pragma unroll
     for (int i = 0; i < 2; ++i) {
@@ -314,6 +316,7 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_glds_kernel(const GemmBfArgs
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 64 + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (MEDGE && row >= g.M) continue;
                 float v = acc[i][j][r] + bias;
                 if (g.add) v += g.add[(size_t)row * g.ldadd + col];
                 if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
@@ -378,12 +381,13 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     g.xcd_remap = noremap ? 0 : 1;
     // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 84 forces one for the sweep
     static const char* force = getenv("STATTN_BF16_TILE");
-    const bool glds_ok = g.M % 256 == 0 && g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB;
+    const bool glds_ok = g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB;      // M edge: clamped rows
     int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
     if (!g.tile && tile == 84 && !glds_ok) tile = 0;          // forced through the environment: only where it applies
     if (tile == 84) {        // 256 x 128, 8 waves, direct-to-LDS staging
         if (!glds_ok) return hipErrorInvalidValue;
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
+        if (g.M % 256) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3(((g.M + 255) / 256) * (g.N / 128)), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL(gemm_bf16_glds_kernel<false>, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
         return hipGetLastError();
     }
     if (tile == 11) return launch_tile<1, 1>(s, g);
@@ -391,8 +395,9 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (tile == 22 && g.N % 128 == 0) return launch_tile<2, 2>(s, g);
     if (tile) return hipErrorInvalidValue;
     // large edge-free problems: the direct-to-LDS 256 x 128 kernel (881 vs 724 TFLOP/s on the MSR-VTT ff_local shape)
-    if (glds_ok && (long)(g.M / 256) * (g.N / 128) >= 256) {
-        hipLaunchKernelGGL(gemm_bf16_glds_kernel, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
+    if (glds_ok && (long)((g.M + 255) / 256) * (g.N / 128) >= 256) {
+        if (g.M % 256) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3(((g.M + 255) / 256) * (g.N / 128)), dim3(512), 0, s, g);
+        else hipLaunchKernelGGL(gemm_bf16_glds_kernel<false>, dim3((g.M / 256) * (g.N / 128)), dim3(512), 0, s, g);
         return hipGetLastError();
     }
     const long t22 = (long)((g.M + 127) / 128) * (g.N / 128);

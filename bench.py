@@ -139,8 +139,8 @@ def cpu_baseline(c, options, params, seed, train, budget_s=20.0):
 def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
     """BASELINE.md section 3 protocol: gen_sample (model_attention.py:852-994) per video through f_init / f_next,
     <eos> suppressed so every hypothesis runs maxlen = caption length steps; row-steps = hypotheses x steps.
-    The boundary hands host arrays to f_next on every call exactly like the reference (:903); the library caches
-    the projected video.  Videos are sharded over ranks, no collective (replicas only)."""
+    The boundary hands host arrays to f_next on every call exactly like the reference (:903); gen_sample stages the
+    video once per caption (explicit Decoder.video_scope), so the per-call F->D re-projection is gone.  Videos are sharded over ranks, no collective (replicas only)."""
     import stattn
     model = stattn.Attention()
     t = c["t"]
@@ -155,6 +155,7 @@ def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
         r[0][:, 0] = 0.0                     # forbid <eos>: deterministic step counts
         nsteps[0] += a[0].shape[0]
         return r
+    f_next.decoder = dec                     # gen_sample stages the video once per call (Decoder.video_scope)
     vids = [(batch['ctxg'][i], batch['mask_ctxg'][i], batch['ctxl'][i], batch['mask_ctxl'][i], batch['ctxm'][i],
              batch['mask_ctxm'][i]) for i in range(c["B"])]
 
@@ -221,15 +222,15 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
     bookkeeping of gen_sample (model_attention.py:921-985) runs on the device, <eos> suppressed.  The raw
     features are staged in HBM by the warm-up call; every timed call redoes the per-video F->D projections.
     row-steps = hypothesis-steps actually evaluated by the reference's loop: 1 + k (maxlen - 1) per video."""
-    k = args.beam if args.beam > 1 else 5
+    k = args.beam if args.beam >= 1 and args.beam_set else 5
     t = c["t"]
-    a = (batch['ctxg'], batch['mask_ctxg'], batch['ctxl'], batch['ctxm'])
+    dec.beam_stage(batch['ctxg'], batch['mask_ctxg'], batch['ctxl'], batch['ctxm'])     # inputs resident in HBM
     for _ in range(max(1, args.warmup)):
-        dec.beam_search(*a, k=k, maxlen=t, suppress_eos=True)
+        dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
     dec.sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        dec.beam_search(*a, k=k, maxlen=t, suppress_eos=True)
+        dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
     dec.sync()
     dt = time.perf_counter() - t0
     rowsteps = c["B"] * (1 + k * (t - 1)) * args.steps * world
@@ -247,6 +248,34 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
         dist.destroy_process_group()
 
 
+def spawn_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start one rank per GPU (same command line, RANK / LOCAL_RANK /
+    WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1) and wait.  Rank 0 prints the JSON line."""
+    import socket
+    import subprocess
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    while any(p.poll() is None for p in procs):
+        time.sleep(0.2)
+        bad = [p.returncode for p in procs if p.poll() not in (None, 0)]
+        if bad:                              # one rank died: the others would wait in a collective for ever
+            rc = bad[0]
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+    rc = rc or next((p.returncode for p in procs if p.returncode), 0)
+    if rc:
+        raise SystemExit("a rank failed (exit code %d)" % rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -254,7 +283,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam"])
-    ap.add_argument("--beam", type=int, default=1, help="decode mode: beam width k of gen_sample (1 = greedy)")
+    ap.add_argument("--beam", type=int, default=None, help="beam width k of gen_sample (decode mode default 1 = greedy, beam mode default 5)")
     ap.add_argument("--h2d", default="none", choices=["none", "sync", "prefetch"],
                     help="train mode only: also move the minibatch host->device every step (never the headline value): "
                          "sync = stattn_set_batch from pageable memory, prefetch = pinned arrays + copy stream, overlapped")
@@ -264,31 +293,40 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
     args = ap.parse_args()
+    args.beam_set = args.beam is not None
+    if args.beam is None:
+        args.beam = 1
+
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        return spawn_ranks(args.gpus)        # plain `python bench.py --gpus N`: this process becomes the launcher
 
     import torch
     import torch.distributed as dist
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus and world > 1:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d ... bench.py --gpus %d, or plain `python bench.py --gpus %d`)"
+                         % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libstattn has no CPU path)")
+    if world > torch.cuda.device_count():
+        raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
+        # torch.distributed is the CONTROL plane only (rendezvous token, barrier, max-over-ranks of the clock): gloo
+        # over 127.0.0.1.  The data path -- the gradient all-reduce -- is RCCL inside libstattn.so (csrc/comm.cpp).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        dist.init_process_group("gloo")
 
     import stattn
     from stattn import dp
     c = CONFIGS[args.config]
     options = make_options(c)
-    # the library runs on a torch stream so that torch.distributed's collective is ordered with its kernels
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
     if args.precision == "bf16" and args.mode == "train":
         raise SystemExit("--precision bf16 is a forward/decode path: use --mode forward, decode or beam")
-    dec = stattn.Decoder(options, device=local, stream=stream.cuda_stream, lt_mode=args.lt_mode, precision=args.precision)
+    dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode, precision=args.precision)   # its own stream
     params = fast_params(dec.param_shapes(), 1234)    # same seed on every rank: replicas start identical
     dec.set_params(params)
     batch = synthetic_batch(c, 1234 + rank)          # every rank owns different rows (videos)
@@ -299,7 +337,13 @@ def main():
     dec.set_batch(**batch)                            # inputs resident in HBM before the timed region
     train = args.mode == "train"
     dec.set_use_noise(1.0 if train else 0.0)
-    dec.set_seed(1234 + rank)
+    if train:
+        dp.init_comm(dec, rank, world)                # RCCL communicator (world > 1), rank 0's weights, seed + rank
+        ncomm = dec.comm_info()[1]
+        if world > 1 and ncomm != world:
+            raise SystemExit("RCCL communicator has %d ranks, expected %d" % (ncomm, world))
+    else:
+        dec.set_seed(1234 + rank)
     step_fn = dp.DataParallelStep(dec, global_batch=c["B"] * world, alpha_c=0.70602, decay_c=1e-4, clip_c=10.0) \
         if train else dec.forward_train               # config.py: decay_c 1e-4, alpha_c 0.70602, clip_c 10
     if train and args.h2d != "none":                  # PCIe-inclusive variants, not the headline
@@ -336,7 +380,7 @@ def main():
     barrier()
     dt = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
 

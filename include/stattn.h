@@ -109,9 +109,12 @@ int stattn_f_init(stattn_handle* h, const float* ctxg, const float* ctxg_mask, i
  *   -> [next_probs (m,V), next_sample (m,), h' (m,D), c' (m,D)]   (:845-848)
  * x (m,) int64 (-1 = first word), ctxl (T,K,F), ctxm (T,F).  ctxl_mask / ctxm_mask are
  * accepted and ignored exactly like the reference (on_unused_input='ignore').
- * The F->D projections the reference recomputes on every call (:782-785, :322-326) are
- * cached per video: keyed by the three ctx pointers, T, K and a content fingerprint;
- * stattn_invalidate_ctx_cache() forces a re-projection.
+ * Like the reference graph, a call that passes ctxg / ctxl / ctxm uploads and re-projects them
+ * (F->D, :782-785, :322-326) EVERY time -- the library never guesses whether a host array changed.
+ * The explicit fast path: stattn_set_video() stages and projects one video once; f_next calls that
+ * pass ctxg = ctxl = ctxm = NULL (T, K still given) then run on that resident video.  The
+ * projections of the resident video are redone automatically after stattn_set_param / stattn_update.
+ * x outside [-1, V) is rejected (the reference raises IndexError).
  * Optional outputs (NULL to skip) for the parity bar: out_alphal (m,T,K), out_alphag/m/lt
  * (m,T), out_logits (m,V). */
 int stattn_f_next(stattn_handle* h, const int64_t* x, int m,
@@ -122,7 +125,9 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m,
                   float* out_probs, int64_t* out_sample, float* out_h, float* out_c,
                   float* out_alphal, float* out_alphag, float* out_alpham, float* out_alphalt,
                   float* out_logits);
-int stattn_invalidate_ctx_cache(stattn_handle* h);
+/* Stage one video for the sampler: ctxg (T,D), ctxl (T,K,F), ctxm (T,F) -> HBM, projected once.
+ * Hoists what gen_sample's loop (model_attention.py:896-903) recomputes inside every f_next call. */
+int stattn_set_video(stattn_handle* h, const float* ctxg, const float* ctxl, const float* ctxm, int T, int K);
 
 /* Batched beam search: gen_sample (model_attention.py:852-994) for `nvid` videos at once with the whole
  * bookkeeping on the device (candidate costs hyp_score - log p, top (k - dead_k), hypothesis / state gather,
@@ -130,7 +135,12 @@ int stattn_invalidate_ctx_cache(stattn_handle* h);
  * once.  ctxg (nvid,T,D), ctxg_mask (nvid,T), ctxl (nvid,T,K,F), ctxm (nvid,T,F); 1 <= k <= 8.
  * Per video the hypotheses come back in gen_sample's order (finished ones in order of death, then the live
  * ones): out_tokens (nvid,k,maxlen) int64, -1 padded; out_scores, out_lens (nvid,k); out_count (nvid).
- * suppress_eos != 0 forbids word 0 so that every hypothesis runs maxlen steps (benchmarks). */
+ * suppress_eos != 0 forbids word 0 so that every hypothesis runs maxlen steps (benchmarks).
+ * Host features are staged on every call; with ctxg = ctxg_mask = ctxl = ctxm = NULL the videos staged by
+ * stattn_beam_stage (same nvid, T, K) are decoded (inputs resident in HBM: benchmarks, re-decoding after an
+ * update).  k = 1 is gen_sample's greedy mode (arg-max word, :896-918 with stochastic=False). */
+int stattn_beam_stage(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                      const float* ctxm, int T, int K);
 int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
                        const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
                        int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count);
@@ -138,7 +148,8 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
 /* ---- training graph: build_model / f_log_probs / f_grad_shared (:583-717, 1126, 1207) -- */
 /* Stage one minibatch in HBM: prepare_data()'s 8-tuple (data_engine.py:258-337).
  * x (t,m) int64, mask (t,m), ctxg (m,T,D), mask_ctxg (m,T), ctxl (m,T,K,F),
- * mask_ctxl (m,T,K) [ignored], ctxm (m,T,F), mask_ctxm (m,T) [ignored]. */
+ * mask_ctxl (m,T,K) [ignored], ctxm (m,T,F), mask_ctxm (m,T) [ignored].
+ * Words outside [0, V) are rejected (STATTN_EINVAL; the reference raises IndexError at :613). */
 int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int t, int m,
                      const float* ctxg, const float* mask_ctxg,
                      const float* ctxl, const float* mask_ctxl,
@@ -159,7 +170,8 @@ int stattn_swap_batch(stattn_handle* h);
  * t decoder steps, readout, vocabulary softmax, masked NLL. */
 int stattn_forward_train(stattn_handle* h);
 /* Results of the last forward.  Any pointer may be NULL.  cost (m,) [= -f_log_probs],
- * probs (t*m,V), alphal (t,m,T,K), alphag/alpham/alphalt (t,m,T), logits (t*m,V). */
+ * probs (t*m,V), alphal (t,m,T,K), alphag/alpham/alphalt (t,m,T), logits (t*m,V).
+ * logits must be read before stattn_backward (it reuses the buffer for d loss / d logit): STATTN_ESTATE after. */
 int stattn_get_forward(stattn_handle* h, float* cost, float* probs,
                        float* alphal, float* alphag, float* alpham, float* alphalt, float* logits);
 /* per-step state of the last forward, for tests: hs, cs (t,m,D), ctx (t,m,D) */
@@ -177,9 +189,37 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c);
 /* value of the loss above + decay_c * sum ||theta||^2, after stattn_backward */
 int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss);
 /* g += 2 decay_c theta; global-norm clip to clip_c (:1194-1203); Adadelta running averages and
- * parameter update (common.py:183-191; the reference ignores `lr`, Appendix C.8). */
+ * parameter update (common.py:183-191; the reference ignores `lr`, Appendix C.8).  One update per
+ * stattn_backward: STATTN_ESTATE without a fresh gradient. */
 int stattn_update(stattn_handle* h, float decay_c, float clip_c);
 int stattn_reset_optimizer(stattn_handle* h);
+
+/* ---- data parallel over the GPUs of one node (the reference is single-process: its
+ *      counterpart is the single f_grad_shared / f_update call site, model_attention.py:1259, 1278) ------------
+ * One process (or thread) per GPU, one handle each, rows (videos) of the caption batch sharded, weights replicated.
+ * Exactness rule: every rank passes nll_scale = 1 / B_global to stattn_backward; the regulariser is a batch SUM;
+ * ranks SUM their gradient buffers; the L2 term and the clip are applied once, after the reduce, in stattn_update.
+ * RCCL (librccl.so.1) is loaded on the first call; nothing here needs torch. */
+#define STATTN_COMM_ID_BYTES 128
+/* rank 0 creates the rendezvous token (ncclGetUniqueId) and hands the bytes to the other ranks by any host means */
+int stattn_comm_unique_id(void* id_out /* STATTN_COMM_ID_BYTES */);
+/* collective: every rank calls it with the same token; binds an RCCL communicator to the handle's GPU */
+int stattn_comm_init(stattn_handle* h, int rank, int nranks, const void* id);
+int stattn_comm_destroy(stattn_handle* h);
+int stattn_comm_info(const stattn_handle* h, int* rank, int* nranks);   /* nranks = 0: no communicator */
+/* overlap (default on): stattn_backward starts summing each region of the gradient buffer over the ranks on a side
+ * stream as soon as it is final (readout gradients before the reverse scan, decoder_* / ff_* / Wemb while the remaining
+ * weight-gradient GEMMs run).  0: one all-reduce of the whole buffer inside stattn_allreduce_grads.  2: overlap even
+ * in a one-rank communicator (a sum over one rank: how the side-stream path is tested on a single-GPU box). */
+int stattn_comm_set_overlap(stattn_handle* h, int enable);
+/* SUM the flat gradient buffer over the ranks (finishes the overlapped reduce); stream-ordered between
+ * stattn_backward and stattn_update.  Without a communicator (or with one rank) it only marks the gradient final.
+ * stattn_update refuses to run on an un-reduced gradient when the handle belongs to a multi-rank communicator. */
+int stattn_allreduce_grads(stattn_handle* h);
+/* copy rank `root`'s parameters to every rank (replicas must start identical) */
+int stattn_broadcast_params(stattn_handle* h, int root);
+/* SUM `n` host floats over the ranks in place (reported cost, counters); n <= 64 */
+int stattn_allreduce_scalars(stattn_handle* h, float* vals, int n);
 
 /* ---- kernel-level entry points (used by tests/ and bench.py to check and time the
  *      building blocks in isolation; not part of the reference surface) ------------- */
@@ -203,7 +243,7 @@ long stattn_dbg_counter(const stattn_handle* h, int which);
  * staging (edge-free shapes only) -- the LDS tile size sweep of BASELINE configs[3]. */
 int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch);
 /* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
- * 1 / 2 / 4 = ablations (loads only / MFMAs only / no reduction), see tools/skinny_probe.py. */
+ * other values are reserved. */
 int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,
                            float* ms_per_launch);
 /* Average duration (ms) of the named kernel class over the last stattn_forward_train

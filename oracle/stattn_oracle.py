@@ -454,7 +454,7 @@ def gen_sample(f_init_fn, f_next_fn, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_
         for idx in range(live_k):
             sample.append(hyp_samples[idx])
             sample_score.append(hyp_scores[idx])
-    return sample, sample_score, next_state, next_memory
+    return sample, sample_score, [next_state], [next_memory]               # one-element lists (n_layers_lstm = 1, :980-994)
 
 
 # ---------------------------------------------------------------------------

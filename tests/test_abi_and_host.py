@@ -95,6 +95,9 @@ def test_gen_sample_host_logic_against_oracle_driver_with_a_fake_step():
         sr, scr, hr, cr = O.gen_sample(f_init, f_next, *a, k=k, maxlen=7)
         assert s == sr
         np.testing.assert_allclose(np.asarray(sc), np.asarray(scr))
+        # one-element lists like the reference's (n_layers_lstm = 1, model_attention.py:980-994)
+        assert isinstance(hs, list) and isinstance(cs, list) and len(hs) == 1 and len(cs) == 1
+        np.testing.assert_array_equal(hs[0], hr[0])
     s, sc, _, _ = model.gen_sample(None, f_init, f_next, *a, {}, None, 1, maxlen=5, stochastic=True)
     assert len(s) <= 5
     with pytest.raises(AssertionError):

@@ -77,6 +77,33 @@ def test_two_rank_step_equals_single_process_step(tmp_path):
         np.testing.assert_allclose(r0[k], P[k], rtol=1e-9, atol=1e-12)
 
 
+def _token_worker(rank, world, port, outdir, use_group):
+    from stattn import dp
+    if use_group:
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+    made = []
+
+    def make():                      # stands in for Decoder.comm_unique_id (needs librccl + a GPU): rank 0 only
+        made.append(1)
+        return bytes(range(128))
+    tok = dp.exchange_token(make, rank, world, path=None if use_group else os.path.join(outdir, "token"))
+    assert tok == bytes(range(128)) and len(made) == (1 if rank == 0 else 0)
+    open(os.path.join(outdir, "ok%d_%d" % (use_group, rank)), "w").close()
+    if use_group:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("use_group", [1, 0])
+def test_rendezvous_token_reaches_every_rank(tmp_path, use_group):
+    """The only thing the host has to do for the in-library RCCL communicator: hand rank 0's 128-byte token to all
+    ranks -- through a torch.distributed group when one exists, else through a shared file."""
+    mp.spawn(_token_worker, args=(2, _free_port(), str(tmp_path), use_group), nprocs=2, join=True)
+    assert all(os.path.exists(os.path.join(str(tmp_path), "ok%d_%d" % (use_group, r))) for r in range(2))
+
+
 def test_shard_rows_partitions_every_row_once():
     from stattn import dp
     from oracle import stattn_oracle as O

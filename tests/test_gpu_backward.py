@@ -126,57 +126,56 @@ def test_sharded_gradient_equals_full_batch_gradient():
     _check_grads(tot, ref)
 
 
-def test_gradient_buffer_aliases_into_torch_and_rccl_allreduce_runs():
-    """The data-parallel step all-reduces a torch view of the library's flat gradient buffer
-    (no copy).  On a 1-GPU box: single-rank RCCL group -- checks the aliasing in both directions,
-    the stream ordering (library runs on a torch stream) and that the collective executes."""
-    import os
-    import torch
-    import torch.distributed as dist
+def test_in_library_rccl_allreduce_and_overlapped_regions():
+    """stattn_comm_init / stattn_allreduce_grads (csrc/comm.cpp) on a 1-GPU box: a one-rank RCCL communicator.
+    Mode 2 forces the overlapped path -- every region of the gradient buffer is handed to ncclAllReduce on the side
+    stream behind an event while backward still runs, and the regions must tile the buffer exactly -- and a sum over
+    one rank must leave gradients, loss and the Adadelta step bit-identical to a handle without a communicator.
+    Also: update refuses a second use of one gradient, allreduce refuses a double sum."""
     import stattn
     from stattn import dp
     from oracle import stattn_oracle as O
     opt = O.default_options(**SMALL)
     P = O.random_params(opt, seed=3, dtype=np.float32)
-    stream = torch.cuda.Stream()
-    torch.cuda.set_stream(stream)
-    dec = stattn.Decoder(opt, lt_mode=1, stream=stream.cuda_stream)
-    dec.set_params(P)
     batch = O.synthetic_batch(opt, B=4, T=4, K=3, t=4, seed=3)
-    dec.set_batch(**batch)
-    dec.forward_train()
-    dec.backward(alpha_c=0.5)
-    g0 = dec.get_grads()
-    gt = dp.grad_tensor(dec)
-    ptr, n = dec.grad_buffer_dev()
-    assert gt.data_ptr() == ptr and gt.numel() == n and gt.dtype == torch.float32
-    own_group = not dist.is_initialized()
-    if own_group:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
-    try:
-        dist.all_reduce(gt, op=dist.ReduceOp.SUM)              # RCCL on the library's stream
-        gt.mul_(2.0)                                           # a torch write is visible to the library
-        torch.cuda.current_stream().synchronize()
-        g1 = dec.get_grads()
-        for k in g0:
-            np.testing.assert_allclose(g1[k], 2.0 * g0[k], rtol=1e-6, atol=1e-12)
-        # full DP step object on one rank == forward/backward/update by hand
+    plain = stattn.Decoder(opt, lt_mode=1)
+    plain.set_params(P); plain.set_batch(**batch)
+    plain.forward_train(); plain.backward(nll_scale=0.25, alpha_c=0.5)
+    g_ref = plain.get_grads()
+    plain.update(decay_c=1e-4, clip_c=10.0)
+    p_ref = plain.get_params()
+    with pytest.raises(stattn.NativeError, match="no fresh gradient"):
+        plain.update(decay_c=1e-4, clip_c=10.0)
+    for mode in (2, 1, 0):
+        dec = stattn.Decoder(opt, lt_mode=1)
+        dec.set_params(P)
+        assert dec.comm_info() == (0, 0)
+        rank, world = dp.init_comm(dec, rank=0, world=1)          # world 1: no communicator needed ...
+        assert (rank, world) == (0, 1) and dec.comm_info()[1] == 0
+        dec.comm_init(0, 1, dec.comm_unique_id())                 # ... but a one-rank RCCL communicator is legal
+        assert dec.comm_info() == (0, 1)
+        dec.comm_set_overlap(mode)
+        dec.broadcast_params(0)
+        dec.set_batch(**batch)
         step = dp.DataParallelStep(dec, global_batch=4, alpha_c=0.5, decay_c=1e-4, clip_c=10.0)
-        step()
+        dec.forward_train(); dec.backward(nll_scale=0.25, alpha_c=0.5)
+        dec.allreduce_grads()
+        with pytest.raises(stattn.NativeError, match="already been summed"):
+            dec.allreduce_grads()
+        g = dec.get_grads()
+        for k in g_ref:
+            if k == 'Wemb':
+                np.testing.assert_allclose(g[k], g_ref[k], rtol=1e-5, atol=1e-9)      # atomic scatter order
+            else:
+                np.testing.assert_array_equal(g[k], g_ref[k])
+        assert abs(dec.allreduce_scalars([1.5, -2.0])[1] + 2.0) < 1e-7
+        step()                                                     # full step object == by hand on the plain handle
         p1 = dec.get_params()
-        dec2 = stattn.Decoder(opt, lt_mode=1)
-        dec2.set_params(P)
-        dec2.set_batch(**batch)
-        dec2.forward_train(); dec2.backward(nll_scale=0.25, alpha_c=0.5); dec2.update(decay_c=1e-4, clip_c=10.0)
-        p2 = dec2.get_params()
-        for k in p1:
-            np.testing.assert_allclose(p1[k], p2[k], rtol=1e-5, atol=1e-7)
-    finally:
-        if own_group:
-            dist.destroy_process_group()
-        torch.cuda.set_stream(torch.cuda.default_stream())
+        for k in p_ref:
+            np.testing.assert_allclose(p1[k], p_ref[k], rtol=1e-5, atol=1e-7)
+        dec.comm_destroy()
+        assert dec.comm_info()[1] == 0
+        dec.close()
 
 
 def test_train_loop_counterpart_learns_and_checkpoints(tmp_path):

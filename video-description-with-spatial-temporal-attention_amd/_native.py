@@ -53,7 +53,8 @@ _SIGNATURES = {
     "stattn_f_init": (C.c_int, [_H, _F, _F, C.c_int, _F, _F]),
     "stattn_f_next": (C.c_int, [_H, _I64, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int, _F, _F,
                                 _F, _I64, _F, _F, _F, _F, _F, _F, _F]),
-    "stattn_invalidate_ctx_cache": (C.c_int, [_H]),
+    "stattn_set_video": (C.c_int, [_H, _F, _F, _F, C.c_int, C.c_int]),
+    "stattn_beam_stage": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int]),
     "stattn_beam_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      _I64, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
@@ -68,6 +69,14 @@ _SIGNATURES = {
     "stattn_get_loss": (C.c_int, [_H, C.c_float, C.c_float, _F]),
     "stattn_update": (C.c_int, [_H, C.c_float, C.c_float]),
     "stattn_reset_optimizer": (C.c_int, [_H]),
+    "stattn_comm_unique_id": (C.c_int, [C.c_void_p]),
+    "stattn_comm_init": (C.c_int, [_H, C.c_int, C.c_int, C.c_void_p]),
+    "stattn_comm_destroy": (C.c_int, [_H]),
+    "stattn_comm_info": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "stattn_comm_set_overlap": (C.c_int, [_H, C.c_int]),
+    "stattn_allreduce_grads": (C.c_int, [_H]),
+    "stattn_broadcast_params": (C.c_int, [_H, C.c_int]),
+    "stattn_allreduce_scalars": (C.c_int, [_H, _F, C.c_int]),
     "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   _F, _F, _F, _F, C.c_int, _F]),
     "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
@@ -267,11 +276,44 @@ class Decoder(object):
         self._chk(self._lib.stattn_f_init(self._h, _fp(ctxg), _fp(ctxg_mask), T, _fp(h0), _fp(c0)))
         return [ctxg, h0, c0]
 
-    def f_next(self, x, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask, h, c, extras=False):
+    def set_video(self, ctxg, ctxl, ctxm):
+        """Stage one video for the sampler (stattn_set_video): features -> HBM, projected once.  f_next calls made with
+        `resident=True` (or inside video_scope with the same arrays) then skip the per-call upload + F->D projection
+        that the reference graph repeats on every call (model_attention.py:782-788)."""
+        ctxg = _f32(ctxg, "ctxg"); ctxl = _f32(ctxl, "ctxl"); ctxm = _f32(ctxm, "ctxm")
+        if ctxl.ndim != 3 or ctxl.shape[2] != self.Fl:
+            raise ValueError("ctxl must be (T, K, %d)" % self.Fl)
+        T, K = ctxl.shape[0], ctxl.shape[1]
+        if ctxg.shape != (T, self.D) or ctxm.shape != (T, self.Fm):
+            raise ValueError("ctxg/ctxm shapes do not match ctxl's T")
+        self._chk(self._lib.stattn_set_video(self._h, _fp(ctxg), _fp(ctxl), _fp(ctxm), T, K))
+
+    def video_scope(self, ctxg, ctxl, ctxm):
+        """Context manager for a decode loop over ONE video: stages it once, and f_next calls inside the scope that are
+        handed these very array objects run on the resident copy.  The scope is explicit and ends with the loop, so
+        nothing is ever inferred from pointers or contents: outside a scope every f_next call re-projects like the
+        reference."""
+        dec = self
+
+        class _Scope(object):
+            def __enter__(self_s):
+                dec.set_video(ctxg, ctxl, ctxm)
+                dec._scope = (ctxg, ctxl, ctxm)
+                return dec
+
+            def __exit__(self_s, *exc):
+                dec._scope = None
+                return False
+        return _Scope()
+
+    def f_next(self, x, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask, h, c, extras=False, resident=False):
         x = _i64(x, "x")
         if x.ndim != 1:
             raise ValueError("x must be a vector")
         m = x.shape[0]
+        sc = getattr(self, "_scope", None)
+        if sc is not None and ctxg is sc[0] and ctxl is sc[1] and ctxm is sc[2]:
+            resident = True
         ctxg = _f32(ctxg, "ctxg"); ctxl = _f32(ctxl, "ctxl"); ctxm = _f32(ctxm, "ctxm")
         if ctxl.ndim != 3 or ctxl.shape[2] != self.Fl:
             raise ValueError("ctxl must be (T, K, %d)" % self.Fl)
@@ -286,8 +328,9 @@ class Decoder(object):
             al = np.empty((m, T, K), np.float32); ag = np.empty((m, T), np.float32)
             am = np.empty((m, T), np.float32); alt = np.empty((m, T), np.float32)
             lg = np.empty((m, self.V), np.float32)
+        pg, pl, pm = (None, None, None) if resident else (_fp(ctxg), _fp(ctxl), _fp(ctxm))
         self._chk(self._lib.stattn_f_next(
-            self._h, x.ctypes.data_as(_I64), m, _fp(ctxg), None, _fp(ctxl), None, _fp(ctxm), None, T, K,
+            self._h, x.ctypes.data_as(_I64), m, pg, None, pl, None, pm, None, T, K,
             _fp(h), _fp(c), _fp(probs), sample.ctypes.data_as(_I64), _fp(ho), _fp(co),
             _fp(al), _fp(ag), _fp(am), _fp(alt), _fp(lg)))
         out = [probs, sample, ho, co]
@@ -295,18 +338,37 @@ class Decoder(object):
             return out, dict(alphal=al, alphag=ag, alpham=am, alphalt=alt, logit=lg)
         return out
 
-    def beam_search(self, ctxg, ctxg_mask, ctxl, ctxm, k=5, maxlen=30, suppress_eos=False):
-        """gen_sample for a batch of videos, device-side (stattn_beam_search).  Returns a list with one
-        (samples, scores) pair per video, ordered like gen_sample's return value."""
+    def _beam_shapes(self, ctxg, ctxg_mask, ctxl, ctxm):
         ctxl = _f32(ctxl, "ctxl")
         if ctxl.ndim != 4 or ctxl.shape[3] != self.Fl:
             raise ValueError("ctxl must be (nvid, T, K, %d)" % self.Fl)
         nvid, T, K = ctxl.shape[0], ctxl.shape[1], ctxl.shape[2]
         ctxg = _f32(ctxg, "ctxg", (nvid, T, self.D)); ctxg_mask = _f32(ctxg_mask, "ctxg_mask", (nvid, T))
         ctxm = _f32(ctxm, "ctxm", (nvid, T, self.Fm))
+        return ctxg, ctxg_mask, ctxl, ctxm, nvid, T, K
+
+    def beam_stage(self, ctxg, ctxg_mask, ctxl, ctxm):
+        """Stage a batch of videos for beam_search(resident=True): inputs resident in HBM (stattn_beam_stage)."""
+        ctxg, ctxg_mask, ctxl, ctxm, nvid, T, K = self._beam_shapes(ctxg, ctxg_mask, ctxl, ctxm)
+        self._chk(self._lib.stattn_beam_stage(self._h, nvid, _fp(ctxg), _fp(ctxg_mask), _fp(ctxl), _fp(ctxm), T, K))
+        self._staged = (nvid, T, K)
+
+    def beam_search(self, ctxg=None, ctxg_mask=None, ctxl=None, ctxm=None, k=5, maxlen=30, suppress_eos=False, resident=False):
+        """gen_sample for a batch of videos, device-side (stattn_beam_search).  Returns a list with one
+        (samples, scores) pair per video, ordered like gen_sample's return value.  k = 1 is the greedy mode.
+        resident=True decodes the videos staged by beam_stage() (no host arrays, nothing re-uploaded)."""
+        if resident:
+            if getattr(self, "_staged", None) is None:
+                raise ValueError("beam_search(resident=True) needs beam_stage() first")
+            nvid, T, K = self._staged
+            pg = pk = pl = pm = None
+        else:
+            ctxg, ctxg_mask, ctxl, ctxm, nvid, T, K = self._beam_shapes(ctxg, ctxg_mask, ctxl, ctxm)
+            pg, pk, pl, pm = _fp(ctxg), _fp(ctxg_mask), _fp(ctxl), _fp(ctxm)
+            self._staged = (nvid, T, K)
         tok = np.empty((nvid, k, maxlen), np.int64); sc = np.empty((nvid, k), np.float32)
         ln = np.empty((nvid, k), np.int32); cnt = np.empty((nvid,), np.int32)
-        self._chk(self._lib.stattn_beam_search(self._h, nvid, _fp(ctxg), _fp(ctxg_mask), _fp(ctxl), _fp(ctxm), T, K, int(k),
+        self._chk(self._lib.stattn_beam_search(self._h, nvid, pg, pk, pl, pm, T, K, int(k),
                                                int(maxlen), int(bool(suppress_eos)), tok.ctypes.data_as(_I64), _fp(sc),
                                                ln.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
         out = []
@@ -314,9 +376,6 @@ class Decoder(object):
             samples = [tok[v, j, :ln[v, j]].tolist() for j in range(cnt[v])]
             out.append((samples, sc[v, :cnt[v]].copy()))
         return out
-
-    def invalidate_ctx_cache(self):
-        self._chk(self._lib.stattn_invalidate_ctx_cache(self._h))
 
     # -- training graph
     def set_batch(self, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
@@ -416,6 +475,47 @@ class Decoder(object):
 
     def update(self, decay_c=0.0, clip_c=0.0):
         self._chk(self._lib.stattn_update(self._h, float(decay_c), float(clip_c)))
+
+    # -- data parallel (in-library RCCL; stattn.dp drives the rendezvous)
+    COMM_ID_BYTES = 128
+
+    def comm_unique_id(self):
+        """Rendezvous token (bytes) made by rank 0 and handed to every rank's comm_init."""
+        buf = C.create_string_buffer(self.COMM_ID_BYTES)
+        rc = self._lib.stattn_comm_unique_id(buf)
+        if rc != 0:
+            raise NativeError("stattn_comm_unique_id failed: %s" % self._lib.stattn_last_error(None).decode())
+        return buf.raw
+
+    def comm_init(self, rank, nranks, token):
+        if len(token) != self.COMM_ID_BYTES:
+            raise ValueError("token must be %d bytes" % self.COMM_ID_BYTES)
+        buf = C.create_string_buffer(bytes(token), self.COMM_ID_BYTES)
+        self._chk(self._lib.stattn_comm_init(self._h, int(rank), int(nranks), buf))
+
+    def comm_destroy(self):
+        self._chk(self._lib.stattn_comm_destroy(self._h))
+
+    def comm_info(self):
+        r = C.c_int(); n = C.c_int()
+        self._chk(self._lib.stattn_comm_info(self._h, C.byref(r), C.byref(n)))
+        return r.value, n.value
+
+    def comm_set_overlap(self, mode):
+        """0 = one all-reduce after backward, 1 = regions reduced while backward runs (default), 2 = same, forced
+        even in a one-rank communicator (test hook)."""
+        self._chk(self._lib.stattn_comm_set_overlap(self._h, int(mode)))
+
+    def allreduce_grads(self):
+        self._chk(self._lib.stattn_allreduce_grads(self._h))
+
+    def broadcast_params(self, root=0):
+        self._chk(self._lib.stattn_broadcast_params(self._h, int(root)))
+
+    def allreduce_scalars(self, vals):
+        v = np.ascontiguousarray(np.asarray(vals, dtype=np.float32).reshape(-1))
+        self._chk(self._lib.stattn_allreduce_scalars(self._h, _fp(v), v.size))
+        return v
 
     def reset_optimizer(self):
         self._chk(self._lib.stattn_reset_optimizer(self._h))

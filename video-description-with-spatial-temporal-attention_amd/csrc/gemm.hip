@@ -87,134 +87,11 @@ struct Tile {
     }
 };
 
-template <int TM, int TN, bool AT, bool BT>
-__global__ __launch_bounds__(256, 2) void gemm_kernel(const GemmArgs g) {
-    constexpr int BM = 64 * TM, BN = 64 * TN;
-    using TA = Tile<BM, !AT>;
-    using TB = Tile<BN, BT>;
-    __shared__ __attribute__((aligned(16))) float smem[2 * (TA::ELEMS + TB::ELEMS)];
-    float* sA = smem;
-    float* sB = smem + 2 * TA::ELEMS;
-
-    // XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
-    // (consecutive tiles share the A row-panel -> L2 hits).  Bijective for any grid size.
-    const int tiles_n = g.N / BN;
-    const int nblk = gridDim.x;
-    const int bid = blockIdx.x;
-    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
-    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
-    const int m0 = (lin / tiles_n) * BM;
-    const int n0 = (lin % tiles_n) * BN;
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;
-    const int l31 = lane & 31, kh = lane >> 5;
-
-    f32x16 acc[TM][TN];
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-    float4 ra[TA::NF4], rb[TB::NF4];
-    // split-K: slice blockIdx.y owns k in [kb, ke) and writes its partial tile to ws
-    int kb = 0, ke = g.K;
-    float* Cout = g.C;
-    int ldc = g.ldc;
-    if (g.kslices > 1) {
-        const int per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
-        kb = blockIdx.y * per;
-        ke = kb + per < g.K ? kb + per : g.K;
-        Cout = g.ws + (size_t)blockIdx.y * g.M * g.N;
-        ldc = g.N;
-    }
-    const int nk = ke > kb ? (ke - kb + BK - 1) / BK : 0;
-
-    TA::gload(ra, g.A, g.lda, m0, g.M, kb, ke, tid);
-    TB::gload(rb, g.B, g.ldb, n0, g.N, kb, ke, tid);
-    TA::sstore(ra, sA, tid);
-    TB::sstore(rb, sB, tid);
-    __syncthreads();
-
-    for (int kt = 0; kt < nk; ++kt) {
-        const int st = kt & 1;
-        const bool more = (kt + 1 < nk);
-        if (more) {   // next tile's global loads fly while this tile is multiplied
-            TA::gload(ra, g.A, g.lda, m0, g.M, kb + (kt + 1) * BK, ke, tid);
-            TB::gload(rb, g.B, g.ldb, n0, g.N, kb + (kt + 1) * BK, ke, tid);
-        }
-        const float* cA = sA + st * TA::ELEMS;
-        const float* cB = sB + st * TB::ELEMS;
-        // Fragment reads are software-pipelined through two register sets: the ds_reads of k-block
-        // kk+1 are issued before the 16 MFMAs of k-block kk, so LDS latency hides under the matrix
-        // pipe instead of serialising with it (sched_barrier pins the order; the compiler's own
-        // schedule sank every B read to just before its first use: read -> wait -> 4 MFMA).
-        float a[2][TM][4], b[2][TN][4];
-#pragma unroll
-        for (int i = 0; i < TM; ++i) TA::frag(a[0][i], cA, wm * 32 * TM + i * 32 + l31, 0, kh);
-#pragma unroll
-        for (int j = 0; j < TN; ++j) TB::frag(b[0][j], cB, wn * 32 * TN + j * 32 + l31, 0, kh);
-#pragma unroll
-        for (int kk = 0; kk < BK / 8; ++kk) {
-            const int cur = kk & 1, nxt = cur ^ 1;
-            if (kk + 1 < BK / 8) {
-#pragma unroll
-                for (int i = 0; i < TM; ++i) TA::frag(a[nxt][i], cA, wm * 32 * TM + i * 32 + l31, kk + 1, kh);
-#pragma unroll
-                for (int j = 0; j < TN; ++j) TB::frag(b[nxt][j], cB, wn * 32 * TN + j * 32 + l31, kk + 1, kh);
-            }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[cur][i][q], b[cur][j][q], acc[i][j], 0, 0, 0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (more) {   // the other stage was last read before the previous barrier
-            TA::sstore(ra, sA + (st ^ 1) * TA::ELEMS, tid);
-            TB::sstore(rb, sB + (st ^ 1) * TB::ELEMS, tid);
-        }
-        __syncthreads();
-    }
-
-    // epilogue.  32x32 C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * 32 * TN + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < g.M && g.kslices > 1) {
-                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
-                } else if (row < g.M) {
-                    float v = g.alpha * acc[i][j][r] + bias;
-                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
-                    if (g.act == 1) v = fast_tanh(v);
-                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
-                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
-                    float* c = g.C + (size_t)row * g.ldc + col;
-                    if (g.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
-
 // ---------------------------------------------------------------------------------------------------------
-// Version 2 of the main loop: same tiles, operands and epilogue, but no MFMA-free phase at the tile boundary.
-// PMC on version 1 (4096^3): matrix pipe busy 79 %, waves stalled on ISSUE 81 % and on waits only 7 % -- the two
-// co-resident waves of a SIMD advance in lock step, reach their "wait for the global loads, write LDS, barrier,
-// first fragment read" phase together, and the pipe idles.  Here
+// Main loop without an MFMA-free phase at the tile boundary.  PMC on the plain "load, barrier, multiply" loop
+// (4096^3): matrix pipe busy 79 %, waves stalled on ISSUE 81 % and on waits only 7 % -- the two co-resident waves
+// of a SIMD advance in lock step, reach their "wait for the global loads, write LDS, barrier, first fragment
+// read" phase together, and the pipe idles.  Here
 //   * global loads run TWO tiles ahead (two register sets), so the LDS write of tile kt+1 needs no wait,
 //   * that write is placed after the MFMAs of k-block 1, the workgroup barrier after k-block 2,
 //   * the first fragments of tile kt+1 are read after the barrier and before the MFMAs of k-block 3,
@@ -241,9 +118,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
+#ifdef STATTN_PROBES
     if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
         g.clk[0] = __builtin_readcyclecounter(); g.clk[1] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -280,7 +159,6 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
 
     float a[2][TM][4], b[2][TN][4];
     auto frags = [&](int set, const float* cA, const float* cB, int kk) {
-        if (g.abl == 2) return;
 #pragma unroll
         for (int i = 0; i < TM; ++i) TA::frag(a[set][i], cA, wm * 32 * TM + i * 32 + l31, kk, kh);
 #pragma unroll
@@ -315,11 +193,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(1);                                                                                             \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        if (!g.abl) { TA::sstore(RA_NEXT, nA, tid);                                                           \
-        TB::sstore(RB_NEXT, nB, tid); }                                                                       \
+        TA::sstore(RA_NEXT, nA, tid);                                                                         \
+        TB::sstore(RB_NEXT, nB, tid);                                                                         \
         /* the freed register set starts fetching tile KT+3?  no: tile KT+2 lives in the FAR set; refill NEXT */\
-        if (!g.abl) { TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);       \
-        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid); }                   \
+        TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);                     \
+        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid);                     \
         /* k-block 2 (its fragments for k-block 3 are fetched BEFORE the barrier) */                          \
         frags(1, cA, cB, 3);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -346,9 +224,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     }
     if (kt < nk) STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
 #undef STATTN_GEMM2_TILE
+#ifdef STATTN_PROBES
     if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
         g.clk[2] = __builtin_readcyclecounter(); g.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
+#endif
 
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
@@ -400,13 +280,7 @@ hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
     const int BM = 64 * TM, BN = 64 * TN;
     const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
     dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1), block(256);
-    static const char* v1 = getenv("STATTN_GEMM_V1");
-    if (v1) {
-        if (!tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, false>), grid, block, 0, s, g);
-        else if (!tA && tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, false, true>), grid, block, 0, s, g);
-        else if (tA && !tB) hipLaunchKernelGGL((gemm_kernel<TM, TN, true, false>), grid, block, 0, s, g);
-        else return hipErrorInvalidValue;
-    } else {
+    {
         // predicate-free loads when no tile straddles an edge that is NOT handled by clamping
         int per = g.K;
         if (g.kslices > 1) per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
@@ -435,9 +309,12 @@ void gemm_defaults(GemmArgs& g) {
     g.rowgroup = 1;
 }
 
-// Clock probe (STATTN_GEMM_CLK=1, tools only): block 0 of every GEMM launch records the shader cycle counter and the
-// 100 MHz wall clock at its start and end; gemm_clock_dump() prints shape, block-0 duration and the implied shader
-// clock for every launch since the last dump.
+// Clock probe (tools only: build with `make PROBES=1`, run with STATTN_GEMM_CLK=1): block 0 of every GEMM launch
+// records the shader cycle counter and the 100 MHz wall clock at its start and end; gemm_clock_dump() prints shape,
+// block-0 duration and the implied shader clock for every launch since the last dump.  Compiled out of product builds.
+#ifndef STATTN_PROBES
+void gemm_clock_dump() {}
+#else
 namespace {
 struct ClkRec { int M, N, K, tA, tB; };
 constexpr int CLK_SLOTS = 4096;
@@ -458,10 +335,12 @@ void gemm_clock_dump() {
     }
     g_clk_rec->clear();
 }
+#endif
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
     g.kslices = 1;
+#ifdef STATTN_PROBES
     static const char* clk = getenv("STATTN_GEMM_CLK");
     if (clk) {
         if (!g_clk_dev) {
@@ -473,10 +352,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
             g_clk_rec->push_back(ClkRec{g.M, g.N, g.K, tA, tB});
         }
     }
+#endif
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
-    static const char* abl = getenv("STATTN_GEMM_ABL");          // ablation probes only (results are wrong)
-    g.abl = abl ? atoi(abl) : 0;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
     if (tB && g.K % 4 != 0) return hipErrorInvalidValue;

@@ -1,0 +1,187 @@
+// Private definitions shared by the translation units behind the C ABI (api.cpp, comm.cpp): the handle, its
+// device-buffer cache and the error helpers.  Not installed; include/stattn.h is the public surface.
+#pragma once
+#include "../../include/stattn.h"
+#include "kernels.h"
+
+#include <hip/hip_runtime.h>
+
+#include <cmath>
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+using namespace stattn;
+
+namespace stattn_detail {
+
+struct ParamInfo {
+    std::string name;
+    int ndim;
+    int64_t dims[2];
+    size_t off;     // offset in the flat buffer (floats)
+    int ld;         // leading dimension (floats) of the device layout
+    size_t count;   // logical element count
+};
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    hipError_t ensure(size_t bytes) {
+        if (bytes <= cap) return hipSuccess;
+        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        size_t want = (bytes + 255) & ~size_t(255);
+        hipError_t e = hipMalloc(&p, want);
+        if (e == hipSuccess) cap = want;
+        return e;
+    }
+    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+};
+
+enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_COUNT };
+
+struct Weights {   // device pointers into the flat parameter buffer
+    float *Wemb, *ff_state_W, *ff_state_b, *ff_memory_W, *ff_memory_b, *ff_local_W, *ff_local_b,
+          *ff_motion_W, *ff_motion_b, *W, *U, *b, *Wc, *Wcg, *Wcm, *Wclt, *Wdg, *Wdm, *Wdlt, *bg, *bm, *blt,
+          *Wcl, *Wdl, *bl, *Ug, *cg, *Um, *cm, *Ult, *clt, *Ul, *cl, *W_sel, *b_sel,
+          *Wl1, *bl1, *Wl2, *bl2, *Wo, *bo;
+};
+
+}  // namespace stattn_detail
+using namespace stattn_detail;
+
+struct stattn_handle {
+    stattn_options opt{};
+    int D = 0, E = 0, V = 0, Vp = 0, Fl = 0, Fm = 0;
+    int device = 0;
+    hipStream_t stream = nullptr;
+    bool own_stream = false;
+    std::string err;
+
+    std::vector<ParamInfo> params;
+    std::map<std::string, int> pindex;
+    float* d_params = nullptr;
+    float* d_grads = nullptr;
+    float* d_rg2 = nullptr;      // Adadelta running averages (common.py:180-181), allocated on first update
+    float* d_ru2 = nullptr;
+    bool have_bwd = false;
+    size_t nflat = 0;
+    Weights w{};
+
+    float use_noise = 0.f;
+    uint64_t seed = 1234, draw = 0;
+
+    std::map<std::string, DevBuf> bufs;
+
+    // training batch
+    int t = 0, m = 0, T = 0, K = 0;
+    bool have_batch = false, have_fwd = false;
+    bool masks_user = false;
+    int masks_t = 0, masks_m = 0;        // shape the mask buffers currently hold
+    int masks_state = 0;                 // 0 invalid, 1 holds eval (0.5), 2 holds a random draw
+
+    // double-buffered batch staging (prepare_data -> HBM pipeline): set 0 / 1, a copy stream and a ready event
+    int cur_set = 0;
+    hipStream_t copy_stream = nullptr;
+    hipEvent_t staged_ev = nullptr;
+    hipEvent_t free_ev[2] = {nullptr, nullptr};   // "every kernel that read set i has been enqueued before this"
+    bool free_valid[2] = {false, false};
+    bool have_pending = false;
+    int p_t = 0, p_m = 0, p_T = 0, p_K = 0;
+
+    // sampler: the resident video (stattn_set_video, or the last f_next call that passed host features).
+    // ck_valid: raw features are in HBM; ck_proj: their projections match the current parameters
+    int ck_T = 0, ck_K = 0;
+    bool ck_proj = false;
+    // beam search: the captured two-word graph is kept while every pointer and shape it baked in is unchanged
+    hipGraphExec_t beam_gexec = nullptr;
+    std::vector<uintptr_t> beam_gsig;
+    long beam_graph_replays = 0;        // replays in the last stattn_beam_search (0 = eager launches)
+    bool ck_valid = false;
+    // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
+    // ~15 us); sn_m / sn_dp / sn_vid remember that the constant step inputs (video index, eval dropout) are in place
+    void* pin_io = nullptr; size_t pin_io_bytes = 0;
+    int sn_m = -1; const void* sn_dp = nullptr; const void* sn_vid = nullptr;
+    uint64_t host_rng = 0x853c49e6748fea9bull;
+    // batched beam search: raw features staged by stattn_beam_stage (or the last call that passed host features)
+    int bk_n = 0, bk_T = 0, bk_K = 0;
+    bool bk_valid = false;
+
+    // profiling
+    bool profiling = false;
+    struct EvPair { hipEvent_t a, b; int cls; };
+    std::vector<EvPair> ev_used;
+    std::vector<hipEvent_t> ev_pool;
+    double k_ms[KC_COUNT] = {0};
+    int k_n[KC_COUNT] = {0};
+
+    // data parallel (comm.cpp): RCCL communicator of this rank, a side stream for the bucketed gradient reduce
+    void* comm = nullptr;                 // ncclComm_t
+    int comm_rank = 0, comm_nranks = 1;
+    int comm_overlap = 1;                 // reduce buckets on comm_stream while backward still computes
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t comm_ready = nullptr;      // main stream: "this bucket's gradients are final"
+    hipEvent_t comm_done = nullptr;       // comm stream: "every bucket issued so far has been reduced"
+    size_t comm_covered = 0;              // floats of the gradient buffer already handed to the overlapped reduce
+    bool grads_reduced = false;           // the gradient buffer holds the SUM over ranks
+};
+
+namespace stattn_detail {
+
+extern std::string g_create_error;
+
+inline int fail(stattn_handle* h, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (h) h->err = buf; else g_create_error = buf;
+    return code;
+}
+
+#define HIPCHK(h, expr)                                                                         \
+    do {                                                                                        \
+        hipError_t e_ = (expr);                                                                 \
+        if (e_ != hipSuccess)                                                                   \
+            return fail(h, STATTN_EHIP, "%s failed: %s (%s:%d)", #expr, hipGetErrorString(e_),  \
+                        __FILE__, __LINE__);                                                    \
+    } while (0)
+
+#define CHK(expr) do { int rc_ = (expr); if (rc_ != STATTN_OK) return rc_; } while (0)
+
+inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+inline int getbuf(stattn_handle* h, const char* name, size_t nbytes, void** out) {
+    DevBuf& b = h->bufs[name];
+    HIPCHK(h, b.ensure(nbytes ? nbytes : 4));
+    *out = b.p;
+    return STATTN_OK;
+}
+template <class T>
+inline int getbuf_t(stattn_handle* h, const char* name, size_t n, T** out) {
+    void* p = nullptr;
+    CHK(getbuf(h, name, n * sizeof(T), &p));
+    *out = static_cast<T*>(p);
+    return STATTN_OK;
+}
+// the six input buffers of a minibatch exist twice (sets 0 and 1): one is read by forward / backward while the
+// other receives the next minibatch from pinned host memory on the copy stream
+inline std::string bset(const stattn_handle* h, const char* name, int set) { return set ? std::string(name) + "#1" : std::string(name); }
+inline std::string bcur(const stattn_handle* h, const char* name) { return bset(h, name, h->cur_set); }
+
+inline float* findbuf(stattn_handle* h, const char* name) {
+    auto it = h->bufs.find(name);
+    return it == h->bufs.end() ? nullptr : static_cast<float*>(it->second.p);
+}
+
+// comm.cpp
+int comm_reduce_range(stattn_handle* h, size_t off, size_t n);
+void comm_backward_begins(stattn_handle* h);
+void comm_release(stattn_handle* h);
+
+}  // namespace stattn_detail

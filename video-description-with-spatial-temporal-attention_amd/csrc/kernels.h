@@ -30,8 +30,7 @@ struct GemmArgs {
     float* ws; size_t ws_floats;
     int kbeg, kend, kslices;           // internal
     int xcd_remap;                     // internal: XCD-aware tile order on/off
-    int abl;                           // internal: ablation probe (0 in the product path)
-    long long* clk;                    // internal: clock probe slot {cycles0, wall0, cycles1, wall1} written by block 0 (null in the product path)
+    long long* clk;                    // internal: clock probe slot {cycles0, wall0, cycles1, wall1} written by block 0 (-DSTATTN_PROBES builds only)
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);
@@ -89,7 +88,6 @@ struct SkArgs {
     // kz-th K-slice and stores its raw partial tile to C + z * part_stride; the consumer sums the kz partials
     // in a fixed order.  No epilogue terms on that path.
     int kz; size_t part_stride;
-    int dbg;                        // ablation switch for tools/skinny_probe.py (0 in the product path)
 };
 void skinny_seg_defaults(SkSeg& s);
 hipError_t launch_skinny(hipStream_t s, const SkArgs& a);

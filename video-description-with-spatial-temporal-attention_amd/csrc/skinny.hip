@@ -35,14 +35,11 @@ constexpr int TILE_N = 64;
 // kernel is otherwise a chain of exposed HBM/L2 latencies (measured 18.8 us vs 9 us for h.[Wd*|U]).
 struct SkOperands { float4 a; float4 b[4]; };
 
-template <int SKIP = 0>   // ablation: 1 = no A loads, 2 = no B loads
 __device__ __forceinline__ void sk_load(SkOperands& o, const float* __restrict__ Ap, const float* __restrict__ Bp, int ldb, int s) {
     const int k0 = s << 4;
-    if (SKIP != 1) o.a = ld4(Ap + k0);
-    if (SKIP != 2) {
+    o.a = ld4(Ap + k0);
 #pragma unroll
-        for (int q = 0; q < 4; ++q) o.b[q] = ld4(Bp + (size_t)(k0 + q) * ldb);
-    }
+    for (int q = 0; q < 4; ++q) o.b[q] = ld4(Bp + (size_t)(k0 + q) * ldb);
 }
 __device__ __forceinline__ void sk_mfma(f32x4 (&acc)[4], const SkOperands& o) {
     const float av[4] = {o.a.x, o.a.y, o.a.z, o.a.w};
@@ -54,7 +51,6 @@ __device__ __forceinline__ void sk_mfma(f32x4 (&acc)[4], const SkOperands& o) {
         acc[3] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[q], o.b[q].w, acc[3], 0, 0, 0);
     }
 }
-template <int SKIP = 0>
 __device__ __forceinline__ void sk_accumulate(f32x4 (&acc)[4], const SkPair& p, int arow, int bcol,
                                               int ks, int nks, int g) {   // ks / nks: global K-slice index / count
     const int nsteps = p.K >> 4;
@@ -65,60 +61,23 @@ __device__ __forceinline__ void sk_accumulate(f32x4 (&acc)[4], const SkPair& p, 
     int s = ks;
     if (s >= nsteps) return;
     SkOperands o0, o1;
-    o0.a = make_float4(1.f, 2.f, 3.f, 4.f); o1.a = o0.a;
-    for (int q = 0; q < 4; ++q) { o0.b[q] = o0.a; o1.b[q] = o0.a; }
-    sk_load<SKIP>(o0, Ap, Bp, ldb, s);
+    sk_load(o0, Ap, Bp, ldb, s);
     // The prefetch is UNCONDITIONAL (at the tail it re-requests the current step, an L1/L2 hit): a branch
     // around the loads makes hipcc count vmcnt for the no-load path and the wait then drains the prefetch too.
     while (true) {
         int sn = s + nks;
-        sk_load<SKIP>(o1, Ap, Bp, ldb, sn < nsteps ? sn : s);
+        sk_load(o1, Ap, Bp, ldb, sn < nsteps ? sn : s);
         __builtin_amdgcn_sched_barrier(0);      // keep the prefetch ABOVE the MFMAs (hipcc sinks it to its first use)
         sk_mfma(acc, o0);
         __builtin_amdgcn_sched_barrier(0);
         if (sn >= nsteps) break;
         s = sn; sn = s + nks;
-        sk_load<SKIP>(o0, Ap, Bp, ldb, sn < nsteps ? sn : s);
+        sk_load(o0, Ap, Bp, ldb, sn < nsteps ? sn : s);
         __builtin_amdgcn_sched_barrier(0);
         sk_mfma(acc, o1);
         __builtin_amdgcn_sched_barrier(0);
         if (sn >= nsteps) break;
         s = sn;
-    }
-}
-
-// same, two steps ahead (three register sets)
-__device__ __forceinline__ void sk_accumulate3(f32x4 (&acc)[4], const SkPair& p, int arow, int bcol,
-                                               int ks, int nks, int g) {
-    const int nsteps = p.K >> 4;
-    const float* __restrict__ Ap = p.A + (size_t)arow * p.lda + 4 * g;
-    const float* __restrict__ Bp = p.B + (size_t)(4 * g) * p.ldb + bcol;
-    int s = ks;
-    if (s >= nsteps) return;
-    const int last = s + ((nsteps - 1 - s) / nks) * nks;      // last step of this wave
-    auto clampi = [&](int x) { return x <= last ? x : last; };
-    SkOperands o0, o1, o2;
-    sk_load(o0, Ap, Bp, p.ldb, s);
-    sk_load(o1, Ap, Bp, p.ldb, clampi(s + nks));
-    while (true) {
-        sk_load(o2, Ap, Bp, p.ldb, clampi(s + 2 * nks));
-        __builtin_amdgcn_sched_barrier(0);
-        sk_mfma(acc, o0);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + nks > last) break;
-        s += nks;
-        sk_load(o0, Ap, Bp, p.ldb, clampi(s + 2 * nks));
-        __builtin_amdgcn_sched_barrier(0);
-        sk_mfma(acc, o1);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + nks > last) break;
-        s += nks;
-        sk_load(o1, Ap, Bp, p.ldb, clampi(s + 2 * nks));
-        __builtin_amdgcn_sched_barrier(0);
-        sk_mfma(acc, o2);
-        __builtin_amdgcn_sched_barrier(0);
-        if (s + nks > last) break;
-        s += nks;
     }
 }
 
@@ -130,7 +89,6 @@ __device__ __forceinline__ void sk_spill(float* red, int w, const f32x4 (&acc)[4
             make_float4(acc[0][r], acc[1][r], acc[2][r], acc[3][r]));
 }
 
-// a.dbg (ablation, tools/skinny_probe.py): 1 = loads only, 2 = MFMAs only, 4 = skip the LDS reduction + epilogue
 __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int mtb) {
     __shared__ __attribute__((aligned(16))) float red[NW * 16 * TILE_N];
     // locate the segment of this column tile
@@ -150,40 +108,8 @@ __global__ __launch_bounds__(1024) void skinny_kernel(const SkArgs a, const int 
 #pragma unroll
     for (int q = 0; q < 4; ++q) acc[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     const int kz = a.kz > 1 ? a.kz : 1;
-    if (a.dbg & 3) {
-        for (int p = 0; p < sg.npairs; ++p) {
-            const SkPair& pr = sg.p[p];
-            const float* Ap = pr.A + (size_t)arow * pr.lda + 4 * g;
-            const float* Bp = pr.B + (size_t)(4 * g) * pr.ldb + n0 + 4 * j;
-            SkOperands o;
-            o.a = make_float4(1.f, 2.f, 3.f, 4.f);
-            for (int q = 0; q < 4; ++q) o.b[q] = make_float4(1.f, 2.f, 3.f, 4.f);
-            for (int st = (int)blockIdx.z * nks + ks; st < (pr.K >> 4); st += nks * kz) {
-                if (a.dbg & 1) {
-                    sk_load(o, Ap, Bp, pr.ldb, st);
-                    asm volatile("" :: "v"(o.a.x), "v"(o.b[0].x), "v"(o.b[1].x), "v"(o.b[2].x), "v"(o.b[3].x));
-                } else {
-                    sk_mfma(acc, o);
-                }
-            }
-        }
-    } else if (a.dbg == 32) {
-        for (int p = 0; p < sg.npairs; ++p)
-            sk_accumulate<1>(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
-    } else if (a.dbg == 64) {
-        for (int p = 0; p < sg.npairs; ++p)
-            sk_accumulate<2>(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
-    } else if (a.dbg & 8) {
-        for (int p = 0; p < sg.npairs; ++p)
-            sk_accumulate3(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
-    } else {
-        for (int p = 0; p < sg.npairs; ++p)
-            sk_accumulate(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
-    }
-    if (a.dbg & 4) {
-        if (acc[0][0] + acc[1][1] + acc[2][2] + acc[3][3] == 12345.678f) sg.C[0] = 1.f;
-        return;
-    }
+    for (int p = 0; p < sg.npairs; ++p)
+        sk_accumulate(acc, sg.p[p], arow, n0 + 4 * j, (int)blockIdx.z * nks + ks, nks * kz, g);
     sk_spill(red, w, acc, j, g);
     __syncthreads();
 
@@ -385,7 +311,7 @@ hipError_t launch_skinny(hipStream_t s, const SkArgs& a) {
     for (int i = 0; i < a.nseg; ++i)
         for (int p = 0; p < a.seg[i].npairs; ++p) packed = packed || a.seg[i].p[p].tile_stride != 0;
     static const char* noshare = getenv("STATTN_SKINNY_NOSHARE");
-    if (mtb >= 2 && !packed && !a.dbg && !noshare) hipLaunchKernelGGL(skinny_shared_kernel, grid, block, 0, s, a, mtb);
+    if (mtb >= 2 && !packed && !noshare) hipLaunchKernelGGL(skinny_shared_kernel, grid, block, 0, s, a, mtb);
     else hipLaunchKernelGGL(skinny_kernel, grid, block, 0, s, a, mtb);
     return hipGetLastError();
 }

@@ -16,7 +16,6 @@ keep working against this class:
 The Theano graph is replaced by libstattn.so (hand-written gfx950 kernels behind a C ABI);
 the symbolic variables build_model returns are inert name tags that `function()` below
 recognises when it stands in for `theano.function` (f_log_probs, :1126; f_alpha*, :1167-1188)."""
-import copy
 import warnings
 from collections import OrderedDict
 
@@ -234,18 +233,19 @@ class Attention(object):
         except ImportError:
             import dp
         dec = self._bind(tparams, options)
+        reducer = dp.GradReducer(dec, group) if global_batch else None    # rank-distinct dropout seed inside
 
         def f_grad_shared(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):
             dec.set_batch(x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm)
             dec.forward_train()
             gb = global_batch if global_batch else x.shape[1]
             dec.backward(nll_scale=1.0 / gb, alpha_c=alpha_c)
-            if global_batch:
-                if not hasattr(dec, '_grad_view'):
-                    dec._grad_view = dp.grad_tensor(dec)
-                dp.allreduce_sum(dec._grad_view, group)
             r = dec.get_forward(probs=True, alphas=True)
-            out = [numpy.float32(dec.get_loss(decay_c)), r['probs'], r['alphal'], r['alphag'], r['alpham'], r['alphalt']]
+            loss = dec.get_loss(decay_c)
+            if reducer is not None:
+                reducer.allreduce()                       # ordered with the library's stream on both sides
+                loss = reducer.global_loss(loss, dec, decay_c)
+            out = [numpy.float32(loss), r['probs'], r['alphal'], r['alphag'], r['alpham'], r['alphalt']]
             if return_grads:
                 out += list(dec.get_grads().values())
             return out
@@ -277,8 +277,14 @@ class Attention(object):
         f_log_probs = self.function(inps, -cost, tparams=tparams)
         f_grad_shared, f_update = self.build_train_functions(tparams, options, decay_c, alpha_c, clip_c)
         best_p, bad_counter, uidx, estop = None, 0, 0, False
+        if iter(batches) is batches:              # a generator would be exhausted after the first epoch
+            batches = list(batches)
+        if valid_batches is not None and iter(valid_batches) is valid_batches:
+            valid_batches = list(valid_batches)
         for eidx in range(max_epochs):
             for batch in batches:
+                if batch[0] is None:              # "Minibatch with zero sample under length" (:1252-1254)
+                    continue
                 uidx += 1
                 use_noise.set_value(1.)
                 c = f_grad_shared(*batch)[0]
@@ -312,85 +318,61 @@ class Attention(object):
     # ---------------------------------------------------------------- beam search driver
     def gen_sample(self, tparams, f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, options,
                    trng=None, k=1, maxlen=30, stochastic=False, restrict_voc=False):
-        """model_attention.py:852-994, host-side beam search around f_next.  Python-2 integer
-        division at :926 becomes `//`."""
-        if k > 1:
-            assert not stochastic, 'Beam search does not support stochastic sampling'
-        sample = []
-        sample_score = []
+        """Host-side driver of the sampler with the contract of model_attention.py:852-994: beam search of width k
+        (k = 1: greedy), or ancestral sampling when `stochastic`.  Returns (sample, sample_score, next_state,
+        next_memory): hypotheses that ended with <eos> in the order they ended, then the ones still alive;
+        sample_score = summed -log p, no length normalisation (metrics.py:130 takes the argmin); next_state /
+        next_memory are one-element lists (n_layers_lstm = 1), like the reference's.
+
+        The candidate table of one step is the (live, V) matrix `cost[i] - log p[i, w]`; its (k - finished) smallest
+        entries are taken with one argsort over the flattened table and split back into (parent row, word) with
+        integer division (the reference's Python-2 `/` at :926).  Survivors are gathered with fancy indexing.
+        When `f_next` belongs to this package, the video is staged once for the whole loop (Decoder.video_scope)."""
+        if k > 1 and stochastic:
+            raise AssertionError('Beam search does not support stochastic sampling')
+        if restrict_voc:
+            raise NotImplementedError()
+        dec = getattr(f_next, 'decoder', None)
+        if dec is None:
+            return self._decode_loop(f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, k, maxlen, stochastic)
+        with dec.video_scope(ctxg_0, ctxl_0, ctxm_0):
+            return self._decode_loop(f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, k, maxlen, stochastic)
+
+    @staticmethod
+    def _decode_loop(f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, k, maxlen, stochastic):
+        ended, ended_cost = [], []                       # finished hypotheses, in order of death
+        prefixes, cost = [[]], numpy.zeros(1, dtype='float32')
+        drawn, drawn_score = [], 0
+        _, h0, c0 = f_init(ctxg_0, ctxg_mask)
+        state, memory = [h0[None, :]], [c0[None, :]]
+        words = numpy.full((1,), -1, dtype='int64')      # -1: no previous word (:803-804)
+        for _step in range(maxlen):
+            probs, words, h, c = f_next(words, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, state[0], memory[0])
+            state, memory = [h], [c]
+            if stochastic:                               # :913-918 (the score sums p, not log p, as the reference does)
+                drawn.append(words[0])
+                drawn_score += probs[0, words[0]]
+                if words[0] == 0:
+                    break
+                continue
+            with numpy.errstate(divide='ignore'):
+                table = (cost[:, None] - numpy.log(probs)).ravel()
+            best = table.argsort()[:k - len(ended)]
+            parent, word = best // probs.shape[1], best % probs.shape[1]
+            grown_cost = table[best].astype('float32')
+            alive = word != 0
+            for i in numpy.flatnonzero(~alive):          # <eos>: the hypothesis leaves the beam (:956-960)
+                ended.append(prefixes[parent[i]] + [int(word[i])])
+                ended_cost.append(grown_cost[i])
+            prefixes = [prefixes[p] + [int(w)] for p, w in zip(parent[alive], word[alive])]
+            cost = grown_cost[alive]
+            if not prefixes or len(ended) >= k:
+                break
+            words = word[alive].astype('int64')
+            state, memory = [h[parent[alive]]], [c[parent[alive]]]
         if stochastic:
-            sample_score = 0
-        live_k = 1
-        dead_k = 0
-        hyp_samples = [[]] * live_k
-        hyp_scores = numpy.zeros(live_k).astype('float32')
-        rval = f_init(ctxg_0, ctxg_mask)
-        ctxg_0 = rval[0]
-        next_state = rval[1].reshape([live_k, rval[1].shape[0]])
-        next_memory = rval[2].reshape([live_k, rval[2].shape[0]])
-        next_w = -1 * numpy.ones((1,)).astype('int64')
-        for ii in range(maxlen):
-            rval = f_next(next_w, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, next_state, next_memory)
-            next_p = rval[0]
-            if restrict_voc:
-                raise NotImplementedError()
-            next_w = rval[1]
-            next_state = rval[2]
-            next_memory = rval[3]
-            if stochastic:
-                sample.append(next_w[0])
-                sample_score += next_p[0, next_w[0]]
-                if next_w[0] == 0:
-                    break
-            else:
-                with numpy.errstate(divide='ignore'):
-                    cand_scores = hyp_scores[:, None] - numpy.log(next_p)
-                cand_flat = cand_scores.flatten()
-                ranks_flat = cand_flat.argsort()[:(k - dead_k)]
-                voc_size = next_p.shape[1]
-                trans_indices = ranks_flat // voc_size
-                word_indices = ranks_flat % voc_size
-                costs = cand_flat[ranks_flat]
-                new_hyp_samples = []
-                new_hyp_scores = numpy.zeros(k - dead_k).astype('float32')
-                new_hyp_states = []
-                new_hyp_memories = []
-                for idx, [ti, wi] in enumerate(zip(trans_indices, word_indices)):
-                    new_hyp_samples.append(hyp_samples[ti] + [int(wi)])
-                    new_hyp_scores[idx] = copy.copy(costs[idx])
-                    new_hyp_states.append(copy.copy(next_state[ti]))
-                    new_hyp_memories.append(copy.copy(next_memory[ti]))
-                new_live_k = 0
-                hyp_samples = []
-                hyp_scores = []
-                hyp_states = []
-                hyp_memories = []
-                for idx in range(len(new_hyp_samples)):
-                    if new_hyp_samples[idx][-1] == 0:
-                        sample.append(new_hyp_samples[idx])
-                        sample_score.append(new_hyp_scores[idx])
-                        dead_k += 1
-                    else:
-                        new_live_k += 1
-                        hyp_samples.append(new_hyp_samples[idx])
-                        hyp_scores.append(new_hyp_scores[idx])
-                        hyp_states.append(new_hyp_states[idx])
-                        hyp_memories.append(new_hyp_memories[idx])
-                hyp_scores = numpy.array(hyp_scores)
-                live_k = new_live_k
-                if new_live_k < 1:
-                    break
-                if dead_k >= k:
-                    break
-                next_w = numpy.array([w[-1] for w in hyp_samples]).astype('int64')
-                next_state = numpy.array(hyp_states)
-                next_memory = numpy.array(hyp_memories)
-        if not stochastic:
-            if live_k > 0:
-                for idx in range(live_k):
-                    sample.append(hyp_samples[idx])
-                    sample_score.append(hyp_scores[idx])
-        return sample, sample_score, next_state, next_memory
+            return drawn, drawn_score, state, memory
+        return ended + prefixes, ended_cost + list(cost), state, memory
 
     def gen_sample_batch(self, tparams, options, ctxgs, ctxg_masks, ctxls, ctxms, k=5, maxlen=30, suppress_eos=False):
         """Batched counterpart of the evaluation loop of metrics.py:121-135 (one gen_sample per video): all videos
@@ -401,16 +383,14 @@ class Attention(object):
 
     # ---------------------------------------------------------------- teacher-forced scoring
     def pred_probs(self, batches, f_log_probs, verbose=False):
-        """model_attention.py:996-1032 over an iterable of prepare_data() 8-tuples: mean NLL and
-        perplexity 2 ** (sum NLL / sum L / ln 2)."""
-        probs, NLL, L = [], [], []
-        for (x, mask, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask) in batches:
-            pred = f_log_probs(x, mask, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask)
-            L.append(mask.sum(0).tolist())
-            NLL.append((-1 * pred).tolist())
-            probs.append(pred.tolist())
-        probs = common.flatten_list_of_list(probs)
-        NLL = common.flatten_list_of_list(NLL)
-        L = common.flatten_list_of_list(L)
-        perp = 2 ** (numpy.sum(NLL) / numpy.sum(L) / numpy.log(2))
-        return -1 * numpy.mean(probs), perp
+        """Teacher-forced scoring of a split with the contract of model_attention.py:996-1032: `batches` yields
+        prepare_data() 8-tuples, f_log_probs returns -cost per caption.  Returns (mean NLL per caption,
+        perplexity = 2 ** (sum NLL / number of words / ln 2))."""
+        nll, nwords = [], 0.0
+        for batch in batches:
+            if batch[0] is None:                 # prepare_data found no usable caption (data_engine.py:318)
+                continue
+            nll.append(-numpy.asarray(f_log_probs(*batch), dtype='float64'))
+            nwords += float(numpy.asarray(batch[1]).sum())
+        nll = numpy.concatenate(nll) if nll else numpy.zeros(0)
+        return nll.mean(), 2 ** (nll.sum() / nwords / numpy.log(2))

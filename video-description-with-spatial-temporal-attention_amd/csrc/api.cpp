@@ -1032,7 +1032,7 @@ int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int 
     HIPCHK(h, hipMemcpyAsync(rm, ctxm, (size_t)m * T * h->Fm * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
     h->t = t; h->m = m; h->T = T; h->K = K;
-    h->have_batch = true; h->have_fwd = false;
+    h->have_batch = true; h->have_fwd = false; h->have_bwd = false;
     return STATTN_OK;
 }
 
@@ -1241,7 +1241,7 @@ int stattn_forward_train(stattn_handle* h) {
     }
     HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, dx, nll, nullptr, (int)R, V));
     HIPCHK(h, launch_cost(s, nll, dmask, cost, t, m));
-    h->have_fwd = true;
+    h->have_fwd = true; h->have_bwd = false;      // fresh logits; any earlier gradient belongs to another pass
     return STATTN_OK;
 }
 

@@ -21,7 +21,7 @@ def _setup(dims, seed, **optkw):
     return O, opt, P, dec
 
 
-def _check_grads(got, ref, rtol=2e-3):
+def _check_grads(got, ref, rtol=1e-4):
     """per-parameter: max abs error relative to the parameter's own gradient scale"""
     bad = []
     for k in ref:

@@ -364,6 +364,25 @@ def test_hip_path_matches_committed_golden_vectors(stattn_mod, O):
                 h = sc['m%d_s%d_h' % (mm, s)].astype(np.float32); c = sc['m%d_s%d_c' % (mm, s)].astype(np.float32)
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (17, 48, 64), (33, 16, 32), (70, 96, 256), (160, 64, 512), (256, 32, 48),
+                                   (64, 8192, 1024), (64, 1024, 4096)])
+def test_row_panel_gemm_matches_float64(stattn_mod, O, M, N, K):
+    """panel.hip: every row in one workgroup, 16 / 32-column panels repacked in MFMA operand order -- all row-group
+    geometries (1..16 m-tiles), both tile widths, and the transposed-source packing of the reverse scan."""
+    dec = _decoder(stattn_mod, O, SMALL, 1)[3]
+    rng = np.random.RandomState(M + N + K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
+    add = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    np.testing.assert_allclose(dec.gemm(A, B, kind=3), ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
+    np.testing.assert_allclose(dec.gemm(A, np.ascontiguousarray(B.T), kind=3, transB=True), ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
+    if K <= 1024:        # (longer sums: the fp32 rounding of the pre-activation, amplified by tanh'(0) = 1, exceeds 1e-5)
+        out = dec.gemm(0.1 * A, B, bias=bias, add=add, act=1, kind=3)
+        np.testing.assert_allclose(out, np.tanh(0.1 * ref + bias + add), atol=1e-5, rtol=1e-5)
+
+
 # ------------------------------------------------------------------ BASELINE.json configs[3], configs[4] shapes
 def test_c4_msrvtt_shape_fp32(stattn_mod, O):
     """configs[3] 'MSR-VTT-shape stress': T=40, K=16 regions (two region groups in the kernels), feat=2048,

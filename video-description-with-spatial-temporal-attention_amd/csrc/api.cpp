@@ -258,6 +258,62 @@ int init_state(stattn_handle* h, int nv, int T, const float* G, const float* mas
     return STATTN_OK;
 }
 
+// ---- packed weight panels of the per-step kernels (panel.hip).  Repacked at the start of every pass that uses them
+// (the parameters may have changed through set_param / update / a broadcast): ~50 MB of copies against 30 steps.
+struct FwdPanels { float *Wd, *U, *Wc, *W, *Wl1, *Wl2, *Wo; };
+struct BwdPanels { float *WcT, *UT, *WdT; };
+
+bool use_panels(const stattn_handle* h, int M) {
+    static const char* off = getenv("STATTN_NO_PANELS");       // A/B switch for tools
+    return !off && M > 16 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
+}
+
+int pack(stattn_handle* h, const float* W, int ldw, int src_t, int K, int ntiles, int cols, float* dst, int S_total = 0, int s_off = 0) {
+    PackJob jb{};
+    jb.W = W; jb.ldw = ldw; jb.src_t = src_t; jb.K = K; jb.ntiles = ntiles; jb.cols = cols; jb.D = h->D;
+    jb.dst = dst; jb.S_total = S_total ? S_total : K / 16; jb.s_off = s_off;
+    HIPCHK(h, launch_pack_panels(h->stream, jb));
+    return STATTN_OK;
+}
+
+int pack_fwd_panels(stattn_handle* h, FwdPanels* p, bool readout) {
+    const int D = h->D, E = h->E, Vp = h->Vp;
+    const Weights& w = h->w;
+    CHK(getbuf_t(h, "pn_Wd", (size_t)4 * D * D, &p->Wd));
+    CHK(getbuf_t(h, "pn_U", (size_t)4 * D * D, &p->U));
+    CHK(getbuf_t(h, "pn_Wc", (size_t)4 * D * D, &p->Wc));
+    const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
+    for (int i = 0; i < 4; ++i) CHK(pack(h, Wd[i], D, 0, D, D / 16, PN_COLS_PLAIN, p->Wd + (size_t)i * D * D));
+    CHK(pack(h, w.U, 4 * D, 0, D, 4 * D / 16, PN_COLS_PLAIN, p->U));
+    CHK(pack(h, w.Wc, 4 * D, 0, D, D / 4, PN_COLS_LSTM, p->Wc));
+    p->W = p->Wl1 = p->Wl2 = p->Wo = nullptr;
+    if (readout) {      // sampler: emb.W joins the LSTM GEMM, and the readout MLP runs per step
+        CHK(getbuf_t(h, "pn_W", (size_t)E * 4 * D, &p->W));
+        CHK(getbuf_t(h, "pn_Wl1", (size_t)D * E, &p->Wl1));
+        CHK(getbuf_t(h, "pn_Wl2", (size_t)D * E, &p->Wl2));
+        CHK(getbuf_t(h, "pn_Wo", (size_t)E * Vp, &p->Wo));
+        CHK(pack(h, w.W, 4 * D, 0, E, D / 4, PN_COLS_LSTM, p->W));
+        CHK(pack(h, w.Wl1, E, 0, D, E / 16, PN_COLS_PLAIN, p->Wl1));
+        if (h->opt.ctx2out) CHK(pack(h, w.Wl2, E, 0, D, E / 16, PN_COLS_PLAIN, p->Wl2));
+        CHK(pack(h, w.Wo, Vp, 0, E, Vp / 16, PN_COLS_PLAIN, p->Wo));
+    }
+    return STATTN_OK;
+}
+
+// transposed recurrent weights of the reverse scan, packed straight from the untransposed parameters
+int pack_bwd_panels(stattn_handle* h, BwdPanels* p) {
+    const int D = h->D;
+    const Weights& w = h->w;
+    CHK(getbuf_t(h, "pn_WcT", (size_t)4 * D * D, &p->WcT));
+    CHK(getbuf_t(h, "pn_UT", (size_t)4 * D * D, &p->UT));
+    CHK(getbuf_t(h, "pn_WdT", (size_t)4 * D * D, &p->WdT));
+    CHK(pack(h, w.Wc, 4 * D, 1, 4 * D, D / 16, PN_COLS_PLAIN, p->WcT));
+    CHK(pack(h, w.U, 4 * D, 1, 4 * D, D / 16, PN_COLS_PLAIN, p->UT));
+    const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
+    for (int i = 0; i < 4; ++i) CHK(pack(h, Wd[i], D, 1, D, D / 16, PN_COLS_PLAIN, p->WdT, 4 * D / 16, i * D / 16));
+    return STATTN_OK;
+}
+
 struct StepIO {
     int M, T, K;
     CtxPtrs c; const int* vid;
@@ -268,13 +324,31 @@ struct StepIO {
     const float* dp; const float* mask; const float* d1;
     float *alphal, *CL, *eg, *em, *elt, *plt, *alphag, *alpham, *alphalt, *csum, *sel, *ctx;
     float *h_out, *c_out, *gates, *hd;
+    const FwdPanels* pn;             // packed weight panels, or null -> the 64-column skinny kernels
+    const float* h_prev_pk;          // with pn: h_prev in the packed A layout (or null: plain rows are gathered)
+    float *h_out_pk, *ctx_pk;        // with pn: packed copies written by the LSTM / temporal kernels (or null)
 };
 
 // one decoder timestep: _step, model_attention.py:366-459
 int run_step(stattn_handle* h, const StepIO& io) {
     const int D = h->D, E = h->E;
     const Weights& w = h->w;
-    {   // state projections: h.[Wdl | Wdg | Wdm | Wdlt] -> sproj, h.U (+ x_) -> preh   (:371, 389, 402, 415, 437-438)
+    if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
+        Prof pr(h, KC_HPROJ);
+        PnArgs a{};
+        a.M = io.M; a.nseg = 2;
+        PnSeg& s0 = a.seg[0];
+        pn_seg_defaults(s0);
+        const PnPair hA = io.h_prev_pk ? PnPair{io.h_prev_pk, D, nullptr, D, 1} : PnPair{io.h_prev, D, nullptr, D, 0};
+        s0.npairs = 1; s0.p[0] = hA; s0.p[0].P = io.pn->Wd;
+        s0.C = io.sproj; s0.ldc = 4 * D; s0.N = 4 * D;         // [Wdl | Wdg | Wdm | Wdlt]: 4 x D/16 consecutive tiles
+        PnSeg& s1 = a.seg[1];
+        pn_seg_defaults(s1);
+        s1.npairs = 1; s1.p[0] = hA; s1.p[0].P = io.pn->U;
+        s1.C = io.preh; s1.ldc = 4 * D; s1.N = 4 * D;
+        if (io.xproj) { s1.add = io.xproj; s1.ldadd = 4 * D; }
+        HIPCHK(h, launch_panel(h->stream, a));
+    } else {   // state projections: h.[Wdl | Wdg | Wdm | Wdlt] -> sproj, h.U (+ x_) -> preh   (:371, 389, 402, 415, 437-438)
         Prof pr(h, KC_HPROJ);
         SkArgs a{};
         a.M = io.M; a.nseg = 5;
@@ -321,11 +395,23 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.eg = io.eg; a.em = io.em; a.elt = io.elt; a.G = io.c.G; a.Mo = io.c.Mo; a.vid = io.vid; a.CL = io.CL;
         a.h_prev = io.h_prev; a.W_sel = h->opt.selector ? w.W_sel : nullptr; a.b_sel = w.b_sel;
         a.alphag = io.alphag; a.alpham = io.alpham; a.alphalt = io.alphalt;
-        a.csum = io.csum; a.sel = io.sel; a.ctx = io.ctx;
+        a.csum = io.csum; a.sel = io.sel; a.ctx = io.ctx; a.ctx_pk = io.pn ? io.ctx_pk : nullptr;
         a.M = io.M; a.T = io.T; a.D = D;
         HIPCHK(h, launch_temporal(h->stream, a));
     }
-    {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457)
+    if (io.pn) {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457) on the row-panel kernel
+        Prof pr(h, KC_LSTM);
+        LstmPnArgs a{};
+        a.npairs = 1; a.p[0] = io.ctx_pk ? PnPair{io.ctx_pk, D, io.pn->Wc, D, 1} : PnPair{io.ctx, D, io.pn->Wc, D, 0};
+        if (io.emb) { a.p[1] = PnPair{io.emb, E, io.pn->W, E, 0}; a.npairs = 2; a.bias = w.b; }
+        a.h_pk = io.h_out_pk;
+        a.pre_add = io.preh; a.ldpre = 4 * D;
+        a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
+        a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
+        a.d1 = io.d1; a.ldd1 = D; a.d1_scalar = 0.5f; a.hd_out = io.hd;
+        a.M = io.M; a.D = D;
+        HIPCHK(h, launch_lstm_panel(h->stream, a));
+    } else {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457)
         Prof pr(h, KC_LSTM);
         LstmArgs a{};
         a.npairs = 1; a.p[0] = SkPair{io.ctx, w.Wc, D, 4 * D, D, 0};
@@ -698,6 +784,7 @@ int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, 
     io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
     io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
     io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+    io.pn = nullptr;              // a handful of rows per call: the 64-column skinny kernels (no repacking per call)
     CHK(run_step(h, io));
 
     {   // readout (:817-838): a = 0.5 * tanh(0.5h.Wl1 + bl1 [+ emb] [+ ctx.Wl2 + bl2]); logit = a.Wo + bo
@@ -871,6 +958,9 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
 
     // one decoded word = a fixed sequence of 15 kernel launches whose arguments depend on the word index only through
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
+    FwdPanels pn{};
+    const bool panels = use_panels(h, M) && Vp % 16 == 0;
+    if (panels) CHK(pack_fwd_panels(h, &pn, true));
     auto enqueue_word = [&](int parity) -> int {
         HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0));
         StepIO io{};
@@ -880,8 +970,28 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
         io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
         io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+        io.pn = panels ? &pn : nullptr;
         CHK(run_step(h, io));
-        {
+        if (panels) {      // readout (:817-838) on the row-panel kernel
+            PnArgs a{};
+            a.M = M; a.nseg = 1;
+            PnSeg& sg = a.seg[0];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{hd, D, pn.Wl1, D};
+            if (h->opt.ctx2out) { sg.p[1] = PnPair{ctx, D, pn.Wl2, D}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.bias = w.bl1;
+            if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+            sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+            HIPCHK(h, launch_panel(s, a));
+            PnArgs b{};
+            b.M = M; b.nseg = 1;
+            PnSeg& so = b.seg[0];
+            pn_seg_defaults(so);
+            so.npairs = 1; so.p[0] = PnPair{a1, E, pn.Wo, E};
+            so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+            HIPCHK(h, launch_panel(s, b));
+            HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
+        } else {
             SkArgs a{};
             a.M = M; a.nseg = 1;
             SkSeg& sg = a.seg[0];
@@ -932,7 +1042,9 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                           (const void*)co, (const void*)hd, (const void*)emb, (const void*)sproj, (const void*)preh, (const void*)dp,
                           (const void*)al, (const void*)CL, (const void*)eg, (const void*)em, (const void*)elt, (const void*)plt,
                           (const void*)ag, (const void*)am, (const void*)alt, (const void*)ctx, (const void*)a1, (const void*)lg,
-                          (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx})
+                          (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
+                          (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
+                          (const void*)pn.Wo})
         sig.push_back((uintptr_t)q);
     if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
         gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is
@@ -1179,6 +1291,21 @@ int stattn_forward_train(stattn_handle* h) {
     }
 
     // ---- the scan over caption positions (:495-512)
+    FwdPanels pn{};
+    const bool panels = use_panels(h, m);
+    float *hpk[2] = {nullptr, nullptr}, *ctxpk = nullptr;
+    if (panels) {
+        CHK(pack_fwd_panels(h, &pn, false));
+        // packed-A copies of the recurrent state (ping-pong: step s reads one and writes the other) and of ctx
+        CHK(getbuf_t(h, "pk_h0", packed_rows_floats(m, D), &hpk[0]));
+        CHK(getbuf_t(h, "pk_h1", packed_rows_floats(m, D), &hpk[1]));
+        CHK(getbuf_t(h, "pk_ctx", packed_rows_floats(m, D), &ctxpk));
+        HIPCHK(h, launch_pack_rows(s, hs, D, m, D, hpk[0]));
+        if (m % 16) {     // the rows past m of the last m-tile are read (and ignored): keep them finite
+            HIPCHK(h, hipMemsetAsync(hpk[1], 0, packed_rows_floats(m, D) * sizeof(float), s));
+            HIPCHK(h, hipMemsetAsync(ctxpk, 0, packed_rows_floats(m, D) * sizeof(float), s));
+        }
+    }
     for (int st = 0; st < t; ++st) {
         const size_t r0 = (size_t)st * m;
         StepIO io{};
@@ -1192,6 +1319,8 @@ int stattn_forward_train(stattn_handle* h) {
         io.alphag = ag + r0 * T; io.alpham = am + r0 * T; io.alphalt = alt + r0 * T;
         io.csum = csum + r0 * D; io.sel = sel + r0; io.ctx = ctx + r0 * D;
         io.h_out = hs + (r0 + m) * D; io.c_out = cs + (r0 + m) * D; io.gates = gates + r0 * 4 * D; io.hd = hd + r0 * D;
+        io.pn = panels ? &pn : nullptr;
+        io.h_prev_pk = hpk[st & 1]; io.h_out_pk = hpk[(st & 1) ^ 1]; io.ctx_pk = ctxpk;
         CHK(run_step(h, io));
     }
 
@@ -1410,10 +1539,19 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     }
     CHK(region_done("ff_logit_lstm_W", nullptr));     // final before the reverse scan even starts
 
-    // ---- transposed copies of the recurrent weights for the backward skinny GEMMs
-    HIPCHK(h, launch_transpose(s, w.U, 4 * D, UT, D, D, 4 * D));
-    HIPCHK(h, launch_transpose(s, w.Wc, 4 * D, WcT, D, D, 4 * D));
-    {
+    // ---- transposed recurrent weights of the reverse scan: packed panels (row-panel kernels) or plain transposed
+    // copies (skinny kernels)
+    BwdPanels bp{};
+    const bool panels = use_panels(h, m);
+    int kz1 = KZ1, kz2 = KZ2;
+    if (panels) {
+        CHK(pack_bwd_panels(h, &bp));
+        // K split so that the launch fills the chip: 2 D / 16 column tiles (dctx | dhU), D / 16 (dhW)
+        kz1 = 256 / (2 * D / 16); kz1 = kz1 < 1 ? 1 : (kz1 > KZ1 ? KZ1 : kz1);
+        kz2 = 256 / (D / 16); kz2 = kz2 < 1 ? 1 : (kz2 > KZ2 ? KZ2 : kz2);
+    } else {
+        HIPCHK(h, launch_transpose(s, w.U, 4 * D, UT, D, D, 4 * D));
+        HIPCHK(h, launch_transpose(s, w.Wc, 4 * D, WcT, D, D, 4 * D));
         const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
         for (int i = 0; i < 4; ++i) HIPCHK(h, launch_transpose(s, Wd[i], D, WdT + (size_t)i * D * D, D, D, D));
     }
@@ -1425,14 +1563,24 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         const bool last = (st == t - 1);
         {
             LstmBwdArgs a{};
-            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = KZ1; a.dhW = dhWP; a.nW = KZ2;
+            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = kz1; a.dhW = dhWP; a.nW = kz2;
             a.dselpre = dselpre + (r0 + m); a.W_sel = h->opt.selector ? w.W_sel : nullptr;
             a.dhd = dhd + r0 * D; a.d1 = d1 + r0 * D; a.gates = gates + r0 * 4 * D;
             a.c_prev = cs + r0 * D; a.c_new = cs + (r0 + m) * D; a.mask = dmask + r0; a.dp = dp + r0 * 3 * D;
             a.dc = dc; a.dpre = dpre + r0 * 4 * D; a.dh_pass_out = dhp_out; a.M = m; a.D = D; a.last = last ? 1 : 0;
             HIPCHK(h, launch_lstm_bwd(s, a));
         }
-        {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
+        if (panels) {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
+            PnArgs a{};
+            a.M = m; a.nseg = 2; a.kz = kz1; a.part_stride = (size_t)m * D;
+            for (int i = 0; i < 2; ++i) {
+                PnSeg& sg = a.seg[i];
+                pn_seg_defaults(sg);
+                sg.npairs = 1; sg.p[0] = PnPair{dpre + r0 * 4 * D, 4 * D, i == 0 ? bp.WcT : bp.UT, 4 * D};
+                sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
+            }
+            HIPCHK(h, launch_panel(s, a));
+        } else {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
             SkArgs a{};
             a.M = m; a.nseg = 2; a.kz = KZ1; a.part_stride = (size_t)m * D;
             for (int i = 0; i < 2; ++i) {
@@ -1445,7 +1593,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         }
         {
             TemporalBwdArgs a{};
-            a.dctxP = dctxP; a.nP = KZ1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
+            a.dctxP = dctxP; a.nP = kz1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
             a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.CL = CL + r0 * T * D;
             a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
             a.has_sel = h->opt.selector ? 1 : 0;
@@ -1464,7 +1612,15 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, launch_spatial_bwd(s, a));
         }
         HIPCHK(h, launch_reduce_T(s, dslp, dsgp, dsmp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D));
-        {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
+        if (panels) {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
+            PnArgs a{};
+            a.M = m; a.nseg = 1; a.kz = kz2; a.part_stride = (size_t)m * D;
+            PnSeg& sg = a.seg[0];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{dsproj + r0 * 4 * D, 4 * D, bp.WdT, 4 * D};
+            sg.C = dhWP; sg.ldc = D; sg.N = D;
+            HIPCHK(h, launch_panel(s, a));
+        } else {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
             SkArgs a{};
             a.M = m; a.nseg = 1; a.kz = KZ2; a.part_stride = (size_t)m * D;
             SkSeg& sg = a.seg[0];
@@ -1478,7 +1634,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // ---- deferred gradients.  Ordered by region of the flat buffer (= dict order) so that a data-parallel rank can
     // hand each region to the overlapped all-reduce as soon as it is final: decoder_* first (its 76 MB travel while
     // the F->D projection gradients -- the largest GEMM of the pass -- are computed), then ff_*, then Wemb.
-    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, KZ1, dhWP, KZ2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
+    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, kz1, dhWP, kz2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
                                 dph0, dpc0, m, D));
     {
         CtxGradArgs a{};
@@ -1649,6 +1805,23 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         if (add) { g.add = dadd; g.ldadd = N; }
         g.act = act; g.rowgroup = 1;
         hipError_t e = launch_gemm_bf16(s, g);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else if (kind == 3) {
+        // row-panel kernel: B repacked on the device (transB: the operand is B^T, packed straight from B [N][K])
+        if (transA || alpha != 1.f || !panel_supported(M) || N % 16 || K % 16)
+            return fail(h, STATTN_EINVAL, "panel kernel: no transA, alpha must be 1, M <= 256, N and K multiples of 16");
+        float* P;
+        CHK(getbuf_t(h, "dbg_P", (size_t)K * N, &P));
+        CHK(pack(h, dB, transB ? K : N, transB ? 1 : 0, K, N / 16, PN_COLS_PLAIN, P));
+        PnArgs a{};
+        a.M = M; a.nseg = 1;
+        PnSeg& sg = a.seg[0];
+        pn_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = PnPair{dA, K, P, K};
+        sg.C = dC; sg.ldc = N; sg.N = N; sg.bias = bias ? dbias : nullptr;
+        if (add) { sg.add = dadd; sg.ldadd = N; }
+        sg.act = act;
+        hipError_t e = launch_panel(s, a);
         if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
     } else {
         if (transA || transB) return fail(h, STATTN_EINVAL, "skinny kernel has no transposed variants");

@@ -418,6 +418,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
         const float sel = s_sel;
         r.x *= sel; r.y *= sel; r.z *= sel; r.w *= sel;
         st4(a.ctx + (size_t)b * D + d, r);
+        if (a.ctx_pk) st4(a.ctx_pk + pn_pack_offset(b, d, D >> 4), r);
     }
 }
 

@@ -111,6 +111,58 @@ struct LstmArgs {
 hipError_t launch_lstm(hipStream_t s, const LstmArgs& a);
 
 // ----------------------------------------------------------------------------
+// Row-panel kernels (panel.hip) for 17..256 rows: a workgroup owns every row and 16 / 32 output columns; the
+// weights are read from panels repacked once per pass in MFMA-operand order (see the file header).
+// ----------------------------------------------------------------------------
+enum { PN_COLS_PLAIN = 0, PN_COLS_LSTM = 1 };
+// Packed layout of an activation matrix [rows][K] (the A operand): [row / 16][k / 16][(k / 4) % 4 * 16 + row % 16][k % 4],
+// i.e. the floats of one (m-tile, k-step) are the 1 KiB a wave loads with one dwordx4 per lane; four consecutive k
+// (k % 4 == 0) stay one float4.  S = K / 16.  Written by the kernels that produce h, ctx, dpre and dsproj.
+__host__ __device__ inline size_t pn_pack_offset(int row, int k, int S) {
+    return ((((size_t)(row >> 4) * S + (k >> 4)) * 64) + ((k >> 2) & 3) * 16 + (row & 15)) * 4 + (k & 3);
+}
+struct PackJob {
+    const float* W; int ldw;      // source matrix
+    int src_t;                    // 0: W is [K][ldw];  1: the operand is W^T, W stored [N][ldw]
+    int K;                        // k extent packed by this job (multiple of 16)
+    int ntiles;                   // number of 16-column tiles
+    int cols; int D;              // PN_COLS_PLAIN, or PN_COLS_LSTM with D hidden units (W has 4D columns)
+    float* dst; int S_total; int s_off;   // destination panel set: k-steps per tile, first k-step filled by this job
+};
+hipError_t launch_pack_panels(hipStream_t s, const PackJob& jb);
+// A: activations [M][lda], or with apk = 1 the packed layout written by the producing kernel (ceil(M / 16) * 16 rows
+// allocated); P: packed weight panels of the segment's first tile
+struct PnPair { const float* A; int lda; const float* P; int K; int apk; };
+struct PnSeg {
+    PnPair p[3]; int npairs;
+    float* C; int ldc; int N;
+    const float* bias; const float* bias2;
+    const float* add; int ldadd;
+    const float* mul; int ldmul;
+    float scale; int act;
+};
+struct PnArgs {
+    PnSeg seg[6]; int nseg; int M;
+    int kz; size_t part_stride;        // K split over gridDim.y: raw partial tiles to C + z * part_stride, no epilogue
+};
+void pn_seg_defaults(PnSeg& s);
+bool panel_supported(int M);
+hipError_t launch_panel(hipStream_t s, const PnArgs& a);
+struct LstmPnArgs {
+    PnPair p[3]; int npairs;           // panels packed with PN_COLS_LSTM
+    const float* pre_add; int ldpre; const float* bias;
+    const float* dp; int lddp; const float* mask;
+    const float* h_prev; const float* c_prev; float* h_out; float* c_out; float* gates;
+    const float* d1; int ldd1; float d1_scalar; float* hd_out;
+    float* h_pk;                       // optional: h_out once more in the packed A layout (next step's state projections)
+    int M, D;
+};
+hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a);
+// dst (packed A layout, see panel.hip) = src [M][ld]; rows M .. roundup(M, 16) are zero filled
+hipError_t launch_pack_rows(hipStream_t s, const float* src, int ld, int M, int K, float* dst);
+size_t packed_rows_floats(int M, int K);
+
+// ----------------------------------------------------------------------------
 // attention kernels (attn.hip)
 // ----------------------------------------------------------------------------
 struct SpatialArgs {
@@ -146,6 +198,7 @@ struct TemporalArgs {
     float* csum;       // [M,D] cg+cm+clt before the gate (for backward), or null
     float* sel;        // [M] or null
     float* ctx;        // [M,D]
+    float* ctx_pk;     // optional: ctx once more in the packed A layout of the row-panel LSTM kernel (pn_pack_offset)
     int M, T, D;
 };
 hipError_t launch_temporal(hipStream_t s, const TemporalArgs& a);

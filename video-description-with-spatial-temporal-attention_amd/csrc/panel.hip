@@ -1,0 +1,491 @@
+// Row-panel fp32 MFMA kernels for the per-timestep dense work of the decoder at batch sizes of 17..256 rows
+// (training: 64 rows; beam search: videos x beam rows):
+//   state projections h.[Wdl|Wdg|Wdm|Wdlt] and h.U        model_attention.py:371, 389, 402, 415, 437
+//   ctx.Wc (+ emb.W) + gates + cell update                 :437-457
+//   readout MLP and vocabulary projection (sampling)       :821-838
+//   the three transposed recurrences of the reverse scan   (tensor.grad of the above, :1193)
+//
+// Partition.  A workgroup owns ALL rows of the batch and a narrow panel of 16 (or 32) output columns, so every
+// weight byte crosses the L2 -> CU path exactly once per launch and the activations (<= 1 MB, L2-resident) are the
+// operand that is re-read.  (The 64-column "skinny" kernels of skinny.hip split the rows over workgroups for
+// occupancy; at 64 rows that streamed every weight panel two to four times and left each wave with 4-8 dependent
+// load -> MFMA steps: 17-20 us per launch against an MFMA floor of 3.4-6.8 us.)
+//
+// Weight layout.  The panels are repacked once per forward / backward pass (the weights are constant across the
+// time steps) into the order the MFMA B operand is consumed:
+//     P[tile c][k-step s][lane][q] = W[16 s + 4 (lane >> 4) + q][col(c, lane & 15)]
+// so one k-step of one column tile is ONE coalesced 1 KiB dwordx4 load per wave, with no LDS staging and no
+// shuffles.  col(c, j) = 16 c + j, or for the LSTM the gate-interleaved (j >> 2) D + 4 c + (j & 3), which puts the
+// four gates of four hidden units into one tile so the cell update runs in the epilogue.
+//
+// v_mfma_f32_16x16x4_f32 contracts k over the four 16-lane groups g = lane >> 4: a lane loads FOUR consecutive k of
+// its A row (one dwordx4), the matching packed B float4 holds the same four k for its column, and the four MFMAs
+// of a 16-k step take component q of both.
+//
+// Block = MG row groups x KS K-slices waves; a wave holds MT m-tiles x NT n-tiles of accumulators and walks every
+// KS-th k-step with a three-deep register ring (two steps of loads in flight behind the MFMAs).  K-slices are
+// reduced through LDS in a fixed order (deterministic), then the epilogue runs once.
+#include "kernels.h"
+#include "devmath.h"
+
+namespace stattn {
+
+// Timeline probe (tools/panel_probe.hip builds this file with -DSTATTN_PROBES): wave 0 of every workgroup stamps the
+// 100 MHz wall clock at the phase boundaries.  Compiled out of the product.
+#ifdef STATTN_PROBES
+#ifndef PN_VARIANT
+#define PN_VARIANT 0                // compile-time ablations: 1 A read as a packed stream, 2 no MFMAs, 3 no A loads, 4 no B loads
+#endif
+__device__ long long* pn_probe = nullptr;
+#define PN_STAMP(i) do { if (pn_probe && threadIdx.x == 0) pn_probe[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define PN_STAMP(i) do {} while (0)
+#endif
+
+namespace {
+
+template <int MT, int NT>
+struct PnOps { float4 a[MT]; float4 b[NT]; };
+
+// s = logical k-step; the physical one is rotated by `rot` (see pn_rotation)
+template <int MT, int NT>
+__device__ __forceinline__ void pn_load(PnOps<MT, NT>& o, const float* const (&Ap)[MT], int astep, const float* __restrict__ Bp,
+                                        size_t tile_floats, int s, int rot, int nsteps) {
+    s += rot;
+    s = s >= nsteps ? s - nsteps : s;
+#if !(defined(STATTN_PROBES) && (PN_VARIANT == 4 || PN_VARIANT == 5))
+#pragma unroll
+    for (int i = 0; i < NT; ++i) o.b[i] = ld4(Bp + (size_t)i * tile_floats + (size_t)s * 256);
+#endif
+#if defined(STATTN_PROBES) && (PN_VARIANT == 3 || PN_VARIANT == 5)
+    return;
+#endif
+#pragma unroll
+    for (int i = 0; i < MT; ++i) o.a[i] = ld4(Ap[i] + (size_t)astep * s);
+}
+
+template <int MT, int NT>
+__device__ __forceinline__ void pn_mfma(f32x4 (&acc)[MT][NT], const PnOps<MT, NT>& o) {
+#if defined(STATTN_PROBES) && PN_VARIANT == 2
+    asm volatile("" :: "v"(o.a[0].x), "v"(o.b[0].x), "v"(o.a[MT - 1].w), "v"(o.b[NT - 1].w)); return;
+#endif
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int i = 0; i < MT; ++i)
+#pragma unroll
+            for (int n = 0; n < NT; ++n)
+                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][q], o.b[n][q], acc[i][n], 0, 0, 0);
+}
+
+// acc += A[rows of this wave, K-steps s0, s0 + stride, ...] . panel
+// Ap[i]: row pointer of m-tile i (+ 4 g), Bp: packed panel of the first column tile (+ 4 lane), nsteps = K / 16.
+//
+// What bounds these kernels is memory-level parallelism, not bandwidth (tools/panel_probe.hip): the weight panel of a
+// workgroup comes from HBM / Infinity Cache with ~2 us of loaded latency, so a wave that keeps two or three k-steps in
+// flight moves ~8 KB/us per CU and the loop takes three times its MFMA time.  Hence a ring of R k-steps of operands in
+// registers: every load of the first R steps is issued before the first MFMA (for K = 1024 and eight K-slice waves
+// that is the wave's whole share: the launch is one burst of loads followed by MFMAs), and a slot is refilled R steps
+// ahead as soon as its MFMAs have been issued.
+// The refills are unconditional: past the last step they re-request it (an L1 hit) -- a branch around the loads
+// would make the compiler merge wait counts over both paths and drain the queue.  ONESHOT (the wave has at most R
+// steps) compiles the refills out.
+template <int MT, int NT, int R, bool ONESHOT>
+__device__ __forceinline__ void pn_accumulate(f32x4 (&acc)[MT][NT], const float* const (&Ap)[MT], int astep,
+                                              const float* __restrict__ Bp, size_t tile_floats, int nsteps, int s0, int stride, int rot) {
+    if (s0 >= nsteps) return;
+    const int n = (nsteps - s0 + stride - 1) / stride;         // steps of this wave
+    const int last = s0 + (n - 1) * stride;
+    PnOps<MT, NT> ring[R];
+#pragma unroll
+    for (int u = 0; u < R; ++u) pn_load(ring[u], Ap, astep, Bp, tile_floats, min(s0 + u * stride, last), rot, nsteps);
+    int base = 0;
+    if (!ONESHOT) {
+        for (; base + 2 * R <= n; base += R) {   // groups whose refills are all real; no branch between loads and MFMAs
+            const int sb = s0 + base * stride;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                pn_mfma(acc, ring[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                pn_load(ring[u], Ap, astep, Bp, tile_floats, sb + (u + R) * stride, rot, nsteps);
+            }
+        }
+        if (base + R < n) {                      // one more refilling group when a partial group follows (clamped refills)
+            const int sb = s0 + base * stride;
+#pragma unroll
+            for (int u = 0; u < R; ++u) {
+                __builtin_amdgcn_sched_barrier(0);
+                pn_mfma(acc, ring[u]);
+                __builtin_amdgcn_sched_barrier(0);
+                pn_load(ring[u], Ap, astep, Bp, tile_floats, min(sb + (u + R) * stride, last), rot, nsteps);
+            }
+            base += R;
+        }
+    }
+    const int rem = n - base;                     // last group: its operands are in the ring, nothing is refilled
+#pragma unroll
+    for (int u = 0; u < R; ++u) {
+        if (u >= rem) break;
+        __builtin_amdgcn_sched_barrier(0);
+        pn_mfma(acc, ring[u]);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+}
+
+// Every workgroup walks its panel in the same k order at the same time.  Unrotated, the 256 CUs would request the same
+// offset of 256 panels that lie a power of two apart (one HBM / L2 channel at a time: the weight stream ran at 2 TB/s)
+// and the same lines of A (32 CUs of an XCD on one L2 channel).  Rotating the k order per workgroup -- by its index
+// within the XCD plus 8 per XCD -- spreads both over the channels; it only permutes the summation order.
+__device__ __forceinline__ int pn_rotation(int block, int nsteps) { return ((block >> 3) + ((block & 7) << 3)) % nsteps; }
+
+// 16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + r.  red[ks][row][col], row pitch CB.
+template <int MT, int NT>
+__device__ __forceinline__ void pn_spill(float* red, int RB, int ks, int mg, const f32x4 (&acc)[MT][NT], int j, int g) {
+    constexpr int CB = 16 * NT;
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+                red[((size_t)ks * RB + (mg * MT + i) * 16 + 4 * g + r) * CB + n * 16 + j] = acc[i][n][r];
+}
+
+// ---- general grouped GEMM with fused epilogue ------------------------------------------------------------
+template <int MT, int NT, int MAXT, int R, bool ONESHOT>
+__global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int MG, const int KS) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    constexpr int CB = 16 * NT;
+    // locate the segment of this group of NT column tiles
+    int tg = blockIdx.x, si = 0;
+    while (si + 1 < a.nseg && tg >= a.seg[si].N / CB) { tg -= a.seg[si].N / CB; ++si; }
+    const PnSeg& sg = a.seg[si];
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int mg = w % MG, ks = w / MG;
+    const int RB = MG * MT * 16;
+    const int kz = a.kz > 1 ? a.kz : 1;
+
+    PN_STAMP(0);
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int i = 0; i < MT; ++i)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < sg.npairs; ++p) {
+        const PnPair& pr = sg.p[p];
+        const float* Ap[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = min((mg * MT + i) * 16 + j, a.M - 1);
+            // packed activations (pn_pack_offset): one coalesced 1 KiB run per m-tile and k-step, like the weights
+            // (a row group may reach past the last m-tile: clamped like the rows, those accumulators are never stored)
+            Ap[i] = pr.apk ? pr.A + ((size_t)min(mg * MT + i, (a.M - 1) >> 4) * (pr.K >> 4)) * 256 + 4 * lane
+                           : pr.A + (size_t)row * pr.lda + 4 * g;
+        }
+        const int astep = pr.apk ? 256 : 16;
+        const int nsteps = pr.K >> 4;
+        const size_t tile_floats = (size_t)nsteps * 256;
+        const float* Bp = pr.P + (size_t)tg * NT * tile_floats + 4 * lane;
+        pn_accumulate<MT, NT, R, ONESHOT>(acc, Ap, astep, Bp, tile_floats, nsteps, (int)blockIdx.y * KS + ks, KS * kz,
+                                          pn_rotation((int)blockIdx.x, nsteps));
+    }
+    PN_STAMP(1);
+    pn_spill<MT, NT>(red, RB, ks, mg, acc, j, g);
+    __syncthreads();
+    PN_STAMP(2);
+
+    const int n0 = tg * CB;
+    for (int idx = tid; idx < RB * CB; idx += blockDim.x) {
+        const int row = idx / CB, col = idx % CB;
+        if (row >= a.M) continue;
+        float v = 0.f;
+        for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + col];
+        const int n = n0 + col;
+        if (kz > 1) { sg.C[(size_t)blockIdx.y * a.part_stride + (size_t)row * sg.ldc + n] = v; continue; }
+        if (sg.bias) v += sg.bias[n];
+        if (sg.bias2) v += sg.bias2[n];
+        if (sg.add) v += sg.add[(size_t)row * sg.ldadd + n];
+        if (sg.act == 1) v = fast_tanh(v);
+        v *= sg.scale;
+        if (sg.mul) v *= sg.mul[(size_t)row * sg.ldmul + n];
+        sg.C[(size_t)row * sg.ldc + n] = v;
+    }
+    PN_STAMP(3);
+}
+
+// ---- LSTM cell with its GEMM (model_attention.py:437-457).  Column tile c = units 4c..4c+3 of all four gates
+// (packed with PN_COLS_LSTM: tile column jj = gate * 4 + u).
+template <int MT, int MAXT, int R, bool ONESHOT>
+__global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, const int MG, const int KS) {
+    extern __shared__ __attribute__((aligned(16))) float red[];
+    constexpr int CB = 16;
+    const int D = a.D;
+    const int c = blockIdx.x;
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int j = lane & 15, g = lane >> 4;
+    const int mg = w % MG, ks = w / MG;
+    const int RB = MG * MT * 16;
+
+    PN_STAMP(0);
+    // The epilogue's operands do not depend on the GEMM: those of the thread's first (row, unit) item -- its only one
+    // unless the block has fewer K-slice waves than m-tiles -- are requested before it, so that the cell update at the
+    // end is arithmetic only (it was a chain of ten dependent global loads: 4.4 us of a 17 us launch).
+    struct EpiIn { float pre[4], dp[3], cp, hp, m, d1; };
+    auto epi_load = [&](int idx) {
+        EpiIn e;
+        const int row = min(idx >> 2, a.M - 1), d = 4 * c + (idx & 3);
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            float v = a.pre_add ? a.pre_add[(size_t)row * a.ldpre + gate * D + d] : 0.f;
+            if (a.bias) v += a.bias[gate * D + d];
+            e.pre[gate] = v;
+        }
+#pragma unroll
+        for (int q = 0; q < 3; ++q) e.dp[q] = a.dp[(size_t)row * a.lddp + q * D + d];
+        e.cp = a.c_prev[(size_t)row * D + d];
+        e.hp = a.h_prev[(size_t)row * D + d];
+        e.m = a.mask ? a.mask[row] : 1.f;
+        e.d1 = a.d1 ? a.d1[(size_t)row * a.ldd1 + d] : a.d1_scalar;
+        return e;
+    };
+    const EpiIn e0 = epi_load(min(tid, RB * 4 - 1));
+    f32x4 acc[MT][1];
+#pragma unroll
+    for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int p = 0; p < a.npairs; ++p) {
+        const PnPair& pr = a.p[p];
+        const float* Ap[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = min((mg * MT + i) * 16 + j, a.M - 1);
+            // packed activations (pn_pack_offset): one coalesced 1 KiB run per m-tile and k-step, like the weights
+            // (a row group may reach past the last m-tile: clamped like the rows, those accumulators are never stored)
+            Ap[i] = pr.apk ? pr.A + ((size_t)min(mg * MT + i, (a.M - 1) >> 4) * (pr.K >> 4)) * 256 + 4 * lane
+                           : pr.A + (size_t)row * pr.lda + 4 * g;
+        }
+        const int astep = pr.apk ? 256 : 16;
+        const int nsteps = pr.K >> 4;
+        const size_t tile_floats = (size_t)nsteps * 256;
+        pn_accumulate<MT, 1, R, ONESHOT>(acc, Ap, astep, pr.P + (size_t)c * tile_floats + 4 * lane, tile_floats, nsteps, ks, KS,
+                                         pn_rotation(c, nsteps));
+    }
+    PN_STAMP(1);
+    pn_spill<MT, 1>(red, RB, ks, mg, acc, j, g);
+    __syncthreads();
+    PN_STAMP(2);
+
+    for (int idx = tid; idx < RB * 4; idx += blockDim.x) {
+        const int row = idx >> 2, u = idx & 3;
+        if (row >= a.M) continue;
+        const EpiIn e = idx == tid ? e0 : epi_load(idx);
+        const int d = 4 * c + u;
+        float pre[4];
+#pragma unroll
+        for (int gate = 0; gate < 4; ++gate) {
+            float v = 0.f;
+            for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + gate * 4 + u];
+            pre[gate] = v + e.pre[gate];
+        }
+        // dropout multiplies the i/f/o PRE-activations (:444-447); g gets none
+        const float gi = fast_sigmoid(pre[0] * e.dp[0]);
+        const float gf = fast_sigmoid(pre[1] * e.dp[1]);
+        const float go = fast_sigmoid(pre[2] * e.dp[2]);
+        const float gg = fast_tanh(pre[3]);
+        float cn = gf * e.cp + gi * gg;                // :453
+        cn = e.m * cn + (1.f - e.m) * e.cp;            // :454
+        float hn = go * fast_tanh(cn);                 // :456 (uses the masked c)
+        hn = e.m * hn + (1.f - e.m) * e.hp;            // :457
+        a.c_out[(size_t)row * D + d] = cn;
+        a.h_out[(size_t)row * D + d] = hn;
+        if (a.h_pk) a.h_pk[pn_pack_offset(row, d, D >> 4)] = hn;
+        if (a.gates) {
+            float* gt = a.gates + (size_t)row * 4 * D + d;
+            gt[0] = gi; gt[D] = gf; gt[2 * D] = go; gt[3 * D] = gg;
+        }
+        if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * e.d1;
+    }
+    PN_STAMP(3);
+}
+
+// ---- repacking.  One thread per packed float4.
+// src_t = 0: W is [K][ldw] (k-major rows): the four k of a float4 are four strided reads;
+// src_t = 1: the operand is W^T with W stored [N][ldw]: the four k are contiguous in one row of W (the reverse-scan
+//            recurrences use the transposed weights without ever materialising a transpose).
+__global__ __launch_bounds__(256) void pack_panels_kernel(const PackJob jb) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int S = jb.K >> 4;
+    const size_t total = (size_t)jb.ntiles * S * 64;
+    if (idx >= total) return;
+    const int lane = (int)(idx & 63);
+    const int s = (int)((idx >> 6) % S);
+    const int c = (int)((idx >> 6) / S);
+    const int j = lane & 15, g = lane >> 4;
+    const int col = jb.cols == PN_COLS_LSTM ? (j >> 2) * jb.D + 4 * c + (j & 3) : 16 * c + j;
+    const int k = 16 * s + 4 * g;
+    float4 v;
+    if (jb.src_t) {
+        v = ld4(jb.W + (size_t)col * jb.ldw + k);
+    } else {
+        const float* p = jb.W + (size_t)k * jb.ldw + col;
+        v = make_float4(p[0], p[jb.ldw], p[2 * (size_t)jb.ldw], p[3 * (size_t)jb.ldw]);
+    }
+    // dst tile pitch: S_total k-steps (this job may fill only the k-range [s_off, s_off + S) of a taller panel)
+    st4(jb.dst + (((size_t)c * jb.S_total + jb.s_off + s) * 64 + lane) * 4, v);
+}
+
+// activations [M][ld] -> packed A layout; one thread per packed float4, rows past M are zero
+__global__ __launch_bounds__(256) void pack_rows_kernel(const float* __restrict__ src, int ld, int M, int K, float* __restrict__ dst) {
+    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const int S = K >> 4, mtiles = (M + 15) >> 4;
+    if (idx >= (size_t)mtiles * S * 64) return;
+    const int lane = (int)(idx & 63), s = (int)((idx >> 6) % S), mt = (int)((idx >> 6) / S);
+    const int row = mt * 16 + (lane & 15), k = 16 * s + 4 * (lane >> 4);
+    st4(dst + idx * 4, row < M ? ld4(src + (size_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f));
+}
+
+struct PnGeom { int MT, MG, KS; };
+
+// more than 64 KiB of dynamic LDS has to be granted per kernel, once
+template <class F>
+hipError_t pn_allow_lds(F f, size_t bytes) {
+    if (bytes <= 65536) return hipSuccess;
+    return hipFuncSetAttribute(reinterpret_cast<const void*>(f), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+}
+
+#ifndef PN_RING
+#define PN_RING 4
+#endif
+constexpr int PN_R = PN_RING;   // k-steps of operands a wave keeps in flight (sweep: tools/panel_probe.hip -DPN_RING=n)
+
+// rows -> m-tiles per wave and row groups; K-slices fill the block up to 8 (M <= 64) / 12..16 waves, but no more than
+// give every wave a full ring of steps (min_steps = k-steps of the shortest pair per K-split block)
+PnGeom pn_geom(int M, int max_waves, int min_steps) {
+    const int mtiles = (M + 15) / 16;
+    PnGeom q;
+    // up to 64 rows: one row group, 4 m-tiles per wave (512-thread blocks, 148 VGPRs).  More rows: several row groups
+    // of 2 m-tiles (1024-thread blocks leave 128 VGPRs per lane; 4 m-tiles would spill)
+    q.MT = mtiles > 4 ? 2 : (mtiles >= 3 ? 4 : (mtiles == 2 ? 2 : 1));
+    q.MG = (mtiles + q.MT - 1) / q.MT;
+    q.KS = max_waves / q.MG;
+    if (q.KS > 8) q.KS = 8;
+    while (q.KS > 1 && min_steps / q.KS < 4) q.KS >>= 1;
+    if (q.KS < 1) q.KS = 1;
+    return q;
+}
+
+}  // namespace
+
+bool panel_supported(int M) { return M >= 1 && M <= 256; }
+
+size_t packed_rows_floats(int M, int K) { return (size_t)((M + 15) / 16) * 16 * K; }
+
+hipError_t launch_pack_rows(hipStream_t s, const float* src, int ld, int M, int K, float* dst) {
+    if (M <= 0 || K % 16 != 0 || ld % 4 != 0) return hipErrorInvalidValue;
+    const size_t total = (size_t)((M + 15) / 16) * (K >> 4) * 64;
+    hipLaunchKernelGGL(pack_rows_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, src, ld, M, K, dst);
+    return hipGetLastError();
+}
+
+hipError_t launch_pack_panels(hipStream_t s, const PackJob& jb) {
+    if (jb.K % 16 != 0 || jb.ntiles <= 0 || !jb.W || !jb.dst) return hipErrorInvalidValue;
+    if (jb.src_t && (jb.ldw % 4 != 0)) return hipErrorInvalidValue;
+    const size_t total = (size_t)jb.ntiles * (jb.K >> 4) * 64;
+    hipLaunchKernelGGL(pack_panels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, jb);
+    return hipGetLastError();
+}
+
+void pn_seg_defaults(PnSeg& s) {
+    s = PnSeg{};
+    s.scale = 1.f;
+}
+
+hipError_t launch_panel(hipStream_t s, const PnArgs& a) {
+    if (a.M <= 0 || a.nseg <= 0) return hipSuccess;
+    if (!panel_supported(a.M)) return hipErrorInvalidValue;
+    int tiles = 0;
+    for (int i = 0; i < a.nseg; ++i) {
+        const PnSeg& sg = a.seg[i];
+        if (sg.N % 16 != 0 || sg.npairs < 1 || sg.npairs > 3) return hipErrorInvalidValue;
+        for (int p = 0; p < sg.npairs; ++p)
+            if (sg.p[p].K % 16 != 0 || sg.p[p].lda % 4 != 0) return hipErrorInvalidValue;
+        tiles += sg.N / 16;
+    }
+    const int kz = a.kz > 1 ? a.kz : 1;
+    int min_steps = 1 << 30, max_steps = 0;
+    for (int i = 0; i < a.nseg; ++i)
+        for (int p = 0; p < a.seg[i].npairs; ++p) {
+            const int st = (a.seg[i].p[p].K / 16 + kz - 1) / kz;
+            min_steps = st < min_steps ? st : min_steps; max_steps = st > max_steps ? st : max_steps;
+        }
+    // two column tiles per workgroup (A operands loaded once for twice the MFMAs) when that still fills the chip;
+    // only for a single row group (512-thread blocks: the register budget of 1024-thread blocks is half)
+    const PnGeom q = pn_geom(a.M, 16, min_steps);
+    const bool oneshot = (max_steps + q.KS - 1) / q.KS <= PN_R;
+    bool nt2 = tiles * kz >= 512 && q.MG == 1;
+    for (int i = 0; i < a.nseg; ++i) nt2 = nt2 && (a.seg[i].N % 32 == 0);
+    const int CB = nt2 ? 32 : 16;
+    dim3 grid(tiles / (nt2 ? 2 : 1), kz), block(64 * q.MG * q.KS);
+    const size_t lds = (size_t)q.KS * q.MG * q.MT * 16 * CB * sizeof(float);
+#define STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, R_, OS_)                                                         \
+    do {                                                                                                    \
+        hipError_t e_ = pn_allow_lds(panel_kernel<MT_, NT_, MAXT_, R_, OS_>, lds);                          \
+        if (e_ != hipSuccess) return e_;                                                                    \
+        hipLaunchKernelGGL((panel_kernel<MT_, NT_, MAXT_, R_, OS_>), grid, block, lds, s, a, q.MG, q.KS);   \
+    } while (0)
+    // 1024-thread blocks (several row groups): 128 VGPRs per lane -> a ring of 4 steps
+#define STATTN_PN_LAUNCH(MT_, NT_, MAXT_)                                                                   \
+    do {                                                                                                    \
+        if (MAXT_ == 1024) { if (oneshot4) STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, 4, true); else STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, 4, false); } \
+        else if (oneshot) STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, PN_R, true);                                   \
+        else STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, PN_R, false);                                               \
+    } while (0)
+    const bool oneshot4 = (max_steps + q.KS - 1) / q.KS <= 4;
+    if (q.MG > 1) STATTN_PN_LAUNCH(2, 1, 1024);
+    else if (nt2) {
+        if (q.MT == 4) STATTN_PN_LAUNCH(4, 2, 512); else if (q.MT == 2) STATTN_PN_LAUNCH(2, 2, 512); else STATTN_PN_LAUNCH(1, 2, 512);
+    } else {
+        if (q.MT == 4) STATTN_PN_LAUNCH(4, 1, 512); else if (q.MT == 2) STATTN_PN_LAUNCH(2, 1, 512); else STATTN_PN_LAUNCH(1, 1, 512);
+    }
+#undef STATTN_PN_LAUNCH
+#undef STATTN_PN_LAUNCH1
+    return hipGetLastError();
+}
+
+hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a) {
+    if (a.M <= 0) return hipSuccess;
+    if (!panel_supported(a.M) || a.D % 4 != 0 || a.npairs < 1 || a.npairs > 3) return hipErrorInvalidValue;
+    for (int p = 0; p < a.npairs; ++p)
+        if (a.p[p].K % 16 != 0 || a.p[p].lda % 4 != 0) return hipErrorInvalidValue;
+    int min_steps = 1 << 30, max_steps = 0;
+    for (int p = 0; p < a.npairs; ++p) {
+        const int st = a.p[p].K / 16;
+        min_steps = st < min_steps ? st : min_steps; max_steps = st > max_steps ? st : max_steps;
+    }
+    const PnGeom q = pn_geom(a.M, 16, min_steps);
+    const bool oneshot = (max_steps + q.KS - 1) / q.KS <= PN_R, oneshot4 = (max_steps + q.KS - 1) / q.KS <= 4;
+    dim3 grid(a.D / 4), block(64 * q.MG * q.KS);
+    const size_t lds = (size_t)q.KS * q.MG * q.MT * 16 * 16 * sizeof(float);
+#define STATTN_LP_LAUNCH1(MT_, MAXT_, R_, OS_)                                                              \
+    do {                                                                                                    \
+        hipError_t e_ = pn_allow_lds(lstm_panel_kernel<MT_, MAXT_, R_, OS_>, lds);                          \
+        if (e_ != hipSuccess) return e_;                                                                    \
+        hipLaunchKernelGGL((lstm_panel_kernel<MT_, MAXT_, R_, OS_>), grid, block, lds, s, a, q.MG, q.KS);   \
+    } while (0)
+#define STATTN_LP_LAUNCH(MT_, MAXT_)                                                                        \
+    do {                                                                                                    \
+        if (MAXT_ == 1024) { if (oneshot4) STATTN_LP_LAUNCH1(MT_, MAXT_, 4, true); else STATTN_LP_LAUNCH1(MT_, MAXT_, 4, false); } \
+        else if (oneshot) STATTN_LP_LAUNCH1(MT_, MAXT_, PN_R, true);                                        \
+        else STATTN_LP_LAUNCH1(MT_, MAXT_, PN_R, false);                                                    \
+    } while (0)
+    if (q.MG > 1) STATTN_LP_LAUNCH(2, 1024);
+    else if (q.MT == 4) STATTN_LP_LAUNCH(4, 512);
+    else if (q.MT == 2) STATTN_LP_LAUNCH(2, 512);
+    else STATTN_LP_LAUNCH(1, 512);
+#undef STATTN_LP_LAUNCH
+#undef STATTN_LP_LAUNCH1
+    return hipGetLastError();
+}
+
+}  // namespace stattn

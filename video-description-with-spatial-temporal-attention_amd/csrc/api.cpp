@@ -1544,8 +1544,15 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     BwdPanels bp{};
     const bool panels = use_panels(h, m);
     int kz1 = KZ1, kz2 = KZ2;
+    float *dpre_pk = nullptr, *dsproj_pk = nullptr;
     if (panels) {
         CHK(pack_bwd_panels(h, &bp));
+        CHK(getbuf_t(h, "pk_dpre", packed_rows_floats(m, 4 * D), &dpre_pk));
+        CHK(getbuf_t(h, "pk_dsproj", packed_rows_floats(m, 4 * D), &dsproj_pk));
+        if (m % 16) {     // rows past m of the last m-tile are read (and ignored): keep them finite
+            HIPCHK(h, hipMemsetAsync(dpre_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
+            HIPCHK(h, hipMemsetAsync(dsproj_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
+        }
         // K split so that the launch fills the chip: 2 D / 16 column tiles (dctx | dhU), D / 16 (dhW)
         kz1 = 256 / (2 * D / 16); kz1 = kz1 < 1 ? 1 : (kz1 > KZ1 ? KZ1 : kz1);
         kz2 = 256 / (D / 16); kz2 = kz2 < 1 ? 1 : (kz2 > KZ2 ? KZ2 : kz2);
@@ -1567,7 +1574,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             a.dselpre = dselpre + (r0 + m); a.W_sel = h->opt.selector ? w.W_sel : nullptr;
             a.dhd = dhd + r0 * D; a.d1 = d1 + r0 * D; a.gates = gates + r0 * 4 * D;
             a.c_prev = cs + r0 * D; a.c_new = cs + (r0 + m) * D; a.mask = dmask + r0; a.dp = dp + r0 * 3 * D;
-            a.dc = dc; a.dpre = dpre + r0 * 4 * D; a.dh_pass_out = dhp_out; a.M = m; a.D = D; a.last = last ? 1 : 0;
+            a.dc = dc; a.dpre = dpre + r0 * 4 * D; a.dpre_pk = dpre_pk; a.dh_pass_out = dhp_out; a.M = m; a.D = D; a.last = last ? 1 : 0;
             HIPCHK(h, launch_lstm_bwd(s, a));
         }
         if (panels) {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
@@ -1576,7 +1583,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             for (int i = 0; i < 2; ++i) {
                 PnSeg& sg = a.seg[i];
                 pn_seg_defaults(sg);
-                sg.npairs = 1; sg.p[0] = PnPair{dpre + r0 * 4 * D, 4 * D, i == 0 ? bp.WcT : bp.UT, 4 * D};
+                sg.npairs = 1; sg.p[0] = PnPair{dpre_pk, 4 * D, i == 0 ? bp.WcT : bp.UT, 4 * D, 1};
                 sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
             }
             HIPCHK(h, launch_panel(s, a));
@@ -1611,13 +1618,13 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             a.dplt = dplt + r0 * T * D; a.del = del + r0 * T * K; a.dslp = dslp; a.M = m; a.T = T; a.K = K; a.D = D;
             HIPCHK(h, launch_spatial_bwd(s, a));
         }
-        HIPCHK(h, launch_reduce_T(s, dslp, dsgp, dsmp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D));
+        HIPCHK(h, launch_reduce_T(s, dslp, dsgp, dsmp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D, dsproj_pk));
         if (panels) {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
             PnArgs a{};
             a.M = m; a.nseg = 1; a.kz = kz2; a.part_stride = (size_t)m * D;
             PnSeg& sg = a.seg[0];
             pn_seg_defaults(sg);
-            sg.npairs = 1; sg.p[0] = PnPair{dsproj + r0 * 4 * D, 4 * D, bp.WdT, 4 * D};
+            sg.npairs = 1; sg.p[0] = PnPair{dsproj_pk, 4 * D, bp.WdT, 4 * D, 1};
             sg.C = dhWP; sg.ldc = D; sg.N = D;
             HIPCHK(h, launch_panel(s, a));
         } else {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T

@@ -124,6 +124,11 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
     st4(a.dc + idx, o_dc);
     float* o = a.dpre + (size_t)b * 4 * D + d;
     st4(o, o_i); st4(o + D, o_f); st4(o + 2 * D, o_o); st4(o + 3 * D, o_g);
+    if (a.dpre_pk) {    // once more in the packed A layout of the row-panel recurrences (dctx, dhU)
+        const int S = (4 * D) >> 4;
+        st4(a.dpre_pk + pn_pack_offset(b, d, S), o_i); st4(a.dpre_pk + pn_pack_offset(b, D + d, S), o_f);
+        st4(a.dpre_pk + pn_pack_offset(b, 2 * D + d, S), o_o); st4(a.dpre_pk + pn_pack_offset(b, 3 * D + d, S), o_g);
+    }
     st4(a.dh_pass_out + idx, o_pass);
 }
 
@@ -287,7 +292,8 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
 // dsproj[b] = [sum_t dslp | sum_t dsgp | sum_t dsmp | sum_t dplt]   (the four state-projection gradients)
 __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__ dslp, const float* __restrict__ dsgp,
                                                        const float* __restrict__ dsmp, const float* __restrict__ dplt,
-                                                       float* __restrict__ dsproj, int lddsp, int T, int D) {
+                                                       float* __restrict__ dsproj, int lddsp, int T, int D,
+                                                       float* __restrict__ dsproj_pk) {
     const int b = blockIdx.x, which = blockIdx.y, d4 = blockIdx.z * 256 + threadIdx.x;
     if (d4 >= (D >> 2)) return;
     const float* __restrict__ src = which == 0 ? dslp : (which == 1 ? dsgp : (which == 2 ? dsmp : dplt));
@@ -295,6 +301,7 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 #pragma unroll 8
     for (int t = 0; t < T; ++t) add4(s1, ld4(src + ((size_t)b * T + t) * D + 4 * d4));
     st4(dsproj + (size_t)b * lddsp + which * D + 4 * d4, s1);
+    if (dsproj_pk) st4(dsproj_pk + pn_pack_offset(b, which * D + 4 * d4, (4 * D) >> 4), s1);    // packed A layout (dhW)
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -618,9 +625,9 @@ hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
-                           float* dsproj, int lddsp, int M, int T, int D) {
+                           float* dsproj, int lddsp, int M, int T, int D, float* dsproj_pk) {
     const int nd4 = D >> 2, bx = nd4 < 256 ? ((nd4 + 63) / 64) * 64 : 256;
-    hipLaunchKernelGGL(reduce_T_kernel, dim3(M, 4, (nd4 + 255) / 256), dim3(bx), 0, s, dslp, dsgp, dsmp, dplt, dsproj, lddsp, T, D);
+    hipLaunchKernelGGL(reduce_T_kernel, dim3(M, 4, (nd4 + 255) / 256), dim3(bx), 0, s, dslp, dsgp, dsmp, dplt, dsproj, lddsp, T, D, dsproj_pk);
     return hipGetLastError();
 }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {

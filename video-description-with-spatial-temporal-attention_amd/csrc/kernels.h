@@ -235,6 +235,7 @@ struct LstmBwdArgs {
     const float* c_prev; const float* c_new; const float* mask; const float* dp;   // dp [M,3D]
     float* dc;                            // [M,D] carried dc (in/out); read only if !last
     float* dpre;                          // [M,4D] out
+    float* dpre_pk;                       // optional: dpre once more in the packed A layout (pn_pack_offset)
     float* dh_pass_out;                   // [M,D] out
     int M, D, last;
 };
@@ -293,7 +294,7 @@ hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a);
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a);
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a);
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
-                           float* dsproj, int lddsp, int M, int T, int D);
+                           float* dsproj, int lddsp, int M, int T, int D, float* dsproj_pk = nullptr);
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a);
 int colsum_parts(int rows, int N);
 hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,

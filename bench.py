@@ -159,9 +159,16 @@ def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
     vids = [(batch['ctxg'][i], batch['mask_ctxg'][i], batch['ctxl'][i], batch['mask_ctxl'][i], batch['ctxm'][i],
              batch['mask_ctxm'][i]) for i in range(c["B"])]
 
+    k = args.beam
+
     def one_pass():
-        for v in vids:
-            model.gen_sample(None, f_init, f_next, *v, options, None, args.beam, maxlen=t)
+        if args.host_loop:               # one f_next call per word from the host, like the reference's gen_sample
+            for v in vids:
+                model.gen_sample(None, f_init, f_next, *v, options, None, k, maxlen=t)
+        else:                            # what Attention.gen_sample does by default: the loop of ONE video on the device
+            for v in vids:               # (features handed over as host arrays on every call, staged + projected inside)
+                dec.beam_search(v[0][None], v[1][None], v[2][None], v[4][None], k=k, maxlen=t, suppress_eos=True)
+                nsteps[0] += 1 + k * (t - 1)
     for _ in range(args.warmup):
         one_pass()
     dec.sync()
@@ -175,9 +182,11 @@ def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
     out = dict(metric="decoder steps/sec (batch x timestep)", value=rowsteps / dt, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                scaling="weak", vs_baseline=None, dtype="bf16" if args.precision == "bf16" else "f32", data="synthetic",
-               config=dict(workload="%s decode: gen_sample(k=%d, maxlen=%d, <eos> suppressed) over %d videos per GPU through "
-                                    "f_init/f_next with host arrays per call, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
-                                    % (args.config, args.beam, t, c["B"], c["T"], c["K"], c["F"], c["D"], c["E"], V, dec.lt_mode),
+               config=dict(workload="%s decode: gen_sample(k=%d, maxlen=%d, <eos> suppressed), one video after the other, %d videos per GPU, %s, "
+                                    "T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, lt_mode=%d"
+                                    % (args.config, args.beam, t, c["B"], "host loop: one f_next call per word with host arrays" if args.host_loop
+                                       else "device loop per video (hipGraph word sequence, host features staged per call)",
+                                       c["T"], c["K"], c["F"], c["D"], c["E"], V, dec.lt_mode),
                            videos=c["B"] * world, beam=args.beam, parallelism="replicas%d" % world))
     if rank == 0:
         if not args.no_cpu_baseline:
@@ -287,6 +296,8 @@ def main():
     ap.add_argument("--h2d", default="none", choices=["none", "sync", "prefetch"],
                     help="train mode only: also move the minibatch host->device every step (never the headline value): "
                          "sync = stattn_set_batch from pageable memory, prefetch = pinned arrays + copy stream, overlapped")
+    ap.add_argument("--host-loop", action="store_true", help="decode mode: drive f_next from the host word by word (reference protocol) "
+                                                             "instead of the device-resident loop gen_sample uses by default")
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
                     help="bf16: the bf16-MFMA forward/decode path of BASELINE configs[3] (not the headline; no training)")

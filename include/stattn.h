@@ -145,6 +145,12 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                        const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
                        int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count);
 
+/* gen_sample's third and fourth return values (next_state, next_memory, :994) for the videos of the last
+ * stattn_beam_search: out_h / out_c (nvid,k,D), the first out_rows[v] rows of video v are valid -- the state outputs of
+ * the f_next call that ended the video's loop (every live hypothesis at that point), or the gathered states of the
+ * hypotheses still live after maxlen words. */
+int stattn_beam_final_state(stattn_handle* h, float* out_h, float* out_c, int32_t* out_rows);
+
 /* ---- training graph: build_model / f_log_probs / f_grad_shared (:583-717, 1126, 1207) -- */
 /* Stage one minibatch in HBM: prepare_data()'s 8-tuple (data_engine.py:258-337).
  * x (t,m) int64, mask (t,m), ctxg (m,T,D), mask_ctxg (m,T), ctxl (m,T,K,F),

@@ -132,6 +132,7 @@ def test_bf16_sampler_and_beam_search_agree_with_fp32_captions():
     opt_b = dict(opt, stattn_precision='bf16')
     tparams = model.init_tparams(P)
     f_init, f_next = model.build_sampler(tparams, opt_b, None, None)
+    f_next.device_loop = False        # gen_sample below = the host-driven loop
     res = model.gen_sample_batch(tparams, opt_b, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=3, maxlen=7)
     for v in range(4):
         args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])

@@ -80,6 +80,7 @@ def test_large_odd_vocabulary_takes_the_multi_pass_softmax():
     model = stattn.Attention()
     tparams = model.init_tparams(P)
     f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    f_next.device_loop = False        # gen_sample below = the host-driven loop
     v = 0
     args = (batch['ctxg'][v], batch['mask_ctxg'][v], batch['ctxl'][v], batch['mask_ctxl'][v], batch['ctxm'][v], batch['mask_ctxm'][v])
     s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 3, maxlen=5)

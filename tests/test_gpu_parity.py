@@ -270,12 +270,19 @@ def test_attention_surface_gen_sample_matches_oracle_driver(stattn_mod, O):
     args64 = tuple(a.astype(np.float64) for a in args)
     fi = lambda g, m: O.f_init(P64, opt, g, m)
     fn = lambda *a: O.f_next(P64, opt, *a)
-    for k in (1, 5):
-        s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=8)
-        sr, scr, _, _ = O.gen_sample(fi, fn, *args64, k=k, maxlen=8)
-        assert len(s) == len(sr)
-        np.testing.assert_allclose(sorted(np.asarray(sc, np.float64)), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=1e-4)
-        assert s[int(np.argmin(sc))] == sr[int(np.argmin(scr))]
+    assert f_next.device_loop                    # default: gen_sample runs its whole loop on the device
+    for device_loop in (True, False):            # ... or drives f_next from the host word by word, like the reference
+        f_next.device_loop = device_loop
+        for k, maxlen in ((1, 8), (5, 8), (3, 40)):     # (3, 40): long enough for every hypothesis to end with <eos>
+            s, sc, hs, cs = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=maxlen)
+            sr, scr, hr, cr = O.gen_sample(fi, fn, *args64, k=k, maxlen=maxlen)
+            assert len(s) == len(sr)
+            np.testing.assert_allclose(sorted(np.asarray(sc, np.float64)), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=1e-4)
+            assert s[int(np.argmin(sc))] == sr[int(np.argmin(scr))]
+            # next_state / next_memory: one-element lists holding the states gen_sample ends with (:980-994)
+            assert isinstance(hs, list) and len(hs) == 1 and hs[0].shape == np.shape(hr[0]), (device_loop, k, hs[0].shape, np.shape(hr[0]))
+            assert np.abs(hs[0] - hr[0]).max() < TOL and np.abs(cs[0] - cr[0]).max() < TOL
+    f_next.device_loop = True
     # unzip / zipp round trip through the device
     pulled = stattn_mod.common.unzip(tparams)
     for k in params:
@@ -442,6 +449,7 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
     f_init, f_next = model.build_sampler(tparams, opt, None, None)
     nvid, T, K, maxlen = 6, 5, 4, 9
     b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=70)
+    f_next.device_loop = False        # gen_sample below = the host-driven loop, compared with the device-side one
     res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
     assert len(res) == nvid
     # the per-word kernel sequence ran as hipGraph replays (two words per replay), not as eager launches
@@ -484,6 +492,7 @@ def test_c5_full_size_device_beam_search(stattn_mod, O):
     model = stattn_mod.Attention()
     tparams = model.init_tparams(P)
     f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    f_next.device_loop = False        # gen_sample below = the host-driven loop
     dec = f_next.decoder
     res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
     assert len(res) == nvid
@@ -527,6 +536,7 @@ def test_c1_greedy_gen_sample_full_vocabulary(stattn_mod, O):
     maxlen = 30
     v = 0
     args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+    f_next.device_loop = False        # host-driven: one f_next call per word, like the reference
     s, sc, hs, cs = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 1, maxlen=maxlen)
     assert isinstance(hs, list) and len(hs) == 1 and hs[0].shape == (1, 512) and isinstance(cs, list)
     a64 = tuple(a.astype(np.float64) for a in args)
@@ -536,6 +546,13 @@ def test_c1_greedy_gen_sample_full_vocabulary(stattn_mod, O):
     assert s == sr and len(s[0]) == maxlen
     np.testing.assert_allclose(np.asarray(sc, np.float64), np.asarray(scr, np.float64), rtol=1e-4, atol=1e-3)
     assert np.abs(hs[0] - hr[0]).max() < TOL
+    # the same call with the loop on the device (the default)
+    f_next.device_loop = True
+    s_d, sc_d, hs_d, cs_d = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 1, maxlen=maxlen)
+    assert s_d == sr
+    np.testing.assert_allclose(np.asarray(sc_d, np.float64), np.asarray(scr, np.float64), rtol=1e-4, atol=1e-3)
+    assert np.abs(hs_d[0] - hr[0]).max() < TOL and np.abs(cs_d[0] - cr[0]).max() < TOL
+    f_next.device_loop = False
     # device-side greedy loop over the 4 videos of the config: same captions as the host loop
     res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=1, maxlen=maxlen)
     assert res[0][0] == s

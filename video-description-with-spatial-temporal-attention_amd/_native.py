@@ -57,6 +57,7 @@ _SIGNATURES = {
     "stattn_beam_stage": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int]),
     "stattn_beam_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      _I64, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "stattn_beam_final_state": (C.c_int, [_H, _F, _F, C.POINTER(C.c_int32)]),
     "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
     "stattn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "stattn_host_free": (C.c_int, [C.c_void_p]),
@@ -371,11 +372,21 @@ class Decoder(object):
         self._chk(self._lib.stattn_beam_search(self._h, nvid, pg, pk, pl, pm, T, K, int(k),
                                                int(maxlen), int(bool(suppress_eos)), tok.ctypes.data_as(_I64), _fp(sc),
                                                ln.ctypes.data_as(C.POINTER(C.c_int32)), cnt.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._beam_shape = (nvid, int(k))
         out = []
         for v in range(nvid):
             samples = [tok[v, j, :ln[v, j]].tolist() for j in range(cnt[v])]
             out.append((samples, sc[v, :cnt[v]].copy()))
         return out
+
+    def beam_final_state(self):
+        """(next_state, next_memory) of gen_sample for every video of the last beam_search: a list of
+        ((rows, D) h, (rows, D) c) pairs (stattn_beam_final_state)."""
+        nvid, k = self._beam_shape
+        hh = np.empty((nvid, k, self.D), np.float32); cc = np.empty((nvid, k, self.D), np.float32)
+        rows = np.empty((nvid,), np.int32)
+        self._chk(self._lib.stattn_beam_final_state(self._h, _fp(hh), _fp(cc), rows.ctypes.data_as(C.POINTER(C.c_int32))))
+        return [(hh[v, :rows[v]].copy(), cc[v, :rows[v]].copy()) for v in range(nvid)]
 
     # -- training graph
     def set_batch(self, x, mask, ctxg, mask_ctxg, ctxl, mask_ctxl, ctxm, mask_ctxm):

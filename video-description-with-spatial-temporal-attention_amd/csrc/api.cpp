@@ -923,6 +923,9 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     CHK(getbuf_t(h, "bs_next_w", (size_t)M, &next_w));
     int* d_step;
     CHK(getbuf_t(h, "bs_step", (size_t)1, &d_step));
+    float *end_h, *end_c; int* end_rows;
+    CHK(getbuf_t(h, "bs_end_h", (size_t)M * D, &end_h)); CHK(getbuf_t(h, "bs_end_c", (size_t)M * D, &end_c));
+    CHK(getbuf_t(h, "bs_end_rows", (size_t)nvid, &end_rows));
     float* tk_cost; int* tk_idx;
     CHK(getbuf_t(h, "bs_tk_cost", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_cost));
     CHK(getbuf_t(h, "bs_tk_idx", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_idx));
@@ -1019,6 +1022,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
+        ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows;
         HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         HIPCHK(h, launch_beam_update(s, ba));
         return STATTN_OK;
@@ -1044,7 +1048,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                           (const void*)ag, (const void*)am, (const void*)alt, (const void*)ctx, (const void*)a1, (const void*)lg,
                           (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
                           (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
-                          (const void*)pn.Wo})
+                          (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows})
         sig.push_back((uintptr_t)q);
     if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
         gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is
@@ -1113,6 +1117,36 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
             out_count[v] = n;
             for (int j = n; j < k; ++j) { out_lens[v * k + j] = 0; out_scores[v * k + j] = 0.f; }
         }
+        // what stattn_beam_final_state hands out: videos whose loop ended early (live count 0) keep the rows saved by
+        // beam_update; the others ran to maxlen and return the gathered states of their live hypotheses (:979-985)
+        h->bf_nvid = nvid; h->bf_k = k; h->bf_live = lv; h->bf_fb = fb;
+    }
+    return STATTN_OK;
+}
+
+int stattn_beam_final_state(stattn_handle* h, float* out_h, float* out_c, int32_t* out_rows) {
+    if (!h || !out_h || !out_c || !out_rows) return fail(h, STATTN_EINVAL, "beam_final_state: bad argument");
+    if (h->bf_nvid <= 0) return fail(h, STATTN_ESTATE, "beam_final_state: no beam search has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int nvid = h->bf_nvid, k = h->bf_k, D = h->D;
+    const size_t n = (size_t)nvid * k * D;
+    std::vector<float> eh(n), ec(n), lh(n), lc(n);
+    std::vector<int> er(nvid);
+    HIPCHK(h, hipMemcpyAsync(eh.data(), findbuf(h, "bs_end_h"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ec.data(), findbuf(h, "bs_end_c"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(er.data(), findbuf(h, "bs_end_rows"), (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(lh.data(), findbuf(h, "bs_hp"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(lc.data(), findbuf(h, "bs_cp"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    memset(out_h, 0, n * 4); memset(out_c, 0, n * 4);
+    for (int v = 0; v < nvid; ++v) {
+        const bool ended = h->bf_live[v] == 0;
+        const int rows = ended ? er[v] : h->bf_live[v];
+        out_rows[v] = rows;
+        const size_t o = (size_t)v * k * D;
+        memcpy(out_h + o, (ended ? eh.data() : lh.data()) + o, (size_t)rows * D * 4);
+        memcpy(out_c + o, (ended ? ec.data() : lc.data()) + o, (size_t)rows * D * 4);
     }
     return STATTN_OK;
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(256) void beam_topk_merge_kernel(const BeamArgs a, 
 
 __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
     __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
-    __shared__ int s_n;
+    __shared__ int s_n, s_ended, s_rows;
     const int v = blockIdx.x, tid = threadIdx.x;
     const int k = a.k, D = a.D, L = a.maxlen, step = *a.step;
     if (tid == 0) {
@@ -148,10 +148,12 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
                 ++nl;
             }
         }
-        s_n = n;
+        s_n = n; s_ended = 0; s_rows = a.live_k[v];
         if (n > 0) {
             a.dead_k[v] = dead;
-            a.live_k[v] = (nl < 1 || dead >= k) ? 0 : nl;      // :974-977
+            const int live = (nl < 1 || dead >= k) ? 0 : nl;   // :974-977
+            a.live_k[v] = live;
+            if (live == 0) { s_ended = 1; if (a.end_rows) a.end_rows[v] = s_rows; }
         }
     }
     __syncthreads();
@@ -169,6 +171,12 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
             float* __restrict__ cd = a.c_next + (size_t)(v * k + slot) * D;
             for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
         }
+    }
+    // the video's loop ends with this word (:974-977): gen_sample returns f_next's state outputs of this very call,
+    // one row per hypothesis that was live going in -- kept aside, later words overwrite h_step
+    if (s_ended && a.end_h) {
+        const size_t base = (size_t)v * k * D;
+        for (int i = tid; i < s_rows * D; i += 256) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
     }
 }
 

@@ -110,6 +110,8 @@ struct stattn_handle {
     // batched beam search: raw features staged by stattn_beam_stage (or the last call that passed host features)
     int bk_n = 0, bk_T = 0, bk_K = 0;
     bool bk_valid = false;
+    int bf_nvid = 0, bf_k = 0, bf_fb = 0;          // last beam search: shape, final ping-pong parity, live counts
+    std::vector<int> bf_live;
 
     // profiling
     bool profiling = false;

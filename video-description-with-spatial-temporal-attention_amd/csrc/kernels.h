@@ -335,6 +335,7 @@ struct BeamArgs {
     int64_t* next_w;                    // [nvid*k] word fed to the next step
     const float* h_step; const float* c_step;       // [nvid*k, D] state after this step
     float* h_next; float* c_next;       // [nvid*k, D] state gathered for the next step
+    float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
 };
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch

@@ -212,6 +212,9 @@ class Attention(object):
             return dec.f_next(x, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask,
                               init_state, init_memory)                      # :845-848
         f_next.decoder = dec
+        # gen_sample runs its beam / greedy loop on the device when handed this very f_next (k <= 8, not stochastic);
+        # set f_next.device_loop = False to drive f_next from the host word by word like the reference does
+        f_next.device_loop = True
         return f_init, f_next
 
     # ---------------------------------------------------------------- gradient / update functions
@@ -333,6 +336,12 @@ class Attention(object):
         if restrict_voc:
             raise NotImplementedError()
         dec = getattr(f_next, 'decoder', None)
+        if dec is not None and not stochastic and k <= 8 and getattr(f_next, 'device_loop', False):
+            # the whole loop on the device (stattn_beam_search: hipGraph-captured word sequence, no per-word host
+            # round trip); k = 1 is the greedy decode of :896-918
+            (sample, score), = dec.beam_search(ctxg_0[None], ctxg_mask[None], ctxl_0[None], ctxm_0[None], k=k, maxlen=maxlen)
+            (hh, cc), = dec.beam_final_state()
+            return sample, list(score), [hh], [cc]
         if dec is None:
             return self._decode_loop(f_init, f_next, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_0, ctxm_mask, k, maxlen, stochastic)
         with dec.video_scope(ctxg_0, ctxl_0, ctxm_0):

@@ -34,6 +34,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 CONFIGS = {
+    # configs[1] with twice the rows: the region tensors (328 MB) exceed the 256 MB Infinity Cache -- HBM vs cache probe
+    "c2b128": dict(B=128, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    # configs[1] with the reference's real vocabulary (config.py:35)
+    "c2v20k": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=20000, t=30),
     # BASELINE.json configs[1] "Single MI355X" / configs[2] per-GPU shard
     "c2": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
     # configs[0] "MSVD tiny"
@@ -257,6 +261,18 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
         dist.destroy_process_group()
 
 
+def measured_traffic(args, dec):
+    """HBM-side bytes per launch of the kernels named in the bench line, from the rocprofv3 PMC passes committed under
+    profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950
+    correction: profiles/README.md, tools/pmc_summary.py --json).  Counters cannot be read from inside the timed run, so a
+    configuration that has no committed PMC summary reports null."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return {}
+    key = "%s/%s/lt%d/%s" % (args.config, args.mode, dec.lt_mode, args.precision)
+    return json.load(open(path)).get(key, {})
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` without a launcher: start one rank per GPU (same command line, RANK / LOCAL_RANK /
     WORLD_SIZE / MASTER_* in the environment, rendezvous on 127.0.0.1) and wait.  Rank 0 prints the JSON line."""
@@ -398,30 +414,32 @@ def main():
     rowsteps = c["B"] * c["t"] * args.steps * world
     value = rowsteps / dt
 
-    # ---- roofline of the dominant kernel, timed live with HIP events on the library's stream
+    # ---- rooflines, timed live with HIP events on the library's stream (forward pass: that is where the per-class events live)
     dec.set_profiling(True)
     for _ in range(3):
-        dec.forward_train()                           # forward only: the per-kernel-class events live there
+        dec.forward_train()
     kms = dec.kernel_ms()
+    gms = dec.gemm_launch_ms()
     dec.set_profiling(False)
     B, T, K, D, E, F, V, t = c["B"], c["T"], c["K"], c["D"], c["E"], c["F"], c["V"], c["t"]
     Vp = (V + 127) // 128 * 128
-    # (1) dominant kernel by time share: the LDS-tiled fp32 MFMA GEMM (45 % of a train step, profiles/).  All of its
-    #     plain (NN) launches of one forward pass: flops per launch (average) / average launch duration.
-    BTK, BT, R = B * T * K, B * T, B * t
-    nn_shapes = [(BTK, D, F), (BT, D, F), (BT, D, D), (BTK, D, D), (BT, D, D)] + ([(BTK, D, D)] if dec.lt_mode == 1 else []) + \
-                [(R, 4 * D, E), (R, E, D), (R, E, D), (R, Vp, E)]
-    if dec.lt_mode == 0:
-        nn_shapes += [(BT, D, D)] * t
-    nn_flops = sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in nn_shapes)
-    g_ms, g_n = kms["gemm_nn"]
-    per_fwd = g_n / 3.0
     bf16 = args.precision == "bf16"
     mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
-    roofline = dict(kernel=("gemm_bf16_kernel<TM,TN> (all launches of one forward pass, %d per pass)" if bf16 else
-                            "gemm_kernel<TM,TN,false,false> (all NN launches of one forward pass, %d per pass)") % round(per_fwd),
+    traffic = measured_traffic(args, dec)            # rocprofv3 PMC bytes per launch from profiles/, or {}
+    # (1) dominant kernel class by time share: the LDS-tiled MFMA GEMM.  `roofline` = all plain (NN) launches of one
+    #     forward pass (flops per launch / average launch duration); `kernels` below has every launch on its own.
+    BTK, BT, R = B * T * K, B * T, B * t
+    nn = [("ff_local", BTK, D, F), ("ff_motion", BT, D, F), ("pctxg", BT, D, D), ("pctxl", BTK, D, D), ("pctxm", BT, D, D)]
+    if dec.lt_mode == 1:
+        nn.append(("L.Wclt", BTK, D, D))
+    nn += [("xproj", R, 4 * D, E), ("readout_h", R, E, D)] + ([("readout_ctx", R, E, D)] if options["ctx2out"] else []) + [("logits", R, Vp, E)]
+    nn_flops = sum(2.0 * m_ * n_ * k_ for _, m_, n_, k_ in nn) + (2.0 * BT * D * D * t if dec.lt_mode == 0 else 0.0)
+    g_ms, g_n = kms["gemm_nn"]
+    per_fwd = g_n / 3.0
+    gname = "gemm_bf16_kernel<TM,TN>" if bf16 else "gemm2_kernel<TM,TN,false,false,EDGE>"
+    roofline = dict(kernel="%s (all %d plain launches of one forward pass)" % (gname, round(per_fwd)),
                     bound="mfma", achieved=(nn_flops / per_fwd) / (g_ms * 1e-3) / 1e12 if g_ms else None,
-                    peak=mfma_peak, unit="TFLOP/s", frac=None, traffic=None,
+                    peak=mfma_peak, unit="TFLOP/s", frac=None, traffic=traffic.get("gemm_nn"),
                     flops_per_launch=nn_flops / max(per_fwd, 1), ms_per_launch=g_ms)
     if roofline["achieved"]:
         roofline["frac"] = roofline["achieved"] / mfma_peak
@@ -429,19 +447,34 @@ def main():
     nslab = 3 if dec.lt_mode == 1 else 2              # PL, L (and LW in lt_mode 1)
     slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
     sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
-    sp_ms = kms["spatial"][0]
-    roofline_hbm = dict(kernel="spatial_bf16_kernel" if bf16 else ("spatial2_kernel<128>" if D % 1024 == 0 else "spatial_kernel"), bound="hbm",
-                        achieved=sp_bytes / (sp_ms * 1e-3) / 1e9 if sp_ms else None,
-                        peak=HBM_PEAK_GBS, unit="GB/s", frac=None, traffic=None,
-                        bytes_per_launch=sp_bytes, ms_per_launch=sp_ms)
-    if roofline_hbm["achieved"]:
-        roofline_hbm["frac"] = roofline_hbm["achieved"] / HBM_PEAK_GBS
-    if args.config == "c2" and dec.lt_mode == 1 and not bf16:
-        # HBM-side bytes per launch from rocprofv3 PMC passes of this very command (collected offline, separate
-        # --pmc FETCH_SIZE / WRITE_SIZE runs, FETCH_SIZE doubled per the gfx950 correction): profiles/r01_c_pmc_*.csv
-        roofline["traffic"] = 435.5e6          # mean over the 10 NN launches: 403.6 MB fetched + 32.0 MB written
-        roofline_hbm["traffic"] = 193.0e6      # 186.0 MB fetched + 7.0 MB written (algorithmic: 184.0 MB)
-        roofline["traffic_source"] = roofline_hbm["traffic_source"] = "rocprofv3 --pmc, profiles/r01_g_pmc_forward_*.csv"
+    sp_name = "spatial_bf16_kernel" if bf16 else ("spatial2_kernel<128>" if D % 1024 == 0 else "spatial_kernel")
+
+    def hbm(name, nbytes, ms, key):
+        r = dict(kernel=name, bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9 if ms else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                 frac=None, traffic=traffic.get(key), bytes_per_launch=nbytes, ms_per_launch=ms)
+        if r["achieved"]:
+            r["frac"] = r["achieved"] / HBM_PEAK_GBS
+        return r
+
+    def mfma(name, flops, ms, nbytes=None):
+        r = dict(kernel=name, bound="mfma", achieved=flops / (ms * 1e-3) / 1e12 if ms else None, peak=mfma_peak, unit="TFLOP/s",
+                 frac=None, flops_per_launch=flops, ms_per_launch=ms)
+        if r["achieved"]:
+            r["frac"] = r["achieved"] / mfma_peak
+        if nbytes and ms:                              # the same launch against the HBM roof (weights streamed once)
+            r["weight_stream_GBs"] = nbytes / (ms * 1e-3) / 1e9
+            r["weight_stream_frac_hbm"] = r["weight_stream_GBs"] / HBM_PEAK_GBS
+        return r
+    roofline_hbm = hbm(sp_name, sp_bytes, kms["spatial"][0], "spatial")
+    # (3) every kernel of the per-step chain and every GEMM launch of the pass on its own roof
+    kernels = dict(
+        spatial=roofline_hbm,
+        state_proj=mfma("h.[Wdl|Wdg|Wdm|Wdlt|U] (panel_kernel / skinny)", 2.0 * B * D * 8 * D, kms["hproj"][0], 8.0 * D * D * 4),
+        lstm=mfma("ctx.Wc + gates (lstm_panel_kernel / lstm_kernel)", 2.0 * B * D * 4 * D, kms["lstm"][0], 4.0 * D * D * 4),
+        temporal=hbm("temporal_kernel", B * T * D * 4.0 * 3, kms["temporal"][0], "temporal"))
+    for (nm, m_, n_, k_), ms in zip(nn, gms):
+        kernels["gemm_" + nm] = mfma("%s %dx%dx%d" % (gname, m_, n_, k_), 2.0 * m_ * n_ * k_, ms)
+    step_ms = sum(kms[k_][0] for k_ in ("hproj", "spatial", "lt_gemm", "temporal", "lstm"))
     if args.kernel_breakdown and rank == 0:
         print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)
 
@@ -454,7 +487,8 @@ def main():
                                        if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
                                        B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),
                            global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world, h2d=args.h2d),
-               roofline=roofline, roofline_hbm=roofline_hbm,
+               roofline=roofline, roofline_hbm=roofline_hbm, kernels=kernels,
+               decoder_step_us=step_ms * 1e3,       # sum of the per-step kernel classes (HIP events, includes the record gaps)
                kernel_ms={k: v[0] for k, v in kms.items()})
     if rank == 0:
         if not args.no_cpu_baseline:

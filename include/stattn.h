@@ -256,7 +256,8 @@ int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int 
 /* Average duration (ms) of the named kernel class over the last stattn_forward_train
  * when profiling is enabled: 0 = spatial attention, 1 = state projections, 2 = local-
  * temporal GEMM, 3 = temporal fuse, 4 = lstm, 5 = prologue scope (sum), 6 = readout scope (sum), 7 = every plain (NN) launch of the
- * LDS-tiled GEMM in the forward pass. */
+ * LDS-tiled GEMM in the forward pass; 8 + i = the i-th of those launches alone (i < 16, in launch order: ff_local,
+ * ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits). */
 int stattn_set_profiling(stattn_handle* h, int enable);
 int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches);
 

@@ -574,3 +574,13 @@ class Decoder(object):
             self._chk(self._lib.stattn_get_kernel_ms(self._h, i, C.byref(ms), C.byref(n)))
             out[name] = (ms.value, n.value)
         return out
+
+    def gemm_launch_ms(self):
+        """Average duration of each of the first 16 plain GEMM launches of a forward pass, in launch order."""
+        out = []
+        for i in range(16):
+            ms = C.c_float(); n = C.c_int()
+            self._chk(self._lib.stattn_get_kernel_ms(self._h, len(KERNEL_CLASSES) + i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out.append(ms.value)
+        return out

@@ -92,7 +92,7 @@ void bind_weights(stattn_handle* h) {
 // ---- profiling helpers -------------------------------------------------------------
 struct Prof {
     stattn_handle* h; int cls; hipEvent_t a = nullptr, b = nullptr; bool on;
-    Prof(stattn_handle* h_, int c) : h(h_), cls(c), on(h_->profiling) {
+    Prof(stattn_handle* h_, int c, bool enable = true) : h(h_), cls(c), on(h_->profiling && enable) {
         if (!on) return;
         auto get = [&]() { hipEvent_t e; if (!h->ev_pool.empty()) { e = h->ev_pool.back(); h->ev_pool.pop_back(); } else { (void)hipEventCreate(&e); } return e; };
         a = get(); b = get();
@@ -120,6 +120,8 @@ void prof_collect(stattn_handle* h) {
 // duration is what rocprofv3 reports for the symbol gemm_kernel<.., false, false>
 hipError_t gemm_nn(stattn_handle* h, const GemmArgs& g) {
     Prof pr(h, KC_GEMM_NN);
+    const int seq = h->gemm_seq++;
+    Prof one(h, KC_COUNT + (seq < KC_GEMM_SEQ ? seq : 0), seq < KC_GEMM_SEQ);   // the first 16 launches one by one
     return launch_gemm(h->stream, g, false, false);
 }
 
@@ -156,6 +158,8 @@ int bf16_weights(stattn_handle* h, BfWeights* b, bool readout) {
 
 hipError_t gemm_bf(stattn_handle* h, const GemmBfArgs& g) {
     Prof pr(h, KC_GEMM_NN);
+    const int seq = h->gemm_seq++;
+    Prof one(h, KC_COUNT + (seq < KC_GEMM_SEQ ? seq : 0), seq < KC_GEMM_SEQ);
     return launch_gemm_bf16(h->stream, g);
 }
 GemmBfArgs bf_args(const uint16_t* A, int lda, const uint16_t* B, int M, int N, int Kd) {
@@ -317,6 +321,7 @@ int pack_bwd_panels(stattn_handle* h, BwdPanels* p) {
 struct StepIO {
     int M, T, K;
     CtxPtrs c; const int* vid;
+    int group;                       // beam search: rows v * group + h share video v (0 / 1: every row has its own video index)
     const float* h_prev; const float* c_prev;
     float *sproj, *preh;             // [M,4D] each
     const float* xproj;              // [M,4D] (training: emb.W + b) or null
@@ -372,6 +377,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.PL = io.c.PL; a.L = io.c.L; a.LW = h->opt.lt_mode == 1 ? io.c.LW : nullptr;
         a.bf16 = h->opt.precision == 1;
         a.PG = io.c.PG; a.PM = io.c.PM; a.vid = io.vid;
+        a.group = h->opt.precision == 0 ? io.group : 0;
         a.sproj = io.sproj; a.ldsp = 4 * D;
         a.Ul = w.Ul; a.cl = w.cl; a.Ug = w.Ug; a.cg = w.cg; a.Um = w.Um; a.cm = w.cm;
         a.Ult = w.Ult; a.clt = w.clt; a.blt = w.blt;
@@ -967,7 +973,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     auto enqueue_word = [&](int parity) -> int {
         HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0));
         StepIO io{};
-        io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid;
+        io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
         io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
         io.dp = dp; io.mask = nullptr; io.d1 = nullptr;
         io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
@@ -1301,6 +1307,7 @@ int stattn_forward_train(stattn_handle* h) {
     CHK(prepare_masks(h, t, m, &dp, &d1, &d2));
 
     // ---- prologue, once per batch
+    h->gemm_seq = 0;
     BfWeights bw{};
     uint16_t* bemb = nullptr;
     CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
@@ -1994,11 +2001,11 @@ int stattn_set_profiling(stattn_handle* h, int enable) {
     if (!h) return STATTN_EINVAL;
     prof_collect(h);
     h->profiling = enable != 0;
-    for (int i = 0; i < KC_COUNT; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
+    for (int i = 0; i < KC_COUNT + KC_GEMM_SEQ; ++i) { h->k_ms[i] = 0; h->k_n[i] = 0; }
     return STATTN_OK;
 }
 int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches) {
-    if (!h || which < 0 || which >= KC_COUNT || !ms_avg) return STATTN_EINVAL;
+    if (!h || which < 0 || which >= KC_COUNT + KC_GEMM_SEQ || !ms_avg) return STATTN_EINVAL;
     prof_collect(h);
     *ms_avg = h->k_n[which] ? (float)(h->k_ms[which] / h->k_n[which]) : 0.f;
     if (launches) *launches = h->k_n[which];

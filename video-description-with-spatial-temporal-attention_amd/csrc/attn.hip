@@ -331,6 +331,120 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
     if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
 }
 
+// ---- beam-search variant: the H hypotheses of a video (rows v*H .. v*H+H-1) attend to the SAME region tensors, so
+// one workgroup per (video, frame) streams each K x D slab ONCE and applies it to all H state projections:
+// per step 3 slabs x nvid x T instead of 3 x H x that (BASELINE configs[4]: 1.0 GB instead of 5.2 GB through the CUs).
+// The slab is walked in groups of 8 regions held in registers (32 VGPRs); per hypothesis only the 8 partial scores,
+// the attended feature and its LW twin are carried (H x (8 + 4 + 4) VGPRs), the softmax lives in LDS.
+template <int H>
+__global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArgs a) {
+    __shared__ float s_red[4 * 2 * H];
+    __shared__ float s_e[H][KMAX];
+    const int T = a.T, K = a.K, D = a.D;
+    const int vt = blockIdx.x, v = vt / T, t = vt % T;
+    const int tid = threadIdx.x;
+    const size_t slab = ((size_t)v * T + t) * K * D;
+    const float* __restrict__ PL = a.PL + slab;
+    const float* __restrict__ L = a.L + slab;
+    const float* __restrict__ LW = a.LW ? a.LW + slab : nullptr;
+    const int b0 = v * H;                                   // first row (hypothesis) of this video
+    const int nd4 = D >> 2;
+
+    // ---- region scores of all hypotheses.  Wave w owns regions 8w .. 8w+7 (+32, ...) over the WHOLE of D (a row of a
+    // slab is 64 lanes x 16 B x D/256 fully coalesced loads), so a wave_sum finishes its scores: no cross-wave reduction
+    const int lane = tid & 63, w = tid >> 6;
+    for (int k0 = 8 * w; k0 < K; k0 += 32) {
+        float p[8 * H];          // p[h * 8 + kk]
+#pragma unroll
+        for (int i = 0; i < 8 * H; ++i) p[i] = 0.f;
+        for (int d4 = lane; d4 < nd4; d4 += 64) {
+            float4 x[8];
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) x[kk] = ld4(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
+            const float4 u4 = ld4(a.Ul + 4 * d4);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float4 s4 = ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4);
+#pragma unroll
+                for (int kk = 0; kk < 8; ++kk) p[h * 8 + kk] += dot4_tanh(x[kk], s4, u4);
+                __builtin_amdgcn_sched_barrier(0);     // one hypothesis at a time: interleaving all 8 H tanh chains spills
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8 * H; ++i) {
+            const float r = wave_sum(p[i]);
+            if (lane == 0 && k0 + (i & 7) < K) s_e[i >> 3][k0 + (i & 7)] = r + a.cl[0];
+        }
+    }
+    // ---- the two frame scores per hypothesis (PG / PM rows are shared by the hypotheses as well)
+    {
+        float q[2 * H];
+#pragma unroll
+        for (int i = 0; i < 2 * H; ++i) q[i] = 0.f;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const size_t fo = ((size_t)v * T + t) * D + 4 * d4;
+            const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo), ug = ld4(a.Ug + 4 * d4), um = ld4(a.Um + 4 * d4);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float* sp = a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4;
+                q[2 * h] += dot4_tanh(pg, ld4(sp + D), ug);
+                q[2 * h + 1] += dot4_tanh(pm, ld4(sp + 2 * D), um);
+            }
+        }
+        block_sum<2 * H>(q, s_red, tid);
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+            if (tid == h) { a.eg[(size_t)(b0 + h) * T + t] = q[2 * h] + a.cg[0]; a.em[(size_t)(b0 + h) * T + t] = q[2 * h + 1] + a.cm[0]; }
+    }
+    __syncthreads();
+    // ---- softmax over the regions, one wave-lane group per hypothesis (K <= 64: one lane per region)
+    for (int h = w; h < H; h += 4) {                        // one wave per hypothesis, one lane per region
+        const float e = lane < K ? s_e[h][lane] : -INFINITY;
+        const float mx = wave_max(e);
+        const float ex = lane < K ? __expf(e - mx) : 0.f;
+        const float al = ex / wave_sum(ex);
+        if (lane < K) { s_e[h][lane] = al; a.alphal[((size_t)(b0 + h) * T + t) * K + lane] = al; }
+    }
+    __syncthreads();
+    // ---- attended local feature (and the local-temporal score) per hypothesis: L / LW streamed once
+    float pe[H];
+#pragma unroll
+    for (int h = 0; h < H; ++h) pe[h] = 0.f;
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        float4 c4[H], w4[H];
+#pragma unroll
+        for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
+#pragma unroll 4
+        for (int k = 0; k < K; ++k) {
+            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
+            const float4 q4 = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int h = 0; h < H; ++h) {
+                const float al = s_e[h][k];
+                c4[h].x += al * l4.x; c4[h].y += al * l4.y; c4[h].z += al * l4.z; c4[h].w += al * l4.w;
+                w4[h].x += al * q4.x; w4[h].y += al * q4.y; w4[h].z += al * q4.z; w4[h].w += al * q4.w;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        const float4 bl = LW ? ld4(a.blt + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int h = 0; h < H; ++h) {
+            st4(a.CL + ((size_t)(b0 + h) * T + t) * D + 4 * d4, c4[h]);
+            if (LW) {
+                float4 z = w4[h];
+                z.x += bl.x; z.y += bl.y; z.z += bl.z; z.w += bl.w;
+                pe[h] += dot4_tanh(z, ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 3 * D + 4 * d4), ld4(a.Ult + 4 * d4));
+            }
+        }
+    }
+    if (LW) {
+        block_sum<H>(pe, s_red, tid);
+#pragma unroll
+        for (int h = 0; h < H; ++h)
+            if (tid == h) a.elt[(size_t)(b0 + h) * T + t] = pe[h] + a.clt[0];
+    }
+}
+
 // one wave per row: out[r] = dot(P[r,:], U) + c
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P, int ldp,
                                                      const float* __restrict__ U, const float* __restrict__ c,
@@ -431,6 +545,22 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
         if (a.D % 8 != 0 || !a.LW) return hipErrorInvalidValue;
         if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
         else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T), dim3(256), 0, s, a);
+        return hipGetLastError();
+    }
+    // beam search: the `group` consecutive rows of a video share its region tensors -> one pass over each slab
+    static const char* noshare = getenv("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
+    // (worth it once the (video, frame) grid alone fills the chip several times: 104 workgroups at configs[0] do not)
+    if (a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= 2048) {
+        const dim3 grid(a.M / a.group * a.T), block(256);
+        switch (a.group) {
+            case 2: hipLaunchKernelGGL(spatial_shared_kernel<2>, grid, block, 0, s, a); break;
+            case 3: hipLaunchKernelGGL(spatial_shared_kernel<3>, grid, block, 0, s, a); break;
+            case 4: hipLaunchKernelGGL(spatial_shared_kernel<4>, grid, block, 0, s, a); break;
+            case 5: hipLaunchKernelGGL(spatial_shared_kernel<5>, grid, block, 0, s, a); break;
+            case 6: hipLaunchKernelGGL(spatial_shared_kernel<6>, grid, block, 0, s, a); break;
+            case 7: hipLaunchKernelGGL(spatial_shared_kernel<7>, grid, block, 0, s, a); break;
+            default: hipLaunchKernelGGL(spatial_shared_kernel<8>, grid, block, 0, s, a); break;
+        }
         return hipGetLastError();
     }
     // D a multiple of 1024: 128-thread workgroups with two columns per thread (all items of configs[1] resident at

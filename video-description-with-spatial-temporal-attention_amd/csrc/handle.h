@@ -43,6 +43,7 @@ struct DevBuf {
 };
 
 enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_COUNT };
+constexpr int KC_GEMM_SEQ = 16;      // the first 16 plain GEMM launches of a forward pass are also timed one by one
 
 struct Weights {   // device pointers into the flat parameter buffer
     float *Wemb, *ff_state_W, *ff_state_b, *ff_memory_W, *ff_memory_b, *ff_local_W, *ff_local_b,
@@ -118,8 +119,9 @@ struct stattn_handle {
     struct EvPair { hipEvent_t a, b; int cls; };
     std::vector<EvPair> ev_used;
     std::vector<hipEvent_t> ev_pool;
-    double k_ms[KC_COUNT] = {0};
-    int k_n[KC_COUNT] = {0};
+    double k_ms[KC_COUNT + KC_GEMM_SEQ] = {0};
+    int k_n[KC_COUNT + KC_GEMM_SEQ] = {0};
+    int gemm_seq = 0;                     // index of the next plain GEMM launch within the current forward pass
 
     // data parallel (comm.cpp): RCCL communicator of this rank, a side stream for the bucketed gradient reduce
     void* comm = nullptr;                 // ncclComm_t

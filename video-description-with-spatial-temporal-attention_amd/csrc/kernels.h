@@ -171,6 +171,8 @@ struct SpatialArgs {
     int bf16;                                           // PL / L / LW hold bf16 (precision = bf16 handles; lt_mode 1)
     const float* PG; const float* PM;                   // [nvid,T,D]
     const int* vid;
+    int group;                                          // > 1: rows b = v * group + h are the hypotheses of video v (beam search);
+                                                        // fp32 only, vid ignored
     // state projections of this step: sproj[b] = [sl | sg | sm | slt], row stride ldsp
     const float* sproj; int ldsp;
     const float* Ul; const float* cl;    // [D], [1]

@@ -332,6 +332,8 @@ struct StepIO {
     const FwdPanels* pn;             // packed weight panels, or null -> the 64-column skinny kernels
     const float* h_prev_pk;          // with pn: h_prev in the packed A layout (or null: plain rows are gathered)
     float *h_out_pk, *ctx_pk;        // with pn: packed copies written by the LSTM / temporal kernels (or null)
+    const float* emb_pk;             // with pn, sampling: emb in the packed A layout (or null)
+    float* hd_pk;                    // with pn, sampling: packed copy of hd for the readout (or null)
 };
 
 // one decoder timestep: _step, model_attention.py:366-459
@@ -409,8 +411,8 @@ int run_step(stattn_handle* h, const StepIO& io) {
         Prof pr(h, KC_LSTM);
         LstmPnArgs a{};
         a.npairs = 1; a.p[0] = io.ctx_pk ? PnPair{io.ctx_pk, D, io.pn->Wc, D, 1} : PnPair{io.ctx, D, io.pn->Wc, D, 0};
-        if (io.emb) { a.p[1] = PnPair{io.emb, E, io.pn->W, E, 0}; a.npairs = 2; a.bias = w.b; }
-        a.h_pk = io.h_out_pk;
+        if (io.emb) { a.p[1] = io.emb_pk ? PnPair{io.emb_pk, E, io.pn->W, E, 1} : PnPair{io.emb, E, io.pn->W, E, 0}; a.npairs = 2; a.bias = w.b; }
+        a.h_pk = io.h_out_pk; a.hd_pk = io.hd_pk;
         a.pre_add = io.preh; a.ldpre = 4 * D;
         a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
         a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
@@ -969,9 +971,19 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
     FwdPanels pn{};
     const bool panels = use_panels(h, M) && Vp % 16 == 0;
-    if (panels) CHK(pack_fwd_panels(h, &pn, true));
+    float *hp_pk = nullptr, *ctx_pk = nullptr, *emb_pk = nullptr, *hd_pk = nullptr, *a1_pk = nullptr;
+    if (panels) {
+        CHK(pack_fwd_panels(h, &pn, true));
+        // packed-A copies of every activation that feeds a row-panel GEMM, written by the kernel that produces it
+        CHK(getbuf_t(h, "bs_hp_pk", packed_rows_floats(M, D), &hp_pk)); CHK(getbuf_t(h, "bs_ctx_pk", packed_rows_floats(M, D), &ctx_pk));
+        CHK(getbuf_t(h, "bs_emb_pk", packed_rows_floats(M, E), &emb_pk)); CHK(getbuf_t(h, "bs_hd_pk", packed_rows_floats(M, D), &hd_pk));
+        CHK(getbuf_t(h, "bs_a1_pk", packed_rows_floats(M, E), &a1_pk));
+        for (float* q : {ctx_pk, hd_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, D) * sizeof(float), s));
+        for (float* q : {emb_pk, a1_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, E) * sizeof(float), s));
+        HIPCHK(h, launch_pack_rows(s, hp, D, M, D, hp_pk));          // initial states; later words: beam_update's gather
+    }
     auto enqueue_word = [&](int parity) -> int {
-        HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0));
+        HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0, emb_pk));
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
         io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
@@ -980,14 +992,16 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
         io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
         io.pn = panels ? &pn : nullptr;
+        io.h_prev_pk = hp_pk; io.h_out_pk = nullptr; io.ctx_pk = ctx_pk; io.emb_pk = emb_pk; io.hd_pk = hd_pk;
         CHK(run_step(h, io));
         if (panels) {      // readout (:817-838) on the row-panel kernel
             PnArgs a{};
             a.M = M; a.nseg = 1;
             PnSeg& sg = a.seg[0];
             pn_seg_defaults(sg);
-            sg.npairs = 1; sg.p[0] = PnPair{hd, D, pn.Wl1, D};
-            if (h->opt.ctx2out) { sg.p[1] = PnPair{ctx, D, pn.Wl2, D}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.npairs = 1; sg.p[0] = PnPair{hd_pk, D, pn.Wl1, D, 1};
+            if (h->opt.ctx2out) { sg.p[1] = PnPair{ctx_pk, D, pn.Wl2, D, 1}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.Cpk = a1_pk;
             sg.bias = w.bl1;
             if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
             sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
@@ -996,7 +1010,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
             b.M = M; b.nseg = 1;
             PnSeg& so = b.seg[0];
             pn_seg_defaults(so);
-            so.npairs = 1; so.p[0] = PnPair{a1, E, pn.Wo, E};
+            so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
             so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
             HIPCHK(h, launch_panel(s, b));
             HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
@@ -1028,7 +1042,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
-        ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows;
+        ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         HIPCHK(h, launch_beam_update(s, ba));
         return STATTN_OK;
@@ -1054,7 +1068,8 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                           (const void*)ag, (const void*)am, (const void*)alt, (const void*)ctx, (const void*)a1, (const void*)lg,
                           (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
                           (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
-                          (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows})
+                          (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows, (const void*)hp_pk,
+                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk})
         sig.push_back((uintptr_t)q);
     if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
         gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is

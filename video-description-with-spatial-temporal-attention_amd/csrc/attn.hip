@@ -414,15 +414,22 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         float4 c4[H], w4[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
-#pragma unroll 4
-        for (int k = 0; k < K; ++k) {
-            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
-            const float4 q4 = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int k0 = 0; k0 < K; k0 += 4) {            // four regions' loads (8 x 16 B per lane) in flight together
+            float4 l4[4], q4[4];
 #pragma unroll
-            for (int h = 0; h < H; ++h) {
-                const float al = s_e[h][k];
-                c4[h].x += al * l4.x; c4[h].y += al * l4.y; c4[h].z += al * l4.z; c4[h].w += al * l4.w;
-                w4[h].x += al * q4.x; w4[h].y += al * q4.y; w4[h].z += al * q4.z; w4[h].w += al * q4.w;
+            for (int kk = 0; kk < 4; ++kk) {
+                const int k = min(k0 + kk, K - 1);
+                l4[kk] = ld4(L + (size_t)k * D + 4 * d4);
+                q4[kk] = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+#pragma unroll
+            for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+                for (int h = 0; h < H; ++h) {
+                    const float al = k0 + kk < K ? s_e[h][k0 + kk] : 0.f;
+                    c4[h].x += al * l4[kk].x; c4[h].y += al * l4[kk].y; c4[h].z += al * l4[kk].z; c4[h].w += al * l4[kk].w;
+                    w4[h].x += al * q4[kk].x; w4[h].y += al * q4[kk].y; w4[h].z += al * q4[kk].z; w4[h].w += al * q4[kk].w;
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
         }

@@ -170,6 +170,8 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
             float* __restrict__ hd = a.h_next + (size_t)(v * k + slot) * D;
             float* __restrict__ cd = a.c_next + (size_t)(v * k + slot) * D;
             for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
+            if (a.h_next_pk)
+                for (int d = tid; d < D; d += 256) a.h_next_pk[pn_pack_offset(v * k + slot, d, D >> 4)] = hs[d];
         }
     }
     // the video's loop ends with this word (:974-977): gen_sample returns f_next's state outputs of this very call,

@@ -140,6 +140,7 @@ struct PnSeg {
     const float* add; int ldadd;
     const float* mul; int ldmul;
     float scale; int act;
+    float* Cpk;                        // optional: the result once more in the packed A layout (it feeds another panel GEMM)
 };
 struct PnArgs {
     PnSeg seg[6]; int nseg; int M;
@@ -155,6 +156,7 @@ struct LstmPnArgs {
     const float* h_prev; const float* c_prev; float* h_out; float* c_out; float* gates;
     const float* d1; int ldd1; float d1_scalar; float* hd_out;
     float* h_pk;                       // optional: h_out once more in the packed A layout (next step's state projections)
+    float* hd_pk;                      // optional: hd_out in the packed A layout (sampler readout)
     int M, D;
 };
 hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a);
@@ -213,7 +215,8 @@ hipError_t launch_iota(hipStream_t s, int* p, int n, int mul);   // p[i] = i * m
 // mean[b,:] = sum_t G[b,t,:] / sum_t mask[b,t]   (model_attention.py:618, 649 / 739, 766)
 hipError_t launch_ctx_mean(hipStream_t s, const float* G, const float* mask, float* mean, int B, int T, int D);
 // emb[r,:] = (x[r] < 0) ? 0 : Wemb[x[r],:] ; shift>0: row r reads x[r - shift] and rows < shift are zero
-hipError_t launch_embed(hipStream_t s, const int64_t* x, const float* Wemb, float* emb, int rows, int E, int V, int shift);
+hipError_t launch_embed(hipStream_t s, const int64_t* x, const float* Wemb, float* emb, int rows, int E, int V, int shift,
+                        float* emb_pk = nullptr);   // emb_pk: optional copy in the packed A layout (pn_pack_offset)
 // row softmax over V (ld = ldl) + optional NLL:  nll[r] = -log(p[r, x[r]] + 1e-8)
 hipError_t launch_softmax_nll(hipStream_t s, const float* logits, int ldl, float* probs, int ldp,
                               const int64_t* x, float* nll, int64_t* argmax, int rows, int V);
@@ -337,6 +340,7 @@ struct BeamArgs {
     int64_t* next_w;                    // [nvid*k] word fed to the next step
     const float* h_step; const float* c_step;       // [nvid*k, D] state after this step
     float* h_next; float* c_next;       // [nvid*k, D] state gathered for the next step
+    float* h_next_pk;                   // optional: h_next in the packed A layout of the row-panel kernels
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
 };
 int beam_topk_splits(int nvid);

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void ctx_mean_kernel(const float* __restrict__
 // (shift = m: "shift forward in time"), rows < shift are zero.  Sampling (:803-804): shift = 0 and
 // a negative index (-1 = first word) gives the zero vector.
 __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ x, const float* __restrict__ Wemb,
-                                                    float* __restrict__ emb, int rows, int E, int V, int shift) {
+                                                    float* __restrict__ emb, int rows, int E, int V, int shift,
+                                                    float* __restrict__ emb_pk) {
     const int r = blockIdx.x;
     int64_t w = -1;
     if (r >= shift) w = x[r - shift];
@@ -42,6 +43,7 @@ __global__ __launch_bounds__(256) void embed_kernel(const int64_t* __restrict__ 
         float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
         if (w >= 0) v = ld4(Wemb + (size_t)w * E + 4 * e4);
         st4(emb + (size_t)r * E + 4 * e4, v);
+        if (emb_pk) st4(emb_pk + pn_pack_offset(r, 4 * e4, E >> 4), v);      // packed A layout of the row-panel kernels
     }
 }
 
@@ -193,9 +195,9 @@ hipError_t launch_ctx_mean(hipStream_t s, const float* G, const float* mask, flo
     hipLaunchKernelGGL(ctx_mean_kernel, dim3(B, (D + 255) / 256), dim3(256), 0, s, G, mask, mean, T, D);
     return hipGetLastError();
 }
-hipError_t launch_embed(hipStream_t s, const int64_t* x, const float* Wemb, float* emb, int rows, int E, int V, int shift) {
+hipError_t launch_embed(hipStream_t s, const int64_t* x, const float* Wemb, float* emb, int rows, int E, int V, int shift, float* emb_pk) {
     if (rows <= 0) return hipSuccess;
-    hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, s, x, Wemb, emb, rows, E, V, shift);
+    hipLaunchKernelGGL(embed_kernel, dim3(rows), dim3(256), 0, s, x, Wemb, emb, rows, E, V, shift, emb_pk);
     return hipGetLastError();
 }
 hipError_t launch_softmax_nll(hipStream_t s, const float* logits, int ldl, float* probs, int ldp,

@@ -211,6 +211,7 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         v *= sg.scale;
         if (sg.mul) v *= sg.mul[(size_t)row * sg.ldmul + n];
         sg.C[(size_t)row * sg.ldc + n] = v;
+        if (sg.Cpk) sg.Cpk[pn_pack_offset(row, n, sg.N >> 4)] = v;
     }
     PN_STAMP(3);
 }
@@ -305,6 +306,7 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
             gt[0] = gi; gt[D] = gf; gt[2 * D] = go; gt[3 * D] = gg;
         }
         if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * e.d1;
+        if (a.hd_pk) a.hd_pk[pn_pack_offset(row, d, D >> 4)] = hn * e.d1;
     }
     PN_STAMP(3);
 }

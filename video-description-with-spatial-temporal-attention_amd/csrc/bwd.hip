@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 //   dMo      = sum_s am_s dcsum_s
 // and the per-(b,t) partials of dUl, dUlt, dUg, dUm (summed over rows by colsum afterwards).
 
-__global__ __launch_bounds__(256) void ctxgrad_kernel(const CtxGradArgs a) {
+__global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a) {
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
     const int bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
     const int nd4 = D >> 2;
@@ -323,13 +323,21 @@ __global__ __launch_bounds__(256) void ctxgrad_kernel(const CtxGradArgs a) {
             const size_t fo = (size_t)bt * D + 4 * d4;
             const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
             float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg;
+            struct FrameIn { float4 sg, sm, dcs; float deg, dem, am; };
+            auto fetch_f = [&](int s_) {
+                FrameIn r;
+                const float* sp = a.sproj + ((size_t)s_ * M + b) * 4 * D;
+                r.sg = ld4(sp + D + 4 * d4); r.sm = ld4(sp + 2 * D + 4 * d4);
+                r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
+                r.deg = a.deg[s_ * MT + bt]; r.dem = a.dem[s_ * MT + bt]; r.am = a.am[s_ * MT + bt];
+                return r;
+            };
             for (int s = 0; s < S; ++s) {
-                const float* sp = a.sproj + ((size_t)s * M + b) * 4 * D;
-                const float deg = a.deg[s * MT + bt], dem = a.dem[s * MT + bt], am = a.am[s * MT + bt];
-                const float4 tg = tanh4s(pg, ld4(sp + D + 4 * d4)), tm = tanh4s(pm, ld4(sp + 2 * D + 4 * d4));
-                fma4(dpg, deg, one_minus_sq(tg)); fma4(ug, deg, tg);
-                fma4(dpm, dem, one_minus_sq(tm)); fma4(um, dem, tm);
-                fma4(dmo, am, ld4(a.dcsum + ((size_t)s * M + b) * D + 4 * d4));
+                const FrameIn cf = fetch_f(s);
+                const float4 tg = tanh4s(pg, cf.sg), tm = tanh4s(pm, cf.sm);
+                fma4(dpg, cf.deg, one_minus_sq(tg)); fma4(ug, cf.deg, tg);
+                fma4(dpm, cf.dem, one_minus_sq(tm)); fma4(um, cf.dem, tm);
+                fma4(dmo, cf.am, cf.dcs);
             }
             st4(a.dPG + fo, mul4(dpg, ld4(a.Ug + 4 * d4)));
             st4(a.dPM + fo, mul4(dpm, ld4(a.Um + 4 * d4)));
@@ -337,48 +345,67 @@ __global__ __launch_bounds__(256) void ctxgrad_kernel(const CtxGradArgs a) {
             st4(a.pUg + fo, ug);
             st4(a.pUm + fo, um);
         }
-        // region-level tensors, 8 regions at a time
+        // region-level tensors, 4 regions at a time.  (8 at a time meant 40 float4 accumulators = one wave per SIMD for a
+        // kernel whose floor is VALU issue -- 0.4 G tanh -- not bandwidth; 4 at a time re-reads the per-step operands
+        // K / 4 times (L2 hits) and runs three waves per SIMD.)
         float4 pul = make_float4(0.f, 0.f, 0.f, 0.f), pult = pul;
-        for (int k0 = 0; k0 < K; k0 += 8) {
-            float4 pl[8], lw[8], dpl[8], dl[8], dlw[8];
+        for (int k0 = 0; k0 < K; k0 += 4) {
+            float4 pl[4], lw[4], lwx[4], dpl[4], dl[4], dlw[4];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
+            for (int kk = 0; kk < 4; ++kk) {
                 const size_t o = slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
                 pl[kk] = ld4(a.PL + o); lw[kk] = ld4(a.LW + o);
+                // first pass, K <= 8: regions 4..7 of LW as well -- plt below needs every region of the frame
+                lwx[kk] = (k0 == 0 && K > 4 && K <= 8) ? ld4(a.LW + slab + (size_t)min(4 + kk, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
             }
-            for (int s = 0; s < S; ++s) {
-                const float* sp = a.sproj + ((size_t)s * M + b) * 4 * D;
-                const float4 sl = ld4(sp + 4 * d4);
-                const float4 dcl = scale4(ld4(a.dcsum + ((size_t)s * M + b) * D + 4 * d4), a.alt[s * MT + bt]);
-                const float4 dp = ld4(a.dplt + (s * MT + bt) * D + 4 * d4);
-                const float* als = a.alphal + (s * MT + bt) * K;
-                const float* des = a.del + (s * MT + bt) * K;
+            struct StepIn { float4 sl, dcs, dp, slt; float alt, delt; float al[4], de[4], alx[4]; };
+            auto fetch = [&](int s_) {
+                StepIn r;
+                const float* sp = a.sproj + ((size_t)s_ * M + b) * 4 * D;
+                r.sl = ld4(sp + 4 * d4);
+                r.slt = ld4(sp + 3 * D + 4 * d4);
+                r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
+                r.dp = ld4(a.dplt + (s_ * MT + bt) * D + 4 * d4);
+                r.alt = a.alt[s_ * MT + bt];
+                r.delt = a.delt[s_ * MT + bt];
+                const float* als = a.alphal + (s_ * MT + bt) * K;
+                const float* des = a.del + (s_ * MT + bt) * K;
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
+                for (int kk = 0; kk < 4; ++kk) {
                     const int k = min(k0 + kk, K - 1);
-                    const float al = als[k], de = des[k];
-                    const float4 th = tanh4s(pl[kk], sl);
-                    fma4(dpl[kk], de, one_minus_sq(th));
-                    if (k0 + kk < K) fma4(pul, de, th);
-                    fma4(dl[kk], al, dcl);
-                    fma4(dlw[kk], al, dp);
+                    r.al[kk] = als[k]; r.de[kk] = des[k]; r.alx[kk] = als[min(4 + kk, K - 1)];
                 }
-                if (k0 == 0) {   // dUlt partial: delt * tanh(plt + slt), plt recomputed from LW (needs all K; K <= 8 fast path)
-                    if (K <= 8) {
-                        float4 plt = blt;
+                return r;
+            };
+            for (int s = 0; s < S; ++s) {
+                const StepIn cur = fetch(s);
+                const float4 dcl = scale4(cur.dcs, cur.alt);
 #pragma unroll
-                        for (int kk = 0; kk < 8; ++kk) if (kk < K) fma4(plt, als[kk], lw[kk]);
-                        fma4(pult, a.delt[s * MT + bt], tanh4s(plt, ld4(sp + 3 * D + 4 * d4)));
+                for (int kk = 0; kk < 4; ++kk) {
+                    const float4 th = tanh4s(pl[kk], cur.sl);
+                    fma4(dpl[kk], cur.de[kk], one_minus_sq(th));
+                    if (k0 + kk < K) fma4(pul, cur.de[kk], th);
+                    fma4(dl[kk], cur.al[kk], dcl);
+                    fma4(dlw[kk], cur.al[kk], cur.dp);
+                }
+                if (k0 == 0) {   // dUlt partial: delt * tanh(plt + slt), plt = blt + sum_k alpha_k LW_k recomputed (all K regions)
+                    float4 plt = blt;
+                    if (K <= 8) {
+#pragma unroll
+                        for (int kk = 0; kk < 4; ++kk) {
+                            if (kk < K) fma4(plt, cur.al[kk], lw[kk]);
+                            if (4 + kk < K) fma4(plt, cur.alx[kk], lwx[kk]);
+                        }
                     } else {
-                        float4 plt = blt;
+                        const float* als = a.alphal + (s * MT + bt) * K;
                         for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
-                        fma4(pult, a.delt[s * MT + bt], tanh4s(plt, ld4(sp + 3 * D + 4 * d4)));
                     }
+                    fma4(pult, cur.delt, tanh4s(plt, cur.slt));
                 }
             }
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
+            for (int kk = 0; kk < 4; ++kk) {
                 if (k0 + kk < K) {
                     const size_t o = slab + (size_t)(k0 + kk) * D + 4 * d4;
                     st4(a.dPL + o, mul4(dpl[kk], ul));

@@ -467,6 +467,11 @@ __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P
     if (lane == 0) out[r] = s + c[0];
 }
 
+// One workgroup per (row b, 256-wide slice of D).  The frames a wave will weight (t = w, w+4, ...) are requested
+// BEFORE the softmaxes: their addresses do not depend on the attention weights, so the loads fly while the three
+// softmaxes are computed (they used to start after the barrier: two dependent latencies per launch).
+constexpr int TPF = 8;    // frames per wave held in registers (T <= 32); longer videos loop
+
 __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     __shared__ float s_al[3][TMAX];
     __shared__ float s_sel;
@@ -475,6 +480,17 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+    const int d = chunk * 256 + 4 * lane;
+    const bool on = d < D;
+    const float* __restrict__ G = a.G + (size_t)v * T * D + (on ? d : 0);
+    const float* __restrict__ Mo = a.Mo + (size_t)v * T * D + (on ? d : 0);
+    const float* __restrict__ CL = a.CL + (size_t)b * T * D + (on ? d : 0);
+    float4 g4[TPF], m4[TPF], c4[TPF];
+#pragma unroll
+    for (int i = 0; i < TPF; ++i) {
+        const int t = min(w + 4 * i, T - 1);
+        g4[i] = ld4(G + (size_t)t * D); m4[i] = ld4(Mo + (size_t)t * D); c4[i] = ld4(CL + (size_t)t * D);
+    }
 
     if (w < 3) {          // three softmaxes over T, one wave each
         const float* e = (w == 0 ? a.eg : (w == 1 ? a.em : a.elt)) + (size_t)b * T;
@@ -510,25 +526,29 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     __syncthreads();
 
     // weighted sums over frames: wave w takes t = w, w+4, ...; lane owns 4 consecutive d
-    const int d = chunk * 256 + 4 * lane;
     float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (d < D) {
-        const float* __restrict__ G = a.G + (size_t)v * T * D + d;
-        const float* __restrict__ Mo = a.Mo + (size_t)v * T * D + d;
-        const float* __restrict__ CL = a.CL + (size_t)b * T * D + d;
-#pragma unroll 2
-        for (int t = w; t < T; t += 4) {
+#pragma unroll
+    for (int i = 0; i < TPF; ++i) {
+        const int t = w + 4 * i;
+        if (t < T) {
             const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
-            const float4 g4 = ld4(G + (size_t)t * D), m4 = ld4(Mo + (size_t)t * D), c4 = ld4(CL + (size_t)t * D);
-            acc.x += ag * g4.x + am * m4.x + alt * c4.x;
-            acc.y += ag * g4.y + am * m4.y + alt * c4.y;
-            acc.z += ag * g4.z + am * m4.z + alt * c4.z;
-            acc.w += ag * g4.w + am * m4.w + alt * c4.w;
+            acc.x += ag * g4[i].x + am * m4[i].x + alt * c4[i].x;
+            acc.y += ag * g4[i].y + am * m4[i].y + alt * c4[i].y;
+            acc.z += ag * g4[i].z + am * m4[i].z + alt * c4[i].z;
+            acc.w += ag * g4[i].w + am * m4[i].w + alt * c4[i].w;
         }
+    }
+    for (int t = w + 4 * TPF; t < T; t += 4) {          // frames past the register-held ones (T > 32)
+        const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
+        const float4 g = ld4(G + (size_t)t * D), m = ld4(Mo + (size_t)t * D), c = ld4(CL + (size_t)t * D);
+        acc.x += ag * g.x + am * m.x + alt * c.x;
+        acc.y += ag * g.y + am * m.y + alt * c.y;
+        acc.z += ag * g.z + am * m.z + alt * c.z;
+        acc.w += ag * g.w + am * m.w + alt * c.w;
     }
     st4(&s_part[w][4 * lane], acc);
     __syncthreads();
-    if (w == 0 && d < D) {
+    if (w == 0 && on) {
         float4 r = ld4(&s_part[0][4 * lane]);
 #pragma unroll
         for (int i = 1; i < 4; ++i) {

@@ -27,3 +27,25 @@ def main(path, out=None):
 
 if __name__ == "__main__":
     main(*sys.argv[1:3])
+
+
+def bench_traffic(fetch_csv, write_csv, out_json, keys):
+    """profiles/pmc_traffic.json for bench.py: HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) of the kernels its
+    roofline objects name, from two summaries written by main().  `keys`: the bench configurations the PMC command covers."""
+    import json
+    pats = {"gemm_nn": "gemm2_kernel<1, 1, false, false, false>", "spatial": "spatial2_kernel<128>", "temporal": "temporal_kernel"}
+
+    def col(path, pat, idx):
+        for r in csv.reader(open(path)):
+            if len(r) > idx and pat in r[0]:
+                return float(r[idx]) * 1e6
+        return 0.0
+    vals = {k: col(fetch_csv, p, 5) + col(write_csv, p, 4) for k, p in pats.items()}
+    try:
+        cur = json.load(open(out_json))
+    except Exception:
+        cur = {}
+    for k in keys:
+        cur[k] = vals
+    json.dump(cur, open(out_json, "w"), indent=1, sort_keys=True)
+    print(vals)

@@ -461,6 +461,59 @@ int prepare_masks(stattn_handle* h, int t, int m, float** dp, float** d1, float*
     return STATTN_OK;
 }
 
+// Plan of the deterministic embedding gradient (bwd.hip embed_bwd_*): tokens 0 .. (t-1)*m - 1 are the ones whose
+// embedding enters the scan (emb is shifted by one step, :613-617).  Layout of the int buffer:
+// perm[ntok] | piece_start[np+1] | piece_word[np] | word_piece_start[nw+1] | word_id[nw] | multi_word[nmulti]
+void build_embed_plan(const int64_t* x, int t, int m, std::vector<int>& buf, stattn_handle::EmbPlanHost& ph) {
+    const int ntok = (t - 1) * m;
+    std::vector<std::pair<int64_t, int>> tok(ntok > 0 ? ntok : 0);
+    for (int i = 0; i < ntok; ++i) tok[i] = {x[i], i};
+    std::sort(tok.begin(), tok.end());                     // by word, then by index (pairs: deterministic)
+    std::vector<int> perm(ntok), piece_start, piece_word, word_piece_start, word_id, multi;
+    for (int i = 0; i < ntok; ++i) perm[i] = tok[i].second;
+    for (int i = 0; i < ntok;) {
+        int j = i;
+        while (j < ntok && tok[j].first == tok[i].first) ++j;
+        const int wi = (int)word_id.size();
+        word_id.push_back((int)tok[i].first);
+        word_piece_start.push_back((int)piece_word.size());
+        for (int p = i; p < j; p += 16) { piece_start.push_back(p); piece_word.push_back(wi); }
+        if (j - i > 16) multi.push_back(wi);
+        i = j;
+    }
+    piece_start.push_back(ntok);
+    word_piece_start.push_back((int)piece_word.size());
+    ph.ntok = ntok; ph.npieces = (int)piece_word.size(); ph.nwords = (int)word_id.size(); ph.nmulti = (int)multi.size();
+    buf.clear();
+    for (const std::vector<int>* v : {&perm, &piece_start, &piece_word, &word_piece_start, &word_id, &multi}) buf.insert(buf.end(), v->begin(), v->end());
+    if (buf.empty()) buf.push_back(0);
+}
+
+// stage the plan of batch set `set` (stream-ordered copy; the host vector is kept alive in the handle until then)
+int stage_embed_plan(stattn_handle* h, const int64_t* x, int t, int m, int set, hipStream_t stream) {
+    static thread_local std::vector<int> buf;
+    build_embed_plan(x, t, m, buf, h->emb_plan[set]);
+    int* d;
+    CHK(getbuf_t(h, bset(h, "embplan", set).c_str(), buf.size(), &d));
+    HIPCHK(h, hipMemcpyAsync(d, buf.data(), buf.size() * sizeof(int), hipMemcpyHostToDevice, stream));
+    HIPCHK(h, hipStreamSynchronize(stream));             // pageable source: the copy must finish before buf is reused
+    return STATTN_OK;
+}
+
+EmbedPlan device_embed_plan(stattn_handle* h, int set) {
+    const stattn_handle::EmbPlanHost& ph = h->emb_plan[set];
+    const int* d = reinterpret_cast<const int*>(h->bufs[bset(h, "embplan", set)].p);
+    EmbedPlan pl{};
+    pl.perm = d; d += ph.ntok;
+    pl.piece_start = d; d += ph.npieces + 1;
+    pl.piece_word = d; d += ph.npieces;
+    pl.word_piece_start = d; d += ph.nwords + 1;
+    pl.word_id = d; d += ph.nwords;
+    pl.multi_word = d;
+    pl.npieces = ph.npieces; pl.nwords = ph.nwords; pl.nmulti = ph.nmulti;
+    return pl;
+}
+
 // Wemb[x] raises IndexError in the reference for an out-of-range word (:613); the kernels would clamp silently
 int check_words(stattn_handle* h, const int64_t* x, size_t n, const char* who) {
     for (size_t i = 0; i < n; ++i)
@@ -540,6 +593,8 @@ void stattn_destroy(stattn_handle* h) {
     comm_release(h);
     if (h->beam_gexec) (void)hipGraphExecDestroy(h->beam_gexec);
     if (h->pin_io) (void)hipHostFree(h->pin_io);
+    if (h->pin_plan[0]) (void)hipHostFree(h->pin_plan[0]);
+    if (h->pin_plan[1]) (void)hipHostFree(h->pin_plan[1]);
     if (h->d_params) (void)hipFree(h->d_params);
     if (h->d_grads) (void)hipFree(h->d_grads);
     if (h->d_rg2) (void)hipFree(h->d_rg2);
@@ -1198,6 +1253,7 @@ int stattn_set_batch(stattn_handle* h, const int64_t* x, const float* mask, int 
     HIPCHK(h, hipMemcpyAsync(rl, ctxl, (size_t)m * T * K * h->Fl * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipMemcpyAsync(rm, ctxm, (size_t)m * T * h->Fm * 4, hipMemcpyHostToDevice, s));
     HIPCHK(h, hipStreamSynchronize(s));
+    CHK(stage_embed_plan(h, x, t, m, h->cur_set, s));
     h->t = t; h->m = m; h->T = T; h->K = K;
     h->have_batch = true; h->have_fwd = false; h->have_bwd = false;
     return STATTN_OK;
@@ -1249,6 +1305,21 @@ int stattn_prefetch_batch(stattn_handle* h, const int64_t* x, const float* mask,
     HIPCHK(h, hipMemcpyAsync(mG, mask_ctxg, (size_t)m * T * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(h, hipMemcpyAsync(rl, ctxl, (size_t)m * T * K * h->Fl * 4, hipMemcpyHostToDevice, cs));
     HIPCHK(h, hipMemcpyAsync(rm, ctxm, (size_t)m * T * h->Fm * 4, hipMemcpyHostToDevice, cs));
+    {   // the embedding-gradient plan of the shadow set: a few KB through a pinned staging block per set (no host wait:
+        // the block of this set last fed a copy two prefetches ago, and that copy finished before the swap in between)
+        std::vector<int> buf;
+        build_embed_plan(x, t, m, buf, h->emb_plan[set]);
+        int* d;
+        CHK(getbuf_t(h, bset(h, "embplan", set).c_str(), buf.size(), &d));
+        if (buf.size() * sizeof(int) > h->pin_plan_bytes[set]) {
+            HIPCHK(h, hipStreamSynchronize(cs));
+            if (h->pin_plan[set]) { (void)hipHostFree(h->pin_plan[set]); h->pin_plan[set] = nullptr; h->pin_plan_bytes[set] = 0; }
+            HIPCHK(h, hipHostMalloc(&h->pin_plan[set], 2 * buf.size() * sizeof(int), hipHostMallocDefault));
+            h->pin_plan_bytes[set] = 2 * buf.size() * sizeof(int);
+        }
+        memcpy(h->pin_plan[set], buf.data(), buf.size() * sizeof(int));
+        HIPCHK(h, hipMemcpyAsync(d, h->pin_plan[set], buf.size() * sizeof(int), hipMemcpyHostToDevice, cs));
+    }
     HIPCHK(h, hipEventRecord(h->staged_ev, cs));
     h->p_t = t; h->p_m = m; h->p_T = T; h->p_K = K; h->have_pending = true;
     return STATTN_OK;
@@ -1557,7 +1628,9 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         return comm_reduce_range(h, lo, hi - lo);
     };
     comm_backward_begins(h);
-    HIPCHK(h, hipMemsetAsync(h->d_grads, 0, h->nflat * sizeof(float), s));
+    // every gradient array is written in full by its GEMM / column sum; only Wemb is written row-wise (the rows of the
+    // words of this batch), so only that region is cleared (the padding between arrays was zeroed at creation)
+    HIPCHK(h, hipMemsetAsync(G_("Wemb"), 0, h->params[h->pindex["ff_state_W"]].off * sizeof(float), s));
 
     // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
     const bool reg = alpha_c > 0.f;
@@ -1762,7 +1835,12 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CHK(region_done("ff_state_W", "decoder_W"));
     // -- region Wemb: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
     HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, 0, h->opt.prev2out ? dz : nullptr, E));
-    HIPCHK(h, launch_embed_bwd(s, dx, demb, G_("Wemb"), (int)R, E, V, m));
+    {
+        const EmbedPlan pl = device_embed_plan(h, h->cur_set);
+        float* epart;
+        CHK(getbuf_t(h, "b_embpart", (size_t)(pl.npieces > 0 ? pl.npieces : 1) * E, &epart));
+        HIPCHK(h, launch_embed_bwd(s, pl, demb, G_("Wemb"), epart, E, m));
+    }
     CHK(region_done("Wemb", "ff_state_W"));
 #undef CSADD
     h->have_bwd = true;
@@ -1810,10 +1888,10 @@ int stattn_update(stattn_handle* h, float decay_c, float clip_c) {
     float *part, *sc;
     CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
     CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
-    // g += 2 decay_c theta (:1130-1136); ||g||^2 in a fixed two-stage order; clip + Adadelta in one pass
+    // || g + 2 decay_c theta ||^2 (:1130-1136) in a fixed two-stage order; decay + clip + Adadelta in one pass
     HIPCHK(h, launch_decay_sumsq(s, h->d_grads, h->d_params, 2.f * decay_c, h->nflat, part, 1024));
     HIPCHK(h, launch_sum_all(s, part, 1024, sc, 1.f, 0));
-    HIPCHK(h, launch_adadelta(s, h->d_params, h->d_grads, h->d_rg2, h->d_ru2, h->nflat, sc, clip_c));
+    HIPCHK(h, launch_adadelta(s, h->d_params, h->d_grads, h->d_rg2, h->d_ru2, h->nflat, sc, clip_c, 2.f * decay_c));
     h->ck_proj = false; h->have_fwd = false; h->have_bwd = false;
     return STATTN_OK;
 }

@@ -545,14 +545,33 @@ __global__ void add_kernel(const float* __restrict__ a, const float* __restrict_
         st4(out + 4 * i, v);
     }
 }
-// dWemb[x[r - shift], :] += demb[r, :]  for r >= shift   (embedding lookup backward, :613-617)
-__global__ __launch_bounds__(256) void embed_bwd_kernel(const int64_t* __restrict__ x, const float* __restrict__ demb,
-                                                        float* __restrict__ dWemb, int rows, int E, int V, int shift) {
-    const int r = blockIdx.x + shift;
-    if (r >= rows) return;
-    int64_t w = x[r - shift];
-    if (w < 0 || w >= V) return;
-    for (int e = threadIdx.x; e < E; e += 256) atomicAdd(dWemb + (size_t)w * E + e, demb[(size_t)r * E + e]);
+// dWemb[x[i], :] = sum over the tokens i of one word of demb[i + shift, :]   (embedding lookup backward, :613-617)
+// without atomics, so that the gradient is run-to-run reproducible.  The token ids are host data: stattn_set_batch
+// sorts them once (stable, by word) into a plan -- perm[] (token indices grouped by word), pieces of at most 16 tokens,
+// and for every distinct word its run of pieces.  Stage 1: one workgroup per piece sums its rows in index order (straight
+// into dWemb when the word has a single piece); stage 2: one workgroup per multi-piece word adds the piece sums in
+// order (the zero-padding word has hundreds of tokens in a batch).  Rows of absent words stay zero (memset).
+__global__ __launch_bounds__(128) void embed_bwd_piece_kernel(const EmbedPlan pl, const float* __restrict__ demb, float* __restrict__ dWemb,
+                                                              float* __restrict__ part, int E, int shift) {
+    const int s = blockIdx.x;
+    const int beg = pl.piece_start[s], end = pl.piece_start[s + 1];
+    const int wi = pl.piece_word[s];                                    // index into the distinct-word list
+    const bool single = pl.word_piece_start[wi + 1] - pl.word_piece_start[wi] == 1;
+    float* __restrict__ dst = single ? dWemb + (size_t)pl.word_id[wi] * E : part + (size_t)s * E;
+    for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += 128) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = beg; j < end; ++j) add4(acc, ld4(demb + (size_t)(pl.perm[j] + shift) * E + 4 * e4));
+        st4(dst + 4 * e4, acc);
+    }
+}
+__global__ __launch_bounds__(128) void embed_bwd_word_kernel(const EmbedPlan pl, const float* __restrict__ part, float* __restrict__ dWemb, int E) {
+    const int wi = pl.multi_word[blockIdx.x];
+    const int beg = pl.word_piece_start[wi], end = pl.word_piece_start[wi + 1];
+    for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += 128) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int s = beg; s < end; ++s) add4(acc, ld4(part + (size_t)s * E + 4 * e4));
+        st4(dWemb + (size_t)pl.word_id[wi] * E + 4 * e4, acc);
+    }
 }
 // out[c, r] = in[r, c]   (weight transposes for the backward skinny GEMMs), 32x32 LDS tiles
 __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, int ldi, float* __restrict__ out, int ldo,
@@ -567,14 +586,21 @@ __global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict_
 }
 
 // ---------------------------------------------------------------------------------------------
-// optimizer: L2 decay into the gradient + sum of squares (two-stage), then clip + Adadelta (common.py:178-195)
-__global__ __launch_bounds__(256) void decay_sumsq_kernel(float* __restrict__ g, const float* __restrict__ p, float two_decay,
+// optimizer: || g + 2 decay_c theta ||^2 (two-stage, fixed order), then L2 decay + clip + Adadelta in ONE pass over the
+// buffers (common.py:178-195).  The decayed gradient is never written back: both passes form it on the fly, which
+// saves a 171 MB store and reload per update.
+__global__ __launch_bounds__(256) void decay_sumsq_kernel(const float* __restrict__ g, const float* __restrict__ p, float two_decay,
                                                           size_t n, float* __restrict__ part) {
     __shared__ float s[4];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+    const size_t n4 = n >> 2;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        const float4 a = ld4(g + 4 * i), b = ld4(p + 4 * i);
+        const float x = a.x + two_decay * b.x, y = a.y + two_decay * b.y, z = a.z + two_decay * b.z, w = a.w + two_decay * b.w;
+        acc += x * x + y * y + z * z + w * w;
+    }
+    for (size_t i = 4 * n4 + (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
         const float v = g[i] + two_decay * p[i];
-        g[i] = v;
         acc += v * v;
     }
     acc = wave_sum(acc);
@@ -583,11 +609,12 @@ __global__ __launch_bounds__(256) void decay_sumsq_kernel(float* __restrict__ g,
     if (threadIdx.x == 0) part[blockIdx.x] = s[0] + s[1] + s[2] + s[3];
 }
 __global__ __launch_bounds__(256) void adadelta_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ rg2,
-                                                       float* __restrict__ ru2, size_t n, const float* __restrict__ g2, float clip_c) {
+                                                       float* __restrict__ ru2, size_t n, const float* __restrict__ g2, float clip_c,
+                                                       float two_decay) {
     const float n2 = g2[0];
     const float scale = (clip_c > 0.f && n2 > clip_c * clip_c) ? clip_c / sqrtf(n2) : 1.f;   // :1194-1203
     for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
-        const float gi = g[i] * scale;
+        const float gi = (g[i] + two_decay * p[i]) * scale;               // :1130-1136 (L2 term), then the clip
         const float r = 0.95f * rg2[i] + 0.05f * gi * gi;                 // common.py:184
         const float ud = -sqrtf(ru2[i] + 1e-6f) / sqrtf(r + 1e-6f) * gi;  // :189
         rg2[i] = r;
@@ -719,9 +746,11 @@ hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out,
     hipLaunchKernelGGL(add_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, a, b, out, n / 4, accumulate);
     return hipGetLastError();
 }
-hipError_t launch_embed_bwd(hipStream_t s, const int64_t* x, const float* demb, float* dWemb, int rows, int E, int V, int shift) {
-    if (rows - shift <= 0) return hipSuccess;
-    hipLaunchKernelGGL(embed_bwd_kernel, dim3(rows - shift), dim3(256), 0, s, x, demb, dWemb, rows, E, V, shift);
+hipError_t launch_embed_bwd(hipStream_t s, const EmbedPlan& pl, const float* demb, float* dWemb, float* part, int E, int shift) {
+    if (pl.npieces <= 0) return hipSuccess;
+    if (E % 4 != 0) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(embed_bwd_piece_kernel, dim3(pl.npieces), dim3(128), 0, s, pl, demb, dWemb, part, E, shift);
+    if (pl.nmulti > 0) hipLaunchKernelGGL(embed_bwd_word_kernel, dim3(pl.nmulti), dim3(128), 0, s, pl, part, dWemb, E);
     return hipGetLastError();
 }
 hipError_t launch_transpose(hipStream_t s, const float* in, int ldi, float* out, int ldo, int rows, int cols) {
@@ -735,12 +764,13 @@ hipError_t launch_state0_bwd(hipStream_t s, const float* dh_pass, const float* d
                        dselpre, W_sel, dc, h0, c0, dph0, dpc0, M, D);
     return hipGetLastError();
 }
-hipError_t launch_decay_sumsq(hipStream_t s, float* g, const float* p, float two_decay, size_t n, float* part, int nblocks) {
+hipError_t launch_decay_sumsq(hipStream_t s, const float* g, const float* p, float two_decay, size_t n, float* part, int nblocks) {
     hipLaunchKernelGGL(decay_sumsq_kernel, dim3(nblocks), dim3(256), 0, s, g, p, two_decay, n, part);
     return hipGetLastError();
 }
-hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c) {
-    hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, rg2, ru2, n, g2, clip_c);
+hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c,
+                           float two_decay) {
+    hipLaunchKernelGGL(adadelta_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, p, g, rg2, ru2, n, g2, clip_c, two_decay);
     return hipGetLastError();
 }
 

@@ -10,6 +10,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <algorithm>
 #include <cstring>
 #include <map>
 #include <string>
@@ -93,6 +94,9 @@ struct stattn_handle {
     bool free_valid[2] = {false, false};
     bool have_pending = false;
     int p_t = 0, p_m = 0, p_T = 0, p_K = 0;
+    // deterministic embedding gradient: per batch set, the plan built from the token ids (kernels.h EmbedPlan)
+    struct EmbPlanHost { int npieces = 0, nwords = 0, nmulti = 0, ntok = 0; } emb_plan[2];
+    void* pin_plan[2] = {nullptr, nullptr}; size_t pin_plan_bytes[2] = {0, 0};   // pinned staging of the plan (stattn_prefetch_batch)
 
     // sampler: the resident video (stattn_set_video, or the last f_next call that passed host features).
     // ck_valid: raw features are in HBM; ck_proj: their projections match the current parameters

@@ -317,13 +317,28 @@ hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part); 
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
 hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);
-hipError_t launch_embed_bwd(hipStream_t s, const int64_t* x, const float* demb, float* dWemb, int rows, int E, int V, int shift);
+// Plan of the deterministic embedding gradient, built on the host from the token ids when a batch is staged
+// (api.cpp build_embed_plan): device pointers into one int buffer.
+struct EmbedPlan {
+    const int* perm;               // [ntok] token indices, grouped by word (ascending inside a word)
+    const int* piece_start;        // [npieces + 1] into perm: at most 16 tokens of one word per piece
+    const int* piece_word;         // [npieces] index of the piece's word in the distinct-word list
+    const int* word_piece_start;   // [nwords + 1] into the piece list
+    const int* word_id;            // [nwords] vocabulary index
+    const int* multi_word;         // [nmulti] distinct-word indices that have more than one piece
+    int npieces, nwords, nmulti;
+};
+// dWemb must be zero on entry (rows of absent words are not written); part: npieces * E floats
+hipError_t launch_embed_bwd(hipStream_t s, const EmbedPlan& pl, const float* demb, float* dWemb, float* part, int E, int shift);
 hipError_t launch_transpose(hipStream_t s, const float* in, int ldi, float* out, int ldo, int rows, int cols);
 hipError_t launch_state0_bwd(hipStream_t s, const float* dh_pass, const float* dhU, int nU, const float* dhW, int nW,
                              const float* dselpre, const float* W_sel, const float* dc, const float* h0, const float* c0,
                              float* dph0, float* dpc0, int M, int D);
-hipError_t launch_decay_sumsq(hipStream_t s, float* g, const float* p, float two_decay, size_t n, float* part, int nblocks);
-hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c);
+// part[block] = partial sums of (g + two_decay p)^2; nothing is written back
+hipError_t launch_decay_sumsq(hipStream_t s, const float* g, const float* p, float two_decay, size_t n, float* part, int nblocks);
+// gradient = (g + two_decay p) clipped by the global norm sqrt(g2[0])
+hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, float* ru2, size_t n, const float* g2, float clip_c,
+                           float two_decay);
 
 // ----------------------------------------------------------------------------
 // batched device-side beam search (beam.hip)

@@ -5,7 +5,7 @@
 // Structure.  Inside the reverse time loop only what the recurrence needs is computed:
 //   lstm_bwd  -> dpre (gate pre-activation grads), carried dc, pass-through dh
 //   [skinny GEMM: dctx = dpre.Wc^T, dhU = dpre.U^T]
-//   temporal_bwd -> dcsum, selector grad, the three temporal softmax backwards, dsg/dsm
+//   temporal_bwd -> dcsum, selector grad, d alpha of the three temporal attentions
 //   spatial_bwd  -> dplt, spatial softmax backward (del), per-frame dsl
 //   reduce_T     -> dsl, dslt summed over frames
 //   [skinny GEMM: dhW = dsproj.[Wdl|Wdg|Wdm|Wdlt]^T]
@@ -134,45 +134,37 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 
-// temporal backward, part 0 (one workgroup per row): dctx = sum of the GEMM K-slice partials + readout term,
-// selector backward (ctx = sel * csum, :433-435), dcsum
-__global__ __launch_bounds__(256) void tbwd0_kernel(const TemporalBwdArgs a) {
-    __shared__ float s_red[4];
-    const int D = a.D, b = blockIdx.x, tid = threadIdx.x;
+// temporal backward, one workgroup per (row b, frame t):
+//   dctx = sum of the GEMM K-slice partials + readout term; selector backward (ctx = sel * csum, :433-435) -> dcsum, dselpre
+//   d alpha = <dcsum, X_t> + regulariser for the three temporal attentions (cg = sum_t ag_t G_t :399, cm :412,
+//   clt = sum_t alt_t CL_t :426)
+// Every frame's workgroup re-forms dcsum of its row from the partials (three 4 KB vectors from L2: cheaper than a
+// separate per-row launch in front, which was 4.8 us + a kernel boundary per step); frame 0 stores it.
+__global__ __launch_bounds__(256) void tbwd_kernel(const TemporalBwdArgs a) {
+    __shared__ float s_red[4 * 4];
+    const int T = a.T, D = a.D, bt = blockIdx.x, b = bt / T, t = bt - b * T, tid = threadIdx.x;
     const int nd4 = D >> 2;
     const size_t MD = (size_t)a.M * D;
     const float sel = a.has_sel ? a.sel[b] : 1.f;
-    float ps[1] = {0.f};
+    float p[4] = {0.f, 0.f, 0.f, 0.f};
     for (int d4 = tid; d4 < nd4; d4 += 256) {
-        const size_t o = (size_t)b * D + 4 * d4;
-        float4 dc = a.dctx_r ? ld4(a.dctx_r + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int p = 0; p < a.nP; ++p) add4(dc, ld4(a.dctxP + (size_t)p * MD + o));
-        ps[0] += dot4(dc, ld4(a.csum + o));
-        st4(a.dcsum + o, scale4(dc, sel));
+        const size_t ob = (size_t)b * D + 4 * d4, o = (size_t)bt * D + 4 * d4;
+        const float4 g4 = ld4(a.G + o), m4 = ld4(a.Mo + o), c4 = ld4(a.CL + o);
+        float4 dc = a.dctx_r ? ld4(a.dctx_r + ob) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < a.nP; ++q) add4(dc, ld4(a.dctxP + (size_t)q * MD + ob));
+        p[3] += dot4(dc, ld4(a.csum + ob));
+        const float4 dcs = scale4(dc, sel);
+        if (t == 0) st4(a.dcsum + ob, dcs);
+        p[0] += dot4(dcs, g4);
+        p[1] += dot4(dcs, m4);
+        p[2] += dot4(dcs, c4);
     }
-    block_sum<1>(ps, s_red, tid, 4);
-    if (tid == 0) a.dselpre[b] = a.has_sel ? ps[0] * sel * (1.f - sel) : 0.f;
-}
-
-// part 1 (one workgroup per (row, frame)): d alpha = <dcsum, X_t> + regulariser for the three temporal
-// attentions (cg = sum_t ag_t G_t :399, cm :412, clt = sum_t alt_t CL_t :426)
-__global__ __launch_bounds__(256) void tbwd1_kernel(const TemporalBwdArgs a) {
-    __shared__ float s_red[4 * 3];
-    const int T = a.T, D = a.D, bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
-    const int nd4 = D >> 2;
-    float p[3] = {0.f, 0.f, 0.f};
-    for (int d4 = tid; d4 < nd4; d4 += 256) {
-        const float4 dc = ld4(a.dcsum + (size_t)b * D + 4 * d4);
-        const size_t o = (size_t)bt * D + 4 * d4;
-        p[0] += dot4(dc, ld4(a.G + o));
-        p[1] += dot4(dc, ld4(a.Mo + o));
-        p[2] += dot4(dc, ld4(a.CL + o));
-    }
-    block_sum<3>(p, s_red, tid, 4);
+    block_sum<4>(p, s_red, tid, 4);
     if (tid < 3) {
         const float* r = tid == 0 ? a.rg : (tid == 1 ? a.rm : a.rlt);
         a.da_raw[(size_t)tid * a.M * T + bt] = p[tid] + (r ? r[bt] : 0.f);
     }
+    if (tid == 3 && t == 0) a.dselpre[b] = a.has_sel ? p[3] * sel * (1.f - sel) : 0.f;
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -669,8 +661,7 @@ hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
     return hipGetLastError();
 }
 hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {
-    hipLaunchKernelGGL(tbwd0_kernel, dim3(a.M), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(tbwd1_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(tbwd_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {

@@ -267,9 +267,12 @@ int init_state(stattn_handle* h, int nv, int T, const float* G, const float* mas
 struct FwdPanels { float *Wd, *U, *Wc, *W, *Wl1, *Wl2, *Wo; };
 struct BwdPanels { float *WcT, *UT, *WdT; };
 
-bool use_panels(const stattn_handle* h, int M) {
+// min_rows: the training scan repacks the panels every pass and uses them from 17 rows up; beam search packs once per
+// call and uses them for any batch (at 4 rows the 16-column panels still give 128+ workgroups where the 64-column
+// kernels give 32)
+bool use_panels(const stattn_handle* h, int M, int min_rows = 17) {
     static const char* off = getenv("STATTN_NO_PANELS");       // A/B switch for tools
-    return !off && M > 16 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
+    return !off && M >= min_rows && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
 }
 
 int pack(stattn_handle* h, const float* W, int ldw, int src_t, int K, int ntiles, int cols, float* dst, int S_total = 0, int s_off = 0) {
@@ -1022,10 +1025,10 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     HIPCHK(h, hipMemcpy2DAsync(cp, (size_t)k * D * 4, c0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)M * 3 * D));
 
-    // one decoded word = a fixed sequence of 15 kernel launches whose arguments depend on the word index only through
+    // one decoded word = a fixed sequence of 12 kernel launches whose arguments depend on the word index only through
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
     FwdPanels pn{};
-    const bool panels = use_panels(h, M) && Vp % 16 == 0;
+    const bool panels = use_panels(h, M, 1) && Vp % 16 == 0;
     float *hp_pk = nullptr, *ctx_pk = nullptr, *emb_pk = nullptr, *hd_pk = nullptr, *a1_pk = nullptr;
     if (panels) {
         CHK(pack_fwd_panels(h, &pn, true));
@@ -1037,8 +1040,13 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         for (float* q : {emb_pk, a1_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, E) * sizeof(float), s));
         HIPCHK(h, launch_pack_rows(s, hp, D, M, D, hp_pk));          // initial states; later words: beam_update's gather
     }
+    // first word: no previous word, zero embedding (:803-804); afterwards beam_update writes the embedding of the
+    // word it selects (no lookup launch inside the loop)
+    HIPCHK(h, hipMemsetAsync(emb, 0, (size_t)M * E * sizeof(float), s));
+    int* d_ticket;
+    CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
+    HIPCHK(h, hipMemsetAsync(d_ticket, 0, sizeof(int), s));
     auto enqueue_word = [&](int parity) -> int {
-        HIPCHK(h, launch_embed(s, next_w, w.Wemb, emb, M, E, V, 0, emb_pk));
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
         io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
@@ -1098,6 +1106,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
+        ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
         HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         HIPCHK(h, launch_beam_update(s, ba));
         return STATTN_OK;
@@ -1124,7 +1133,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                           (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
                           (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
                           (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows, (const void*)hp_pk,
-                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk})
+                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket})
         sig.push_back((uintptr_t)q);
     if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
         gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is

@@ -172,6 +172,16 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
             for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
             if (a.h_next_pk)
                 for (int d = tid; d < D; d += 256) a.h_next_pk[pn_pack_offset(v * k + slot, d, D >> 4)] = hs[d];
+            // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here,
+            // so the word loop needs no separate lookup launch
+            if (a.emb_next) {
+                const float* __restrict__ we = a.Wemb + (size_t)s_wi[r] * a.E;
+                for (int e = tid; e < a.E; e += 256) {
+                    const float x = we[e];
+                    a.emb_next[(size_t)(v * k + slot) * a.E + e] = x;
+                    if (a.emb_next_pk) a.emb_next_pk[pn_pack_offset(v * k + slot, e, a.E >> 4)] = x;
+                }
+            }
         }
     }
     // the video's loop ends with this word (:974-977): gen_sample returns f_next's state outputs of this very call,
@@ -179,6 +189,13 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
     if (s_ended && a.end_h) {
         const size_t base = (size_t)v * k * D;
         for (int i = tid; i < s_rows * D; i += 256) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
+    }
+    // Advance the word counter.  Every workgroup read *a.step when it started; the LAST one to get here (a ticket)
+    // knows all of them did, so it may write step + 1 for the next word's kernels (was a one-thread launch of its own).
+    __syncthreads();
+    if (tid == 0) {
+        __threadfence();
+        if (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) { *a.ticket = 0; *a.step = step + 1; }
     }
 }
 
@@ -197,12 +214,9 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
     hipLaunchKernelGGL(beam_topk_merge_kernel, dim3(a.nvid), dim3(256), 0, s, a, ns, part_cost, part_idx);
     return hipGetLastError();
 }
-__global__ void beam_step_inc_kernel(int* step) { *step += 1; }
-
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a) {
+    if (!a.ticket) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a);
-    // every workgroup of the update reads *step at its start: the increment is its own (stream-ordered) launch
-    hipLaunchKernelGGL(beam_step_inc_kernel, dim3(1), dim3(1), 0, s, a.step);
     return hipGetLastError();
 }
 

@@ -356,11 +356,14 @@ struct BeamArgs {
     const float* h_step; const float* c_step;       // [nvid*k, D] state after this step
     float* h_next; float* c_next;       // [nvid*k, D] state gathered for the next step
     float* h_next_pk;                   // optional: h_next in the packed A layout of the row-panel kernels
+    const float* Wemb; int E;           // embedding table: the update writes the next step's input embedding ...
+    float* emb_next; float* emb_next_pk;   // ... [nvid*k, E] (and optionally its packed copy); null = not written
+    int* ticket;                        // device int, zero: last workgroup of the update advances *step
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
 };
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch
 hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx);
-hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);   // also advances *a.step (a trailing one-thread kernel)
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);   // also advances *a.step (last workgroup, ticket)
 
 }  // namespace stattn

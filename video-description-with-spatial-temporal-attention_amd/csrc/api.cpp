@@ -973,15 +973,12 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     CHK(project_context(h, nvid, T, K, c.G, rawl, rawm, c));       // once per video, not once per word
     CHK(init_state(h, nvid, T, c.G, mG, mean, h0, c0));            // f_init (:880)
 
-    int *vid, *live_k, *dead_k, *nsel, *sel_ti, *sel_wi, *tok[2], *fin_tok, *fin_len;
+    int *vid, *live_k, *dead_k, *tok[2], *fin_tok, *fin_len;
     int64_t* next_w;
     float *hp, *cp, *ho, *co, *hd, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *a1, *lg, *pr,
-          *score[2], *sel_cost, *fin_score;
+          *score[2], *fin_score;
     CHK(getbuf_t(h, "bs_vid", (size_t)M, &vid));
     CHK(getbuf_t(h, "bs_live", (size_t)nvid, &live_k)); CHK(getbuf_t(h, "bs_dead", (size_t)nvid, &dead_k));
-    CHK(getbuf_t(h, "bs_nsel", (size_t)nvid, &nsel));
-    CHK(getbuf_t(h, "bs_sel_ti", (size_t)M, &sel_ti)); CHK(getbuf_t(h, "bs_sel_wi", (size_t)M, &sel_wi));
-    CHK(getbuf_t(h, "bs_sel_cost", (size_t)M, &sel_cost));
     CHK(getbuf_t(h, "bs_tok0", (size_t)M * L0, &tok[0])); CHK(getbuf_t(h, "bs_tok1", (size_t)M * L0, &tok[1]));
     CHK(getbuf_t(h, "bs_fin_tok", (size_t)M * L0, &fin_tok)); CHK(getbuf_t(h, "bs_fin_len", (size_t)M, &fin_len));
     CHK(getbuf_t(h, "bs_fin_score", (size_t)M, &fin_score));
@@ -1025,7 +1022,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     HIPCHK(h, hipMemcpy2DAsync(cp, (size_t)k * D * 4, c0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
     HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)M * 3 * D));
 
-    // one decoded word = a fixed sequence of 12 kernel launches whose arguments depend on the word index only through
+    // one decoded word = a fixed sequence of 10 kernel launches whose arguments depend on the word index only through
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
     FwdPanels pn{};
     const bool panels = use_panels(h, M, 1) && Vp % 16 == 0;
@@ -1101,14 +1098,13 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = d_step;
         ba.suppress_eos = suppress_eos;
         ba.live_k = live_k; ba.dead_k = dead_k; ba.hyp_score = score[parity]; ba.hyp_score_out = score[parity ^ 1];
-        ba.nsel = nsel; ba.sel_ti = sel_ti; ba.sel_wi = sel_wi; ba.sel_cost = sel_cost;
         ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
         HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
-        HIPCHK(h, launch_beam_update(s, ba));
+        HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
     HIPCHK(h, hipMemsetAsync(d_step, 0, sizeof(int), s));
@@ -1123,8 +1119,8 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos,
                                   (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
     for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
-                          (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k, (const void*)nsel,
-                          (const void*)sel_ti, (const void*)sel_wi, (const void*)sel_cost, (const void*)tok[0], (const void*)tok[1],
+                          (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,
+                          (const void*)tok[0], (const void*)tok[1],
                           (const void*)fin_tok, (const void*)fin_len, (const void*)fin_score, (const void*)score[0],
                           (const void*)score[1], (const void*)next_w, (const void*)hp, (const void*)cp, (const void*)ho,
                           (const void*)co, (const void*)hd, (const void*)emb, (const void*)sproj, (const void*)preh, (const void*)dp,

@@ -5,8 +5,8 @@
 // list surgery (model_attention.py:921-985) -- ~0.5 ms of numpy per word at k = 5, V = 12k, more than
 // the whole decoder step on the GPU.  Here the same bookkeeping runs on the device for many videos at
 // once (one workgroup per video), so a decode step is a fixed kernel sequence with no host round trip:
-//   beam_topk_part/merge the (k - dead_k) smallest candidate costs of a video: per vocabulary slice, then merged (:921-928)
-//   beam_update_kernel  new hypotheses, finished ones (word 0) retired, h/c gathered    (:939-985)
+//   beam_topk_part      the (k - dead_k) smallest candidate costs of a video per vocabulary slice (:921-928)
+//   beam_update_kernel  slice winners merged; new hypotheses, finished ones (word 0) retired, h/c gathered    (:923-985)
 #include "kernels.h"
 #include "devmath.h"
 
@@ -98,52 +98,43 @@ __global__ __launch_bounds__(256) void beam_topk_part_kernel(const BeamArgs a, i
     if (tid < KB) { oc[tid] = res_c[tid]; oi[tid] = res_i[tid]; }
 }
 
-// Stage 2: one workgroup per video merges the nsplit * KB slice winners (<= 256) and writes the selection
-__global__ __launch_bounds__(256) void beam_topk_merge_kernel(const BeamArgs a, int nsplit, const float* __restrict__ pcost,
-                                                              const int* __restrict__ pidx) {
+// Stage 2 + bookkeeping, one workgroup per video: merge the nsplit * KB slice winners (<= 256) into the selection
+// (:923-928), then build the new hypotheses, retire the finished ones and gather the states (:939-985).
+__global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int nsplit, const float* __restrict__ pcost,
+                                                          const int* __restrict__ pidx) {
+    __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
+    __shared__ int s_n, s_ended, s_rows;
     __shared__ float s_cost[4];
     __shared__ int s_idx[4];
     __shared__ int s_owner[4];
     __shared__ float res_c[KB];
     __shared__ int res_i[KB];
     const int v = blockIdx.x, tid = threadIdx.x;
-    const int k = a.k, V = a.V;
-    const int live = a.live_k[v], dead = a.dead_k[v];
-    const int n = live > 0 ? k - dead : 0;
-    if (tid == 0) a.nsel[v] = n;
-    if (n <= 0) return;
-    float lc[KB]; int li[KB];
+    const int k = a.k, D = a.D, L = a.maxlen, V = a.V, step = *a.step;
+    const int nsel = a.live_k[v] > 0 ? k - a.dead_k[v] : 0;    // how many candidates survive (:923)
+    if (nsel > 0) {                                            // (uniform over the workgroup)
+        float lc[KB]; int li[KB];
 #pragma unroll
-    for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
-    if (tid < nsplit * KB) { lc[0] = pcost[(size_t)v * nsplit * KB + tid]; li[0] = pidx[(size_t)v * nsplit * KB + tid]; }
-    block_select(lc, li, n, s_cost, s_idx, s_owner, res_c, res_i);
-    if (tid < n) {
-        const int idx = res_i[tid];
-        a.sel_cost[v * k + tid] = res_c[tid];
-        a.sel_ti[v * k + tid] = idx / V;                      // trans_indices = ranks_flat // voc_size (:926)
-        a.sel_wi[v * k + tid] = idx % V;                      // word_indices  = ranks_flat %  voc_size (:927)
+        for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+        if (tid < nsplit * KB) { lc[0] = pcost[(size_t)v * nsplit * KB + tid]; li[0] = pidx[(size_t)v * nsplit * KB + tid]; }
+        block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
     }
-}
-
-__global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a) {
-    __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
-    __shared__ int s_n, s_ended, s_rows;
-    const int v = blockIdx.x, tid = threadIdx.x;
-    const int k = a.k, D = a.D, L = a.maxlen, step = *a.step;
+    __syncthreads();
     if (tid == 0) {
-        const int n = a.nsel[v];
+        const int n = nsel;
         int dead = a.dead_k[v], nl = 0;
         for (int r = 0; r < n; ++r) {
-            const int ti = a.sel_ti[v * k + r], wi = a.sel_wi[v * k + r];
+            const int ti = res_i[r] / V, wi = res_i[r] % V;    // trans_indices = ranks_flat // voc_size, word_indices = % (:926-927)
+            const float cost = res_c[r];
             s_ti[r] = ti; s_wi[r] = wi;
             if (wi == 0) {                                     // <eos>: the hypothesis dies (:958-962)
                 s_fin[r] = 1; s_slot[r] = dead;
-                a.fin_score[v * k + dead] = a.sel_cost[v * k + r];
+                a.fin_score[v * k + dead] = cost;
                 a.fin_len[v * k + dead] = step + 1;
                 ++dead;
             } else {                                           // stays live (:963-970)
                 s_fin[r] = 0; s_slot[r] = nl;
-                a.hyp_score_out[v * k + nl] = a.sel_cost[v * k + r];
+                a.hyp_score_out[v * k + nl] = cost;
                 a.next_w[v * k + nl] = wi;
                 ++nl;
             }
@@ -211,12 +202,11 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
     if (a.k > KB || a.k < 1) return hipErrorInvalidValue;
     const int ns = beam_topk_splits(a.nvid);
     hipLaunchKernelGGL(beam_topk_part_kernel, dim3(a.nvid, ns), dim3(256), 0, s, a, ns, part_cost, part_idx);
-    hipLaunchKernelGGL(beam_topk_merge_kernel, dim3(a.nvid), dim3(256), 0, s, a, ns, part_cost, part_idx);
     return hipGetLastError();
 }
-hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a) {
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx) {
     if (!a.ticket) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
     return hipGetLastError();
 }
 

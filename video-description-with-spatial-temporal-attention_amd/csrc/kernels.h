@@ -349,7 +349,6 @@ struct BeamArgs {
     int* step;                          // device counter: index of the word being decoded (so a captured graph replays unchanged)
     int* live_k; int* dead_k;           // [nvid]
     const float* hyp_score; float* hyp_score_out;   // [nvid*k] scores of the live hypotheses (in / out)
-    int* nsel; int* sel_ti; int* sel_wi; float* sel_cost;   // [nvid], [nvid*k] x3
     const int* tok_in; int* tok_out;    // [nvid*k, maxlen] words of the live hypotheses (in / out)
     int* fin_tok; float* fin_score; int* fin_len;   // finished hypotheses, in order of death
     int64_t* next_w;                    // [nvid*k] word fed to the next step
@@ -364,6 +363,6 @@ struct BeamArgs {
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch
 hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx);
-hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a);   // also advances *a.step (last workgroup, ticket)
+hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx);   // also advances *a.step (last workgroup, ticket)
 
 }  // namespace stattn

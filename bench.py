@@ -304,8 +304,8 @@ def spawn_ranks(n):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam"])
     ap.add_argument("--beam", type=int, default=None, help="beam width k of gen_sample (decode mode default 1 = greedy, beam mode default 5)")
@@ -429,15 +429,22 @@ def main():
     # (1) dominant kernel class by time share: the LDS-tiled MFMA GEMM.  `roofline` = all plain (NN) launches of one
     #     forward pass (flops per launch / average launch duration); `kernels` below has every launch on its own.
     BTK, BT, R = B * T * K, B * T, B * t
-    nn = [("ff_local", BTK, D, F), ("ff_motion", BT, D, F), ("pctxg", BT, D, D), ("pctxl", BTK, D, D), ("pctxm", BT, D, D)]
-    if dec.lt_mode == 1:
-        nn.append(("L.Wclt", BTK, D, D))
-    nn += [("xproj", R, 4 * D, E), ("readout_h", R, E, D)] + ([("readout_ctx", R, E, D)] if options["ctx2out"] else []) + [("logits", R, Vp, E)]
-    nn_flops = sum(2.0 * m_ * n_ * k_ for _, m_, n_, k_ in nn) + (2.0 * BT * D * D * t if dec.lt_mode == 0 else 0.0)
+    # plain GEMM launches of one forward pass in launch order; the fp32 path groups independent problems into one launch
+    # (csrc/gemm.hip launch_gemm_group): a launch = a list of (name, M, N, K)
+    proj1 = [("ff_local", BTK, D, F), ("ff_motion", BT, D, F), ("pctxg", BT, D, D)]
+    proj2 = [("pctxl", BTK, D, D)] + ([("L.Wclt", BTK, D, D)] if dec.lt_mode == 1 else []) + [("pctxm", BT, D, D)]
+    tail = [[("readout_h", R, E, D)]] + ([[("readout_ctx", R, E, D)]] if options["ctx2out"] else []) + [[("logits", R, Vp, E)]]
+    if bf16:
+        launches = [[x_] for x_ in proj1 + [proj2[0]] + [proj2[-1]] + proj2[1:-1]] + [[("xproj", R, 4 * D, E)]] + tail
+    elif os.environ.get("STATTN_GEMM_NOGROUP"):
+        launches = [[x_] for x_ in proj1 + [("xproj", R, 4 * D, E)] + proj2] + tail
+    else:
+        launches = [proj1 + [("xproj", R, 4 * D, E)], proj2] + tail
+    nn_flops = sum(2.0 * m_ * n_ * k_ for l_ in launches for _, m_, n_, k_ in l_) + (2.0 * BT * D * D * t if dec.lt_mode == 0 else 0.0)
     g_ms, g_n = kms["gemm_nn"]
     per_fwd = g_n / 3.0
     gname = "gemm_bf16_kernel<TM,TN>" if bf16 else "gemm2_kernel<TM,TN,false,false,EDGE>"
-    roofline = dict(kernel="%s (all %d plain launches of one forward pass)" % (gname, round(per_fwd)),
+    roofline = dict(kernel="%s%s (all %d plain launches of one forward pass)" % (gname, "" if bf16 else " / gemm2_group_kernel", round(per_fwd)),
                     bound="mfma", achieved=(nn_flops / per_fwd) / (g_ms * 1e-3) / 1e12 if g_ms else None,
                     peak=mfma_peak, unit="TFLOP/s", frac=None, traffic=traffic.get("gemm_nn"),
                     flops_per_launch=nn_flops / max(per_fwd, 1), ms_per_launch=g_ms)
@@ -472,8 +479,10 @@ def main():
         state_proj=mfma("h.[Wdl|Wdg|Wdm|Wdlt|U] (panel_kernel / skinny)", 2.0 * B * D * 8 * D, kms["hproj"][0], 8.0 * D * D * 4),
         lstm=mfma("ctx.Wc + gates (lstm_panel_kernel / lstm_kernel)", 2.0 * B * D * 4 * D, kms["lstm"][0], 4.0 * D * D * 4),
         temporal=hbm("temporal_kernel", B * T * D * 4.0 * 3, kms["temporal"][0], "temporal"))
-    for (nm, m_, n_, k_), ms in zip(nn, gms):
-        kernels["gemm_" + nm] = mfma("%s %dx%dx%d" % (gname, m_, n_, k_), 2.0 * m_ * n_ * k_, ms)
+    for l_, ms in zip(launches, gms):
+        kernels["gemm_" + "+".join(x_[0] for x_ in l_)] = mfma(
+            "%s %s" % (gname if len(l_) == 1 else "gemm2_group_kernel<1,1,false,false,EDGE>", " + ".join("%dx%dx%d" % x_[1:] for x_ in l_)),
+            sum(2.0 * m_ * n_ * k_ for _, m_, n_, k_ in l_), ms)
     step_ms = sum(kms[k_][0] for k_ in ("hproj", "spatial", "lt_gemm", "temporal", "lstm"))
     if args.kernel_breakdown and rank == 0:
         print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)

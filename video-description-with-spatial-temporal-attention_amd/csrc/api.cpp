@@ -125,6 +125,20 @@ hipError_t gemm_nn(stattn_handle* h, const GemmArgs& g) {
     return launch_gemm(h->stream, g, false, false);
 }
 
+// several independent plain GEMMs in one launch (gemm.hip launch_gemm_group); timed like one launch of the class
+int gemm_group(stattn_handle* h, const GemmArgs* gs, int n) {
+    static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");     // A/B switch for tools: one launch per problem
+    if (nogroup) {
+        for (int i = 0; i < n; ++i) HIPCHK(h, gemm_nn(h, gs[i]));
+        return STATTN_OK;
+    }
+    Prof pr(h, KC_GEMM_NN);
+    const int seq = h->gemm_seq++;
+    Prof one(h, KC_COUNT + (seq < KC_GEMM_SEQ ? seq : 0), seq < KC_GEMM_SEQ);
+    HIPCHK(h, launch_gemm_group(h->stream, gs, n));
+    return STATTN_OK;
+}
+
 // ---- shared building blocks ---------------------------------------------------------
 // Project raw features of `nv` videos to the decoder's context tensors (the part f_next
 // recomputes on every call in the reference, model_attention.py:782-785 + 322-326).
@@ -208,38 +222,53 @@ int project_context_bf16(stattn_handle* h, int nv, int T, int K, const float* ct
     return STATTN_OK;
 }
 
+// `extra`: one more independent plain GEMM that rides in the first launch (training: the x projection), or null.
 int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
-                    const CtxPtrs& c) {
+                    const CtxPtrs& c, const GemmArgs* extra = nullptr) {
     if (h->opt.precision == 1) return project_context_bf16(h, nv, T, K, ctxg, ctxl, ctxm, c);
     const int D = h->D;
     const Weights& w = h->w;
     Prof pr(h, KC_PROLOGUE);
-    GemmArgs g;
-    // L = tanh(ctxl . ff_local_W + b)  (:664-665 / :782-783)
-    gemm_defaults(g);
-    g.A = ctxl; g.lda = h->Fl; g.B = w.ff_local_W; g.ldb = D; g.C = c.L; g.ldc = D;
-    g.M = nv * T * K; g.N = D; g.K = h->Fl; g.bias = w.ff_local_b; g.act = 1;
-    HIPCHK(h, gemm_nn(h, g));
-    // M = tanh(ctxm . ff_motion_W + b) (:666-667 / :784-785)
-    gemm_defaults(g);
-    g.A = ctxm; g.lda = h->Fm; g.B = w.ff_motion_W; g.ldb = D; g.C = c.Mo; g.ldc = D;
-    g.M = nv * T; g.N = D; g.K = h->Fm; g.bias = w.ff_motion_b; g.act = 1;
-    HIPCHK(h, gemm_nn(h, g));
-    // pctxg_, pctxl_, pctxm_ (:322-326)
-    gemm_defaults(g);
-    g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
-    HIPCHK(h, gemm_nn(h, g));
-    gemm_defaults(g);
-    g.A = c.L; g.lda = D; g.B = w.Wcl; g.ldb = D; g.C = c.PL; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D; g.bias = w.bl;
-    HIPCHK(h, gemm_nn(h, g));
-    gemm_defaults(g);
-    g.A = c.Mo; g.lda = D; g.B = w.Wcm; g.ldb = D; g.C = c.PM; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bm;
-    HIPCHK(h, gemm_nn(h, g));
+    // Two grouped launches instead of six (seven) separate ones: the frame-level projections are 416-tile problems
+    // that under-fill the chip on their own (77-90 TFLOP/s); as tail fillers of the region-level GEMMs they are
+    // nearly free.  Launch 1: everything that reads raw inputs; launch 2: what reads L / M.
+    GemmArgs g1[GEMM_GROUP_MAX], g2[GEMM_GROUP_MAX];
+    int n1 = 0, n2 = 0;
+    {   // L = tanh(ctxl . ff_local_W + b)  (:664-665 / :782-783)
+        GemmArgs& g = g1[n1++];
+        gemm_defaults(g);
+        g.A = ctxl; g.lda = h->Fl; g.B = w.ff_local_W; g.ldb = D; g.C = c.L; g.ldc = D;
+        g.M = nv * T * K; g.N = D; g.K = h->Fl; g.bias = w.ff_local_b; g.act = 1;
+    }
+    {   // M = tanh(ctxm . ff_motion_W + b) (:666-667 / :784-785)
+        GemmArgs& g = g1[n1++];
+        gemm_defaults(g);
+        g.A = ctxm; g.lda = h->Fm; g.B = w.ff_motion_W; g.ldb = D; g.C = c.Mo; g.ldc = D;
+        g.M = nv * T; g.N = D; g.K = h->Fm; g.bias = w.ff_motion_b; g.act = 1;
+    }
+    {   // pctxg_ (:322)
+        GemmArgs& g = g1[n1++];
+        gemm_defaults(g);
+        g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
+    }
+    if (extra) g1[n1++] = *extra;
+    CHK(gemm_group(h, g1, n1));
+    {   // pctxl_ (:324)
+        GemmArgs& g = g2[n2++];
+        gemm_defaults(g);
+        g.A = c.L; g.lda = D; g.B = w.Wcl; g.ldb = D; g.C = c.PL; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D; g.bias = w.bl;
+    }
     if (h->opt.lt_mode == 1) {   // LW = L . Wclt  (the :416 projection hoisted out of the time loop)
+        GemmArgs& g = g2[n2++];
         gemm_defaults(g);
         g.A = c.L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = c.LW; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D;
-        HIPCHK(h, gemm_nn(h, g));
     }
+    {   // pctxm_ (:326)
+        GemmArgs& g = g2[n2++];
+        gemm_defaults(g);
+        g.A = c.Mo; g.lda = D; g.B = w.Wcm; g.ldb = D; g.C = c.PM; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bm;
+    }
+    CHK(gemm_group(h, g2, n2));
     return STATTN_OK;
 }
 
@@ -1401,25 +1430,29 @@ int stattn_forward_train(stattn_handle* h) {
     h->gemm_seq = 0;
     BfWeights bw{};
     uint16_t* bemb = nullptr;
-    CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
+    {
+        Prof pp(h, KC_PROLOGUE);
+        HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, (int)R, E, V, m));      // emb shifted one step (:613-617)
+    }
+    if (h->opt.precision == 1) {
+        CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
+        Prof pp(h, KC_PROLOGUE);
+        CHK(bf16_weights(h, &bw, true));
+        CHK(getbuf_t(h, "bx_emb", R * E, &bemb));
+        HIPCHK(h, launch_cvt_bf16(s, emb, bemb, R * E));
+        GemmBfArgs g = bf_args(bemb, E, bw.W, (int)R, 4 * D, E);       // x_ = emb.W + b (:334-335)
+        g.bias = w.b; g.C = xproj; g.ldc = 4 * D;
+        HIPCHK(h, gemm_bf(h, g));
+    } else {
+        GemmArgs g;
+        gemm_defaults(g);                                               // x_ = emb.W + b (:334-335): rides with the projections
+        g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
+        g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
+        CHK(project_context(h, m, T, K, c.G, rawl, rawm, c, &g));
+    }
     {
         Prof pp(h, KC_PROLOGUE);
         CHK(init_state(h, m, T, c.G, mG, mean, hs, cs));
-        HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, (int)R, E, V, m));      // emb shifted one step (:613-617)
-        if (h->opt.precision == 1) {
-            CHK(bf16_weights(h, &bw, true));
-            CHK(getbuf_t(h, "bx_emb", R * E, &bemb));
-            HIPCHK(h, launch_cvt_bf16(s, emb, bemb, R * E));
-            GemmBfArgs g = bf_args(bemb, E, bw.W, (int)R, 4 * D, E);       // x_ = emb.W + b (:334-335)
-            g.bias = w.b; g.C = xproj; g.ldc = 4 * D;
-            HIPCHK(h, gemm_bf(h, g));
-        } else {
-            GemmArgs g;
-            gemm_defaults(g);                                               // x_ = emb.W + b (:334-335)
-            g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
-            g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
-            HIPCHK(h, gemm_nn(h, g));
-        }
     }
 
     // ---- the scan over caption positions (:495-512)

@@ -99,8 +99,9 @@ struct Tile {
 // Hazards: stage s^1 is written (k-block 1 of iteration kt) only after barrier(kt-1), and its last readers read it
 // before that barrier (their k-block-3 fragments are fetched during k-block 2); stage s^1 is read (k-block 3)
 // only after barrier(kt), which follows every wave's write.
+// `lin`: linear tile index of this workgroup within the problem (after the XCD remap); `ky`: its K slice (split-K).
 template <int TM, int TN, bool AT, bool BT, bool EDGE>
-__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
+__device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, const int ky) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = Tile<BM, !AT>;
     using TB = Tile<BN, BT>;
@@ -109,17 +110,13 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     float* sB = smem + 2 * TA::ELEMS;
 
     const int tiles_n = g.N / BN;
-    const int nblk = gridDim.x;
-    const int bid = blockIdx.x;
-    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
-    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
     const int m0 = (lin / tiles_n) * BM;
     const int n0 = (lin % tiles_n) * BN;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int l31 = lane & 31, kh = lane >> 5;
 #ifdef STATTN_PROBES
-    if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
+    if (g.clk && lin == 0 && ky == 0 && tid == 0) {
         g.clk[0] = __builtin_readcyclecounter(); g.clk[1] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
@@ -137,9 +134,9 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     int ldc = g.ldc;
     if (g.kslices > 1) {
         const int per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
-        kb = blockIdx.y * per;
+        kb = ky * per;
         ke = kb + per < g.K ? kb + per : g.K;
-        Cout = g.ws + (size_t)blockIdx.y * g.M * g.N;
+        Cout = g.ws + (size_t)ky * g.M * g.N;
         ldc = g.N;
     }
     const int nk = ke > kb ? (ke - kb + BK - 1) / BK : 0;
@@ -225,7 +222,7 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
     if (kt < nk) STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
 #undef STATTN_GEMM2_TILE
 #ifdef STATTN_PROBES
-    if (g.clk && bid == 0 && blockIdx.y == 0 && tid == 0) {
+    if (g.clk && lin == 0 && ky == 0 && tid == 0) {
         g.clk[2] = __builtin_readcyclecounter(); g.clk[3] = __builtin_amdgcn_s_memrealtime();
     }
 #endif
@@ -255,6 +252,39 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
             }
         }
     }
+}
+
+// XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
+// (consecutive tiles share the A row-panel -> L2 hits).  Bijective for any grid size.
+__device__ __forceinline__ int xcd_linear(int bid, int nblk, int remap) {
+    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
+    return remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
+}
+
+template <int TM, int TN, bool AT, bool BT, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
+    gemm2_body<TM, TN, AT, BT, EDGE>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
+}
+
+// Several independent problems in one launch (same transposes, no split-K): the tiles of the small ones fill the
+// tail of the large one instead of running as under-filled launches of their own (a 1664 x 1024 projection is 416
+// tiles for 1024 resident workgroups).  tile_start[p] .. tile_start[p + 1] = the tiles of problem p.
+// Work balance: the tiles of every problem are dealt to the eight XCDs separately (block b runs on XCD b % 8, which walks
+// its share of problem 0, then of problem 1, ...), so each XCD gets the same mix of long-K and short-K tiles and the
+// short ones fill its tail.  (One contiguous run of the concatenated tile list per XCD left the XCDs that drew the
+// K = 4096 tiles working 40 % longer than the others.)
+template <int TM, int TN, bool AT, bool BT, bool EDGE>
+__global__ __launch_bounds__(256, 2) void gemm2_group_kernel(const GemmGroup G) {
+    const int xcd = blockIdx.x % NXCD;
+    int j = blockIdx.x / NXCD, p = 0, lin = 0;
+    for (; p < G.n; ++p) {
+        const int tiles = G.tile_start[p + 1] - G.tile_start[p], q8 = tiles / NXCD, r8 = tiles % NXCD;
+        const int mine = q8 + (xcd < r8 ? 1 : 0);
+        if (j < mine) { lin = xcd * q8 + (xcd < r8 ? xcd : r8) + j; break; }
+        j -= mine;
+    }
+    if (p == G.n) return;                                       // padding block of this XCD
+    gemm2_body<TM, TN, AT, BT, EDGE>(G.g[p], lin, 0);
 }
 
 // C[i] (+)= alpha * sum_z ws[z][i]   (fixed summation order: deterministic)
@@ -336,6 +366,31 @@ void gemm_clock_dump() {
     g_clk_rec->clear();
 }
 #endif
+
+hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n) {
+    if (n < 1 || n > GEMM_GROUP_MAX) return hipErrorInvalidValue;
+    if (n == 1) return launch_gemm(s, gs[0], false, false);
+    GemmGroup G{};
+    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    bool edge = false;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = gs[i];
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || g.K % 4 != 0 || g.ws) return hipErrorInvalidValue;
+        g.kslices = 1; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
+        edge = edge || g.K % BK != 0;
+        G.g[i] = g;
+        G.tile_start[i] = tiles;
+        tiles += ((g.M + 63) / 64) * (g.N / 64);
+    }
+    G.tile_start[n] = tiles; G.n = n;
+    int per_xcd = 0;                                            // blocks an XCD may have to walk: sum of its largest shares
+    for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
+    const dim3 grid(per_xcd * NXCD);
+    if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, true>), grid, dim3(256), 0, s, G);
+    else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, false>), grid, dim3(256), 0, s, G);
+    return hipGetLastError();
+}
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;

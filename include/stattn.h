@@ -190,7 +190,8 @@ int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx);
  *     nll_scale * sum_b cost[b]  +  alpha_c * sum_{4 alphas} mean_{T(,K)} sum_b (1 - sum_t alpha)^2 .
  * nll_scale = 1/m reproduces cost.mean() (:1129); a data-parallel rank passes 1/B_global and the
  * all-reduce SUMS the buffers (the regulariser is a batch sum, :1140-1143).  The L2 term
- * (:1130-1136) is batch-independent and is applied once, in stattn_update.  lt_mode 1 only. */
+ * (:1130-1136) is batch-independent and is applied once, in stattn_update.  Both lt_modes (the derivative of the
+ * per-step CL.Wclt of lt_mode 0 is evaluated in the hoisted form: same function, section 8 of DESIGN.md); fp32 handles. */
 int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c);
 /* value of the loss above + decay_c * sum ||theta||^2, after stattn_backward */
 int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss);

@@ -61,6 +61,28 @@ def test_gradients_match_autograd_oracle(dims, B, T, K, t, kw):
     np.testing.assert_allclose(dec.get_loss(1e-3), ref_d['loss'], rtol=2e-4)
 
 
+@pytest.mark.parametrize("dims,B,T,K,t", [(SMALL, 5, 5, 4, 6), (MEDIUM, 9, 26, 8, 7), (SMALL, 4, 5, 11, 5)])
+def test_gradients_in_the_reference_summation_order_lt_mode_0(dims, B, T, K, t):
+    """lt_mode 0 = CL.Wclt as one GEMM per step like the reference (:416); its backward pass evaluates the same
+    derivative in the hoisted form.  All 41 gradients against the autograd oracle, and an update step."""
+    import stattn
+    from oracle import stattn_oracle as O
+    from oracle import stattn_oracle_grad as OG
+    opt = O.default_options(**dims)
+    P = O.random_params(opt, seed=6, dtype=np.float32)
+    dec = stattn.Decoder(opt, lt_mode=0)
+    dec.set_params(P)
+    batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=31)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    dec.backward(alpha_c=0.70602)
+    ref = OG.loss_and_grads(P, opt, batch, decay_c=0.0, alpha_c=0.70602)
+    _check_grads(dec.get_grads(), ref['grads'])
+    np.testing.assert_allclose(dec.get_loss(0.0), ref['loss'], rtol=2e-4)
+    dec.update(decay_c=1e-4, clip_c=10.0)
+    assert all(np.isfinite(v).all() for v in dec.get_params().values())
+
+
 def test_gradients_are_run_to_run_reproducible_including_the_embedding():
     """No atomics anywhere in the backward pass: the embedding gradient is gathered along per-word token chains in a
     fixed order (round 1 scattered it with atomicAdd), split-K and K-slice reductions run in a fixed order."""

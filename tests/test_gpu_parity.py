@@ -600,10 +600,6 @@ def test_call_order_errors_are_reported_not_fatal(stattn_mod, O):
     with pytest.raises(stattn_mod.NativeError, match="no forward pass"):
         dec.backward()
     dec.forward_train()
-    dec0 = stattn_mod.Decoder(opt, lt_mode=0)
-    dec0.set_params(P); dec0.set_batch(**batch); dec0.forward_train()
-    with pytest.raises(ValueError, match="lt_mode 1"):
-        dec0.backward()
     with pytest.raises(KeyError):
         dec.set_param('no_such_param', np.zeros(3, np.float32))
     with pytest.raises(ValueError):

@@ -1577,7 +1577,6 @@ int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx) {
 int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (!h) return STATTN_EINVAL;
     if (!h->have_fwd) return fail(h, STATTN_ESTATE, "backward: no forward pass has run on the staged batch");
-    if (h->opt.lt_mode != 1) return fail(h, STATTN_EINVAL, "backward is implemented for lt_mode 1 only");
     if (h->opt.precision != 0) return fail(h, STATTN_EINVAL, "backward needs an fp32 handle: the bf16 path is forward / decode only");
     HIPCHK(h, hipSetDevice(h->device));
     const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp, Fl = h->Fl, Fm = h->Fm;
@@ -1669,6 +1668,17 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // every gradient array is written in full by its GEMM / column sum; only Wemb is written row-wise (the rows of the
     // words of this batch), so only that region is cleared (the padding between arrays was zeroed at creation)
     HIPCHK(h, hipMemsetAsync(G_("Wemb"), 0, h->params[h->pindex["ff_state_W"]].off * sizeof(float), s));
+
+    // lt_mode 0 ran CL.Wclt per step in the forward pass (the reference's summation order, :416).  Its derivative is the
+    // same function as lt_mode 1's: <dplt.Wclt^T, L_k> = <dplt, L_k.Wclt> and sum_s CL_s^T.dplt_s = L^T.(sum_s alpha dplt_s),
+    // so the backward pass uses the hoisted form for both: LW = L.Wclt is formed here once (27.9 GFLOP at C2).
+    if (h->opt.lt_mode == 0) {
+        CHK(getbuf_t(h, "LW", MTK * D, &LW));
+        GemmArgs g;
+        gemm_defaults(g);
+        g.A = L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = LW; g.ldc = D; g.M = (int)MTK; g.N = D; g.K = D;
+        HIPCHK(h, launch_gemm(s, g, false, false));
+    }
 
     // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
     const bool reg = alpha_c > 0.f;

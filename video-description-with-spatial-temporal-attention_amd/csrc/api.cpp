@@ -1851,17 +1851,25 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, gemm(true, false, L, D, dPL, D, G_("decoder_Wcl_att"), D, D, D, (int)MTK, 0));
     CSADD(dPL, D, (int)MTK, D, G_("decoder_bl_att"), 0, nullptr);
     HIPCHK(h, gemm(true, false, L, D, dLW, D, G_("decoder_Wclt_att"), D, D, D, (int)MTK, 0));
-    HIPCHK(h, gemm(true, false, Gc, D, dPG, D, G_("decoder_Wcg_att"), D, D, D, (int)MT, 0));
     CSADD(dPG, D, (int)MT, D, G_("decoder_bg_att"), 0, nullptr);
-    HIPCHK(h, gemm(true, false, Mo, D, dPM, D, G_("decoder_Wcm_att"), D, D, D, (int)MT, 0));
     CSADD(dPM, D, (int)MT, D, G_("decoder_bm_att"), 0, nullptr);
     // recurrent weights: one batched TN GEMM over all (t*m) rows each
     HIPCHK(h, gemm(true, false, hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R, 0));
     HIPCHK(h, gemm(true, false, ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R, 0));
-    {
+    {   // the six D x D weight gradients with a short K (frames or steps x rows): 256 tiles each -- alone they needed a
+        // split-K pass each; as ONE grouped launch of 1536 tiles they fill the chip directly
+        GemmArgs gq[6];
+        auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int Kd) {
+            gemm_defaults(q);
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = D; q.M = D; q.N = D; q.K = Kd;
+        };
+        tn(gq[0], Gc, D, dPG, D, G_("decoder_Wcg_att"), (int)MT);
+        tn(gq[1], Mo, D, dPM, D, G_("decoder_Wcm_att"), (int)MT);
         const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
-        for (int i = 0; i < 4; ++i)
-            HIPCHK(h, gemm(true, false, hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), D, D, D, (int)R, 0));
+        for (int i = 0; i < 4; ++i) tn(gq[2 + i], hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), (int)R);
+        static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
+        if (nogroup) { for (const GemmArgs& q : gq) HIPCHK(h, gemm(true, false, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 0)); }
+        else HIPCHK(h, launch_gemm_group(s, gq, 6, true));
     }
     HIPCHK(h, gemm(true, false, emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R, 0));
     CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);

@@ -367,18 +367,18 @@ void gemm_clock_dump() {
 }
 #endif
 
-hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n) {
+hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA) {
     if (n < 1 || n > GEMM_GROUP_MAX) return hipErrorInvalidValue;
-    if (n == 1) return launch_gemm(s, gs[0], false, false);
+    if (n == 1) return launch_gemm(s, gs[0], tA, false);
     GemmGroup G{};
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     bool edge = false;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         GemmArgs g = gs[i];
-        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || g.K % 4 != 0 || g.ws) return hipErrorInvalidValue;
-        g.kslices = 1; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
-        edge = edge || g.K % BK != 0;
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;
+        g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
+        edge = edge || g.K % BK != 0 || (tA && g.M % 64 != 0);
         G.g[i] = g;
         G.tile_start[i] = tiles;
         tiles += ((g.M + 63) / 64) * (g.N / 64);
@@ -387,8 +387,13 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n) {
     int per_xcd = 0;                                            // blocks an XCD may have to walk: sum of its largest shares
     for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
     const dim3 grid(per_xcd * NXCD);
-    if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, true>), grid, dim3(256), 0, s, G);
-    else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, false>), grid, dim3(256), 0, s, G);
+    if (tA) {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, false>), grid, dim3(256), 0, s, G);
+    } else {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, false>), grid, dim3(256), 0, s, G);
+    }
     return hipGetLastError();
 }
 

@@ -1701,18 +1701,36 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
 
     // ---- softmax / NLL and readout (:687-715), all (t*m) rows at once
     HIPCHK(h, launch_dlogit(s, pr, Vp, dx, dmask, nll_scale, lg, Vp, (int)R, V, Vp));           // dlogit overwrites logits
-    HIPCHK(h, gemm(true, false, a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R, 0));         // dWo = a^T dlogit
     CSADD(lg, Vp, (int)R, Vp, G_("ff_logit_b"), 0, nullptr);
     HIPCHK(h, gemm(false, true, lg, Vp, w.Wo, Vp, da, E, (int)R, E, Vp, 0));                     // da = dlogit Wo^T
     HIPCHK(h, launch_tanh_bwd(s, da, tz, d2, da, R * E));                                        // dz (in place)
     float* dz = da;
-    HIPCHK(h, gemm(true, false, hd, D, dz, E, G_("ff_logit_lstm_W"), E, D, E, (int)R, 0));
     CSADD(dz, E, (int)R, E, G_("ff_logit_lstm_b"), 0, nullptr);
-    HIPCHK(h, gemm(false, true, dz, E, w.Wl1, E, dhd, D, (int)R, D, E, 0));                      // dhd = dz Wl1^T
-    if (h->opt.ctx2out) {
-        HIPCHK(h, gemm(true, false, ctx, D, dz, E, G_("ff_logit_ctxglm_W"), E, D, E, (int)R, 0));
-        CSADD(dz, E, (int)R, E, G_("ff_logit_ctxglm_b"), 0, nullptr);
-        HIPCHK(h, gemm(false, true, dz, E, w.Wl2, E, dctx_r, D, (int)R, D, E, 0));
+    if (h->opt.ctx2out) CSADD(dz, E, (int)R, E, G_("ff_logit_ctxglm_b"), 0, nullptr);
+    {   // the three readout weight gradients (K = t*m rows) in one grouped launch: dWo = a^T dlogit (1504 tiles) carries
+        // dWl1 = hd^T dz and dWl2 = ctx^T dz (128 tiles each, a split-K pass each on their own); likewise the two
+        // input gradients dhd = dz Wl1^T, dctx = dz Wl2^T
+        static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
+        GemmArgs gw[3], gi[2];
+        int nw = 0, ni = 0;
+        auto set = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int K_) {
+            gemm_defaults(q);
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = K_;
+        };
+        set(gw[nw++], a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R);
+        set(gw[nw++], hd, D, dz, E, G_("ff_logit_lstm_W"), E, D, E, (int)R);
+        set(gi[ni++], dz, E, w.Wl1, E, dhd, D, (int)R, D, E);
+        if (h->opt.ctx2out) {
+            set(gw[nw++], ctx, D, dz, E, G_("ff_logit_ctxglm_W"), E, D, E, (int)R);
+            set(gi[ni++], dz, E, w.Wl2, E, dctx_r, D, (int)R, D, E);
+        }
+        if (nogroup) {
+            for (int i = 0; i < nw; ++i) HIPCHK(h, gemm(true, false, gw[i].A, gw[i].lda, gw[i].B, gw[i].ldb, gw[i].C, gw[i].ldc, gw[i].M, gw[i].N, gw[i].K, 0));
+            for (int i = 0; i < ni; ++i) HIPCHK(h, gemm(false, true, gi[i].A, gi[i].lda, gi[i].B, gi[i].ldb, gi[i].C, gi[i].ldc, gi[i].M, gi[i].N, gi[i].K, 0));
+        } else {
+            HIPCHK(h, launch_gemm_group(s, gw, nw, true, false));
+            HIPCHK(h, launch_gemm_group(s, gi, ni, false, true));
+        }
     }
     CHK(region_done("ff_logit_lstm_W", nullptr));     // final before the reverse scan even starts
 

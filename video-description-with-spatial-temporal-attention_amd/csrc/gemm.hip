@@ -367,16 +367,16 @@ void gemm_clock_dump() {
 }
 #endif
 
-hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA) {
-    if (n < 1 || n > GEMM_GROUP_MAX) return hipErrorInvalidValue;
-    if (n == 1) return launch_gemm(s, gs[0], tA, false);
+hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
+    if (n < 1 || n > GEMM_GROUP_MAX || (tA && tB)) return hipErrorInvalidValue;
+    if (n == 1) return launch_gemm(s, gs[0], tA, tB);
     GemmGroup G{};
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     bool edge = false;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         GemmArgs g = gs[i];
-        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;   // (tB: K % 4 == 0 as well, covered)
         g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
         edge = edge || g.K % BK != 0 || (tA && g.M % 64 != 0);
         G.g[i] = g;
@@ -390,6 +390,9 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA) 
     if (tA) {
         if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, true>), grid, dim3(256), 0, s, G);
         else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, false>), grid, dim3(256), 0, s, G);
+    } else if (tB) {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, true, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, true, false>), grid, dim3(256), 0, s, G);
     } else {
         if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, true>), grid, dim3(256), 0, s, G);
         else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, false>), grid, dim3(256), 0, s, G);

@@ -34,11 +34,12 @@ struct GemmArgs {
 };
 void gemm_defaults(GemmArgs& g);
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& g, bool transA, bool transB);
-// up to eight independent problems (64x64 tiles, no split-K; all NN, or all with A given as [K,M]) in ONE launch: small
+// up to eight independent problems (64x64 tiles, no split-K; all NN, all with A given as [K,M], or all with B given as
+// [N,K]) in ONE launch: small
 // problems ride in the tail of a large one instead of under-filling the chip on their own
 constexpr int GEMM_GROUP_MAX = 8;
 struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int tile_start[GEMM_GROUP_MAX + 1]; int n; };
-hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool transA = false);
+hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool transA = false, bool transB = false);
 void gemm_clock_dump();   // tools only (STATTN_GEMM_CLK=1)
 
 // ----------------------------------------------------------------------------

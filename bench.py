@@ -505,6 +505,9 @@ def main():
         print(json.dumps(out))
     if world > 1:
         dist.barrier()
+        if train:
+            dec.comm_destroy()            # every rank leaves the communicator together, before any process exits
+        dist.barrier()
         dist.destroy_process_group()
 
 

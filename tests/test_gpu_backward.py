@@ -218,6 +218,29 @@ def test_in_library_rccl_allreduce_and_overlapped_regions():
         dec.close()
 
 
+def test_train_functions_with_global_batch_in_a_single_process():
+    """build_train_functions(global_batch=...) is the data-parallel entry of the Python surface; with one process (no
+    process group) it must behave exactly like the plain functions: same cost, same update."""
+    import stattn
+    from oracle import stattn_oracle as O
+    opt = O.default_options(**SMALL)
+    P = O.random_params(opt, seed=5, dtype=np.float32)
+    batch = O.synthetic_batch(opt, B=6, T=4, K=3, t=5, seed=9)
+    args = [batch[k] for k in ('x', 'mask', 'ctxg', 'mask_ctxg', 'ctxl', 'mask_ctxl', 'ctxm', 'mask_ctxm')]
+    outs = []
+    for gb in (None, 6):
+        model = stattn.Attention()
+        tparams = model.init_tparams(P)
+        model.build_model(tparams, opt)
+        f_grad_shared, f_update = model.build_train_functions(tparams, opt, decay_c=1e-4, alpha_c=0.5, clip_c=10.0, global_batch=gb)
+        r = f_grad_shared(*args)
+        f_update(0.01)
+        outs.append((r[0], stattn.common.unzip(tparams)))
+    assert abs(float(outs[0][0]) - float(outs[1][0])) < 1e-6 * max(1.0, abs(float(outs[0][0])))
+    for k in outs[0][1]:
+        np.testing.assert_array_equal(outs[0][1][k], outs[1][1][k])
+
+
 def test_train_loop_counterpart_learns_and_checkpoints(tmp_path):
     """Attention.train (minimal counterpart of model_attention.py:1239-1517): the loss goes down on a tiny
     synthetic task, checkpoints use the reference's npz layout (key = parameter name + history_errs), reload works."""

@@ -78,8 +78,12 @@ def init_comm(decoder, rank=None, world=None, group=None, path=None, seed=1234):
     identical, and give every rank its own dropout stream (the reference draws one mask per global batch; ranks
     that shared a seed would repeat the same mask on every shard)."""
     if rank is None or world is None:
-        import torch.distributed as dist
-        rank, world = dist.get_rank(group), dist.get_world_size(group)
+        try:
+            import torch.distributed as dist
+            have = dist.is_available() and dist.is_initialized()
+        except ImportError:
+            have = False
+        rank, world = (dist.get_rank(group), dist.get_world_size(group)) if have else (0, 1)   # no group: a single process
     if world > 1:
         decoder.comm_init(rank, world, exchange_token(decoder.comm_unique_id, rank, world, group, path))
         decoder.broadcast_params(0)

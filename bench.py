@@ -351,8 +351,6 @@ def main():
     from stattn import dp
     c = CONFIGS[args.config]
     options = make_options(c)
-    if args.precision == "bf16" and args.mode == "train":
-        raise SystemExit("--precision bf16 is a forward/decode path: use --mode forward, decode or beam")
     dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode, precision=args.precision)   # its own stream
     params = fast_params(dec.param_shapes(), 1234)    # same seed on every rank: replicas start identical
     dec.set_params(params)

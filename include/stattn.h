@@ -64,8 +64,10 @@ typedef struct stattn_options {
                                operands with fp32 accumulation, and the projected region tensors
                                L / PL / LW are stored in bf16 (the per-step attention kernel reads
                                half the bytes).  Recurrent matmuls, softmaxes and the LSTM stay
-                               fp32.  Forward / decode only (stattn_backward refuses), lt_mode 1.
-                               Accuracy: ~1e-3 on attention weights, ~2e-2 on logits.            */
+                               fp32.  lt_mode 1.  stattn_backward on such a handle is the fp32 backward
+                               pass evaluated at the stored (bf16) activations: mixed-precision training.
+                               Accuracy: ~1e-3 on attention weights, ~2e-2 on logits, gradients within
+                               a few per cent of their scale.                                    */
     int32_t reserved[4];
 } stattn_options;
 
@@ -191,7 +193,8 @@ int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx);
  * nll_scale = 1/m reproduces cost.mean() (:1129); a data-parallel rank passes 1/B_global and the
  * all-reduce SUMS the buffers (the regulariser is a batch sum, :1140-1143).  The L2 term
  * (:1130-1136) is batch-independent and is applied once, in stattn_update.  Both lt_modes (the derivative of the
- * per-step CL.Wclt of lt_mode 0 is evaluated in the hoisted form: same function, section 8 of DESIGN.md); fp32 handles. */
+ * per-step CL.Wclt of lt_mode 0 is evaluated in the hoisted form: same function, section 8 of DESIGN.md); on a bf16
+ * handle it is the fp32 backward pass evaluated at the stored bf16 activations. */
 int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c);
 /* value of the loss above + decay_c * sum ||theta||^2, after stattn_backward */
 int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss);

@@ -1501,12 +1501,13 @@ int stattn_forward_train(stattn_handle* h) {
         g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
         if (h->opt.ctx2out) { g.C = z1; g.ldc = E; }
-        else { g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E; }
+        else { g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E; g.C = a1; g.ldc = E; }   // (a1 in fp32 too: backward)
         HIPCHK(h, gemm_bf(h, g));
         if (h->opt.ctx2out) {
             HIPCHK(h, launch_cvt_bf16(s, ctx, bctx, R * D));
             g = bf_args(bctx, D, bw.Wl2, (int)R, E, D);
             g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E;
+            g.C = a1; g.ldc = E;                                            // (a1 in fp32 too: the backward pass reads it)
             HIPCHK(h, gemm_bf(h, g));
         }
         g = bf_args(ba1, E, bw.Wo, (int)R, Vp, E);
@@ -1577,7 +1578,6 @@ int stattn_get_states(stattn_handle* h, float* hs, float* cs, float* ctx) {
 int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (!h) return STATTN_EINVAL;
     if (!h->have_fwd) return fail(h, STATTN_ESTATE, "backward: no forward pass has run on the staged batch");
-    if (h->opt.precision != 0) return fail(h, STATTN_EINVAL, "backward needs an fp32 handle: the bf16 path is forward / decode only");
     HIPCHK(h, hipSetDevice(h->device));
     const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp, Fl = h->Fl, Fm = h->Fm;
     const Weights& w = h->w;
@@ -1668,6 +1668,19 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // every gradient array is written in full by its GEMM / column sum; only Wemb is written row-wise (the rows of the
     // words of this batch), so only that region is cleared (the padding between arrays was zeroed at creation)
     HIPCHK(h, hipMemsetAsync(G_("Wemb"), 0, h->params[h->pindex["ff_state_W"]].off * sizeof(float), s));
+
+    // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout
+    // only as a = tanh(z) * d2.  The backward pass is the fp32 one, evaluated at those stored activations: they are widened
+    // (exactly) into fp32 buffers, tanh(z) is recovered from a and the dropout multiplier, everything else was fp32 anyway.
+    if (h->opt.precision == 1) {
+        float *L32, *PL32, *LW32;
+        CHK(getbuf_t(h, "b_L32", MTK * D, &L32)); CHK(getbuf_t(h, "b_PL32", MTK * D, &PL32)); CHK(getbuf_t(h, "b_LW32", MTK * D, &LW32));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(L), L32, MTK * D));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(PL), PL32, MTK * D));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(LW), LW32, MTK * D));
+        L = L32; PL = PL32; LW = LW32;
+        HIPCHK(h, launch_unmul(s, a1, d2, tz, R * E));
+    }
 
     // lt_mode 0 ran CL.Wclt per step in the forward pass (the reference's summation order, :416).  Its derivative is the
     // same function as lt_mode 1's: <dplt.Wclt^T, L_k> = <dplt, L_k.Wclt> and sum_s CL_s^T.dplt_s = L^T.(sum_s alpha dplt_s),

@@ -744,6 +744,16 @@ hipError_t launch_embed_bwd(hipStream_t s, const EmbedPlan& pl, const float* dem
     if (pl.nmulti > 0) hipLaunchKernelGGL(embed_bwd_word_kernel, dim3(pl.nmulti), dim3(128), 0, s, pl, part, dWemb, E);
     return hipGetLastError();
 }
+__global__ __launch_bounds__(256) void unmul_kernel(const float* __restrict__ a, const float* __restrict__ mul, float* __restrict__ t, size_t n) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)gridDim.x * 256) {
+        const float m = mul[i];
+        t[i] = m != 0.f ? a[i] / m : 0.f;
+    }
+}
+hipError_t launch_unmul(hipStream_t s, const float* a, const float* mul, float* t, size_t n) {
+    hipLaunchKernelGGL(unmul_kernel, dim3(grid_for(n, 256, 2048)), dim3(256), 0, s, a, mul, t, n);
+    return hipGetLastError();
+}
 hipError_t launch_transpose(hipStream_t s, const float* in, int ldi, float* out, int ldo, int rows, int cols) {
     hipLaunchKernelGGL(transpose_kernel, dim3((cols + 31) / 32, (rows + 31) / 32), dim3(256), 0, s, in, ldi, out, ldo, rows, cols);
     return hipGetLastError();

@@ -433,6 +433,25 @@ hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_
     return hipGetLastError();
 }
 
+// bf16 -> fp32 (exact) for the backward pass of a bf16 handle, 8 values per thread
+__global__ __launch_bounds__(256) void cvt_f32_kernel(const uint16_t* __restrict__ src, float* __restrict__ dst, size_t n8) {
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+        const uint4 v = *reinterpret_cast<const uint4*>(src + 8 * i);
+        st4(dst + 8 * i, make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                                     __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u)));
+        st4(dst + 8 * i + 4, make_float4(__uint_as_float(v.z << 16), __uint_as_float(v.z & 0xffff0000u),
+                                         __uint_as_float(v.w << 16), __uint_as_float(v.w & 0xffff0000u)));
+    }
+}
+hipError_t launch_cvt_f32(hipStream_t s, const uint16_t* src, float* dst, size_t n) {
+    if (n == 0) return hipSuccess;
+    if (n % 8 != 0) return hipErrorInvalidValue;
+    const size_t n8 = n / 8;
+    int nb = (int)((n8 + 255) / 256); if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(cvt_f32_kernel, dim3(nb), dim3(256), 0, s, src, dst, n8);
+    return hipGetLastError();
+}
+
 hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N) {
     if (K <= 0 || N <= 0) return hipSuccess;
     hipLaunchKernelGGL(cvt_bf16_t_kernel, dim3((N + 31) / 32, (K + 31) / 32), dim3(256), 0, s, src, ld_src, dst, ld_dst, K, N);

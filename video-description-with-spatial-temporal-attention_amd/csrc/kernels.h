@@ -64,6 +64,7 @@ struct GemmBfArgs {
 hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
 hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n);               // n % 8 == 0
 hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N);  // dst[n][k] = src[k][n]
+hipError_t launch_cvt_f32(hipStream_t s, const uint16_t* src, float* dst, size_t n);                 // exact widening, n % 8 == 0
 
 // ----------------------------------------------------------------------------
 // Register-streaming "skinny" grouped GEMM (skinny.hip) for M <= a few hundred rows:
@@ -322,6 +323,8 @@ struct MultiSumArgs { const float* src[12]; size_t n[12]; float* dst[12]; float 
 hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]]); part: >= 384 floats
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
 hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
+// t[i] = mul[i] != 0 ? a[i] / mul[i] : 0: recovers tanh(z) from a = tanh(z) * mul where only a was kept (bf16 readout)
+hipError_t launch_unmul(hipStream_t s, const float* a, const float* mul, float* t, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);
 // Plan of the deterministic embedding gradient, built on the host from the token ids when a batch is staged
 // (api.cpp build_embed_plan): device pointers into one int buffer.

@@ -237,7 +237,7 @@ int stattn_allreduce_scalars(stattn_handle* h, float* vals, int n);
  * transA: A given as [K,M]; transB: B given as [N,K]; act: 0 none, 1 tanh.
  * Runs the LDS-tiled fp32 MFMA kernel (kind=0), the register-streaming skinny
  * kernel (kind=1), the bf16-MFMA kernel (kind=2: no transA, alpha = 1, K % 8 == 0) or the row-panel kernel of the
- * per-step GEMMs (kind=3: M <= 256, N % 16 == 0, K % 16 == 0, no transA, alpha = 1; B is repacked on the device).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
+ * per-step GEMMs (kind=3: M <= 512, N % 16 == 0, K % 16 == 0, no transA, alpha = 1; B is repacked on the device).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
 int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K,
                     float alpha, const float* A, const float* B, const float* bias,
                     const float* add, int act, float* C);

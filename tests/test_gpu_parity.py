@@ -371,7 +371,7 @@ def test_hip_path_matches_committed_golden_vectors(stattn_mod, O):
                 h = sc['m%d_s%d_h' % (mm, s)].astype(np.float32); c = sc['m%d_s%d_c' % (mm, s)].astype(np.float32)
 
 
-@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (17, 48, 64), (33, 16, 32), (70, 96, 256), (160, 64, 512), (256, 32, 48),
+@pytest.mark.parametrize("M,N,K", [(64, 256, 128), (17, 48, 64), (33, 16, 32), (70, 96, 256), (160, 64, 512), (256, 32, 48), (320, 64, 256), (512, 32, 128),
                                    (64, 8192, 1024), (64, 1024, 4096)])
 def test_row_panel_gemm_matches_float64(stattn_mod, O, M, N, K):
     """panel.hip: every row in one workgroup, 16 / 32-column panels repacked in MFMA operand order -- all row-group

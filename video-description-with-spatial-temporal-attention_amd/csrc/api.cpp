@@ -301,7 +301,8 @@ struct BwdPanels { float *WcT, *UT, *WdT; };
 // kernels give 32)
 bool use_panels(const stattn_handle* h, int M, int min_rows = 17) {
     static const char* off = getenv("STATTN_NO_PANELS");       // A/B switch for tools
-    return !off && M >= min_rows && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
+    // (the kernels take up to 512 rows; past 256 the 64-column kernels, which split the rows over workgroups, are as fast)
+    return !off && M >= min_rows && M <= 256 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
 }
 
 int pack(stattn_handle* h, const float* W, int ldw, int src_t, int K, int ntiles, int cols, float* dst, int S_total = 0, int s_off = 0) {
@@ -2037,7 +2038,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
     } else if (kind == 3) {
         // row-panel kernel: B repacked on the device (transB: the operand is B^T, packed straight from B [N][K])
         if (transA || alpha != 1.f || !panel_supported(M) || N % 16 || K % 16)
-            return fail(h, STATTN_EINVAL, "panel kernel: no transA, alpha must be 1, M <= 256, N and K multiples of 16");
+            return fail(h, STATTN_EINVAL, "panel kernel: no transA, alpha must be 1, M <= 512, N and K multiples of 16");
         float* P;
         CHK(getbuf_t(h, "dbg_P", (size_t)K * N, &P));
         CHK(pack(h, dB, transB ? K : N, transB ? 1 : 0, K, N / 16, PN_COLS_PLAIN, P));

@@ -118,7 +118,7 @@ struct LstmArgs {
 hipError_t launch_lstm(hipStream_t s, const LstmArgs& a);
 
 // ----------------------------------------------------------------------------
-// Row-panel kernels (panel.hip) for 17..256 rows: a workgroup owns every row and 16 / 32 output columns; the
+// Row-panel kernels (panel.hip) for up to 512 rows: a workgroup owns every row and 16 / 32 output columns; the
 // weights are read from panels repacked once per pass in MFMA-operand order (see the file header).
 // ----------------------------------------------------------------------------
 enum { PN_COLS_PLAIN = 0, PN_COLS_LSTM = 1 };

@@ -1,4 +1,4 @@
-// Row-panel fp32 MFMA kernels for the per-timestep dense work of the decoder at batch sizes of 17..256 rows
+// Row-panel fp32 MFMA kernels for the per-timestep dense work of the decoder at batch sizes of up to 512 rows
 // (training: 64 rows; beam search: videos x beam rows):
 //   state projections h.[Wdl|Wdg|Wdm|Wdlt] and h.U        model_attention.py:371, 389, 402, 415, 437
 //   ctx.Wc (+ emb.W) + gates + cell update                 :437-457
@@ -379,7 +379,7 @@ PnGeom pn_geom(int M, int max_waves, int min_steps) {
 
 }  // namespace
 
-bool panel_supported(int M) { return M >= 1 && M <= 256; }
+bool panel_supported(int M) { return M >= 1 && M <= 512; }    // 16 row groups of two m-tiles in a 1024-thread workgroup
 
 size_t packed_rows_floats(int M, int K) { return (size_t)((M + 15) / 16) * 16 * K; }
 

@@ -31,16 +31,24 @@ if __name__ == "__main__":
 
 def bench_traffic(fetch_csv, write_csv, out_json, keys):
     """profiles/pmc_traffic.json for bench.py: HBM-side bytes per launch (FETCH_SIZE x 2 + WRITE_SIZE) of the kernels its
-    roofline objects name, from two summaries written by main().  `keys`: the bench configurations the PMC command covers."""
+    roofline objects name, from two summaries written by main().  `keys`: the bench configurations the PMC command covers.
+    A class may span several kernel symbols (the plain forward GEMM launches are gemm2_group_kernel and gemm2_kernel
+    instances): launch-weighted mean over all of them."""
     import json
-    pats = {"gemm_nn": "gemm2_kernel<1, 1, false, false, false>", "spatial": "spatial2_kernel<128>", "temporal": "temporal_kernel"}
+    pats = {"gemm_nn": ["gemm2_group_kernel<1, 1, false, false, false>", "gemm2_kernel<1, 1, false, false, false>"],
+            "spatial": ["spatial2_kernel<128>"], "temporal": ["temporal_kernel"]}
 
-    def col(path, pat, idx):
+    def total(path, plist, idx):
+        tot, n = 0.0, 0
         for r in csv.reader(open(path)):
-            if len(r) > idx and pat in r[0]:
-                return float(r[idx]) * 1e6
-        return 0.0
-    vals = {k: col(fetch_csv, p, 5) + col(write_csv, p, 4) for k, p in pats.items()}
+            if len(r) > idx and any(p in r[0] for p in plist):
+                tot += float(r[idx]) * 1e6 * int(r[2]); n += int(r[2])
+        return tot, n
+    vals = {}
+    for k, plist in pats.items():
+        f, n = total(fetch_csv, plist, 5)
+        w, _ = total(write_csv, plist, 4)
+        vals[k] = (f + w) / n if n else None
     try:
         cur = json.load(open(out_json))
     except Exception:

@@ -315,7 +315,7 @@ def main():
     ap.add_argument("--host-loop", action="store_true", help="decode mode: drive f_next from the host word by word (reference protocol) "
                                                              "instead of the device-resident loop gen_sample uses by default")
     ap.add_argument("--lt-mode", type=int, default=None)
-    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"],
                     help="bf16: the bf16-MFMA forward/decode path of BASELINE configs[3] (not the headline; no training)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")

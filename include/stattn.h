@@ -67,7 +67,14 @@ typedef struct stattn_options {
                                fp32.  lt_mode 1.  stattn_backward on such a handle is the fp32 backward
                                pass evaluated at the stored (bf16) activations: mixed-precision training.
                                Accuracy: ~1e-3 on attention weights, ~2e-2 on logits, gradients within
-                               a few per cent of their scale.                                    */
+                               a few per cent of their scale.
+                           2 = fp32 results with the LDS-tiled GEMMs (context projections, x projection,
+                               readout, and all their weight / input gradients) computed on the bf16
+                               matrix cores: each fp32 operand is split EXACTLY into three bf16 terms
+                               and six of the nine term products are accumulated in fp32 (the dropped
+                               three are below one fp32 rounding of the product).  Same accuracy
+                               against float64 as precision 0 (tests/test_gpu_split.py), ~2x the GEMM
+                               rate.  Everything else is the precision-0 path; both lt_modes.      */
     int32_t reserved[4];
 } stattn_options;
 

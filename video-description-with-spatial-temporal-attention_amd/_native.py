@@ -160,9 +160,9 @@ class Decoder(object):
         # 'fp32' (default, the parity configuration) or 'bf16' (bf16-MFMA forward/decode path, BASELINE configs[3])
         if precision is None:
             precision = os.environ.get("STATTN_PRECISION", options.get("stattn_precision", "fp32"))
-        if precision not in ("fp32", "bf16"):
-            raise ValueError("precision must be 'fp32' or 'bf16'")
-        o.precision = 1 if precision == "bf16" else 0
+        if precision not in ("fp32", "bf16", "split"):
+            raise ValueError("precision must be 'fp32', 'bf16' or 'split' (fp32 results, GEMMs on the bf16 matrix cores)")
+        o.precision = {"fp32": 0, "bf16": 1, "split": 2}[precision]
         self.precision = precision
         self.options = dict(options)
         rc = lib.stattn_create(C.byref(o), int(device), C.c_void_p(stream) if stream else None, C.byref(self._h))

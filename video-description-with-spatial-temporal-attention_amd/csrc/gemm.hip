@@ -367,9 +367,21 @@ void gemm_clock_dump() {
 }
 #endif
 
+hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, float* C, int ldc, int M, int N, int slices, float alpha, int accumulate) {
+    const size_t n4 = (size_t)M * N / 4;
+    int nb = (int)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, ws, C, ldc, M, N, slices, alpha, accumulate);
+    return hipGetLastError();
+}
+
 hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
     if (n < 1 || n > GEMM_GROUP_MAX || (tA && tB)) return hipErrorInvalidValue;
     if (n == 1) return launch_gemm(s, gs[0], tA, tB);
+    {
+        bool split = true;
+        for (int i = 0; i < n; ++i) split = split && gs[i].split && gemm_split_supported(gs[i], tA, tB);
+        if (split) return launch_gemm_split_group(s, gs, n, tA, tB);
+    }
     GemmGroup G{};
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     bool edge = false;
@@ -401,6 +413,7 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, 
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
+    if (gin.split && gemm_split_supported(gin, tA, tB)) return launch_gemm_split(s, gin, tA, tB);
     GemmArgs g = gin;
     g.kslices = 1;
 #ifdef STATTN_PROBES
@@ -436,11 +449,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
                 g.kslices = ks;
                 hipError_t e = launch_cfg<1, 1>(s, g, tA, tB);
                 if (e != hipSuccess) return e;
-                const size_t n4 = (size_t)g.M * g.N / 4;
-                int nb = (int)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
-                hipLaunchKernelGGL(splitk_reduce_kernel, dim3(nb), dim3(256), 0, s, g.ws, g.C, g.ldc, g.M, g.N,
-                                   ks, g.alpha, g.accumulate);
-                return hipGetLastError();
+                return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
             }
         }
     }

@@ -30,6 +30,7 @@ struct GemmArgs {
     float* ws; size_t ws_floats;
     int kbeg, kend, kslices;           // internal
     int xcd_remap;                     // internal: XCD-aware tile order on/off
+    int split;                         // 1: run on the bf16 matrix cores with three-term operands (gemm_split.hip)
     long long* clk;                    // internal: clock probe slot {cycles0, wall0, cycles1, wall1} written by block 0 (-DSTATTN_PROBES builds only)
 };
 void gemm_defaults(GemmArgs& g);
@@ -41,6 +42,17 @@ constexpr int GEMM_GROUP_MAX = 8;
 struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int tile_start[GEMM_GROUP_MAX + 1]; int n; };
 hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool transA = false, bool transB = false);
 void gemm_clock_dump();   // tools only (STATTN_GEMM_CLK=1)
+hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, float* C, int ldc, int M, int N, int slices, float alpha, int accumulate);
+
+// ----------------------------------------------------------------------------
+// fp32 GEMM on the bf16 matrix cores (gemm_split.hip): same problem description and epilogue as above, every operand
+// split exactly into three bf16 terms, six MFMA products per k-block, fp32 accumulation.  launch_gemm /
+// launch_gemm_group route here when GemmArgs::split is set and gemm_split_supported() (N % 128 == 0, 16-byte
+// aligned k-contiguous operands); otherwise they run the fp32-MFMA kernel.
+// ----------------------------------------------------------------------------
+bool gemm_split_supported(const GemmArgs& g, bool transA, bool transB);
+hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& g, bool transA, bool transB);
+hipError_t launch_gemm_split_group(hipStream_t s, const GemmArgs* gs, int n, bool transA, bool transB);
 
 // ----------------------------------------------------------------------------
 // bf16-MFMA GEMM (gemm_bf16.hip), precision = bf16 handles only:  C = epi(A[M,K] . B[N,K]^T), both operands bf16

@@ -316,8 +316,10 @@ def main():
                                                              "instead of the device-resident loop gen_sample uses by default")
     ap.add_argument("--lt-mode", type=int, default=None)
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16", "split"],
-                    help="bf16: the bf16-MFMA forward/decode path of BASELINE configs[3] (not the headline; no training)")
+                    help="bf16: the bf16-MFMA path of BASELINE configs[3]; split: fp32 results with the large GEMMs on the bf16 matrix "
+                         "cores through exactly split operands (neither is the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-split", action="store_true", help="skip the extra precision='split' measurement reported beside the fp32 headline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
     args = ap.parse_args()
     args.beam_set = args.beam is not None
@@ -422,7 +424,9 @@ def main():
     B, T, K, D, E, F, V, t = c["B"], c["T"], c["K"], c["D"], c["E"], c["F"], c["V"], c["t"]
     Vp = (V + 127) // 128 * 128
     bf16 = args.precision == "bf16"
-    mfma_peak = MFMA_BF16_PEAK_TF if bf16 else MFMA_F32_PEAK_TF
+    split = args.precision == "split"
+    # split: fp32 work done as six bf16 MFMA products per multiply -> the roof is the dense bf16 peak / 6
+    mfma_peak = MFMA_BF16_PEAK_TF if bf16 else (MFMA_BF16_PEAK_TF / 6.0 if split else MFMA_F32_PEAK_TF)
     traffic = measured_traffic(args, dec)            # rocprofv3 PMC bytes per launch from profiles/, or {}
     # (1) dominant kernel class by time share: the LDS-tiled MFMA GEMM.  `roofline` = all plain (NN) launches of one
     #     forward pass (flops per launch / average launch duration); `kernels` below has every launch on its own.
@@ -441,8 +445,9 @@ def main():
     nn_flops = sum(2.0 * m_ * n_ * k_ for l_ in launches for _, m_, n_, k_ in l_) + (2.0 * BT * D * D * t if dec.lt_mode == 0 else 0.0)
     g_ms, g_n = kms["gemm_nn"]
     per_fwd = g_n / 3.0
-    gname = "gemm_bf16_kernel<TM,TN>" if bf16 else "gemm2_kernel<TM,TN,false,false,EDGE>"
-    roofline = dict(kernel="%s%s (all %d plain launches of one forward pass)" % (gname, "" if bf16 else " / gemm2_group_kernel", round(per_fwd)),
+    gname = "gemm_bf16_kernel<TM,TN>" if bf16 else ("gemm3_kernel<MT,NT,false,false,EDGE>" if split else "gemm2_kernel<TM,TN,false,false,EDGE>")
+    ggroup = "gemm3_group_kernel" if split else "gemm2_group_kernel"
+    roofline = dict(kernel="%s%s (all %d plain launches of one forward pass)" % (gname, "" if bf16 else " / " + ggroup, round(per_fwd)),
                     bound="mfma", achieved=(nn_flops / per_fwd) / (g_ms * 1e-3) / 1e12 if g_ms else None,
                     peak=mfma_peak, unit="TFLOP/s", frac=None, traffic=traffic.get("gemm_nn"),
                     flops_per_launch=nn_flops / max(per_fwd, 1), ms_per_launch=g_ms)
@@ -479,7 +484,7 @@ def main():
         temporal=hbm("temporal_kernel", B * T * D * 4.0 * 3, kms["temporal"][0], "temporal"))
     for l_, ms in zip(launches, gms):
         kernels["gemm_" + "+".join(x_[0] for x_ in l_)] = mfma(
-            "%s %s" % (gname if len(l_) == 1 else "gemm2_group_kernel<1,1,false,false,EDGE>", " + ".join("%dx%dx%d" % x_[1:] for x_ in l_)),
+            "%s %s" % (gname if len(l_) == 1 else ggroup, " + ".join("%dx%dx%d" % x_[1:] for x_ in l_)),
             sum(2.0 * m_ * n_ * k_ for _, m_, n_, k_ in l_), ms)
     step_ms = sum(kms[k_][0] for k_ in ("hproj", "spatial", "lt_gemm", "temporal", "lstm"))
     if args.kernel_breakdown and rank == 0:
@@ -487,9 +492,10 @@ def main():
 
     out = dict(metric="decoder steps/sec (batch x timestep)", value=value, unit="row-steps/s", n_gpus=world,
                steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
-               scaling="weak", vs_baseline=None, dtype="bf16" if bf16 else "f32", data="synthetic",
+               scaling="weak", vs_baseline=None, dtype="bf16" if bf16 else ("f32 (GEMM operands as three exact bf16 terms)" if split else "f32"), data="synthetic",
                config=dict(workload="%s %s%s: %s, batch %d per GPU, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d, caption length %d, lt_mode=%d"
-                                    % (args.config, args.mode, " (bf16-MFMA projections/readout, bf16 region tensors, fp32 recurrence)" if bf16 else "",
+                                    % (args.config, args.mode, " (bf16-MFMA projections/readout, bf16 region tensors, fp32 recurrence)" if bf16 else
+                                       (" (fp32 results; the LDS-tiled GEMMs run on the bf16 matrix cores with exactly split operands)" if split else ""),
                                        "optimisation step = build_model forward + BPTT backward + gradient all-reduce + clip + Adadelta"
                                        if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
                                        B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),
@@ -497,6 +503,34 @@ def main():
                roofline=roofline, roofline_hbm=roofline_hbm, kernels=kernels,
                decoder_step_us=step_ms * 1e3,       # sum of the per-step kernel classes (HIP events, includes the record gaps)
                kernel_ms={k: v[0] for k, v in kms.items()})
+    if args.precision == "fp32" and world == 1 and not args.no_split and args.h2d == "none":
+        # The same workload with precision='split' (fp32 results, the big GEMMs on the bf16 matrix cores with exactly
+        # split operands: csrc/gemm_split.hip), reported beside the headline, never as it.
+        alt = stattn.Decoder(options, device=local, lt_mode=args.lt_mode, precision="split")
+        alt.set_params(params)
+        alt.set_batch(**batch)
+        alt.set_use_noise(1.0 if train else 0.0)
+        alt.set_seed(1234 + rank)
+        alt_fn = dp.DataParallelStep(alt, global_batch=c["B"], alpha_c=0.70602, decay_c=1e-4, clip_c=10.0) if train else alt.forward_train
+        for _ in range(args.warmup):
+            alt_fn()
+        alt.sync()
+        t1 = time.perf_counter()
+        for _ in range(args.steps):
+            alt_fn()
+        alt.sync()
+        adt = time.perf_counter() - t1
+        alt.set_profiling(True)
+        for _ in range(3):
+            alt.forward_train()
+        akms = alt.kernel_ms()
+        alt.set_profiling(False)
+        a_ms = akms["gemm_nn"][0]
+        out["split_gemm"] = dict(value=c["B"] * c["t"] * args.steps / adt, unit="row-steps/s", ms_per_step=adt / args.steps * 1e3,
+                                 precision="split", gemm_TFLOPs=(nn_flops / per_fwd) / (a_ms * 1e-3) / 1e12 if a_ms else None,
+                                 gemm_peak_TFLOPs=MFMA_BF16_PEAK_TF / 6.0,
+                                 note="same step with stattn_options.precision = 2: fp32 results at the fp32 parity bar (tests/test_gpu_split.py)")
+        del alt
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, options, params, 99, train)

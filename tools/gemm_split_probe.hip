@@ -2,7 +2,8 @@
 //   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DSTATTN_PROBES [-DGS_VARIANT=n] tools/gemm_split_probe.hip -o /tmp/gs_probe && /tmp/gs_probe
 // GS_VARIANT: 0 product kernel; 1 no split arithmetic (all three planes = the upper halves); 2 no LDS stores in the loop;
 // 3 no global loads in the loop; 4 no MFMAs; 5 MFMAs only (no operand reads, stores or loads in the loop);
-// 6 every global load re-reads the first two k-tiles (cache hits: issue cost without the memory latency).
+// 6 every global load re-reads the first two k-tiles (cache hits: issue cost without the memory latency);
+// 8 the global loads replaced by one multiply per value (split + stores stay live, no memory instructions).
 // Results of variants > 0 are wrong by construction; only the time is of interest.
 #include "../video-description-with-spatial-temporal-attention_amd/csrc/gemm_split.hip"
 

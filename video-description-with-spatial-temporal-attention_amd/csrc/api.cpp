@@ -1922,7 +1922,10 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
     CHK(region_done("ff_state_W", "decoder_W"));
     // -- region Wemb: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
-    HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, 0, h->opt.prev2out ? dz : nullptr, E));
+    // (dz is copied in first and the product accumulated onto it: without an `add` operand the 1920 x 512 x 4096 problem
+    // -- 240 tiles of 64 x 64 -- may be cut along K, which fills the chip)
+    if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, h->opt.prev2out ? 1 : 0));
     {
         const EmbedPlan pl = device_embed_plan(h, h->cur_set);
         float* epart;

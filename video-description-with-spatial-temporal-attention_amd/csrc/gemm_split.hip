@@ -262,7 +262,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
         unsigned char* wA = smem + wr * STAGE;                                                                \
         unsigned char* wB = wA + TA::BYTES;                                                                   \
         constexpr bool LD = GS_VARIANT != 5, ST = GS_VARIANT != 2 && GS_VARIANT != 5;                         \
-        constexpr bool GL = GS_VARIANT != 3 && GS_VARIANT != 5;                                               \
+        constexpr bool GL = GS_VARIANT != 3 && GS_VARIANT != 5 && GS_VARIANT != 8;                                               \
         if constexpr (LD) TA::frag(FA_NEXT[0], cA, wm * 32 * MT + l31, kh);                                   \
         if constexpr (ST) TA::template sstore_part<0>(RA, wA, tid);                                           \
         STATTN_GEMM3_MFMAS(FA, FB, 0, 1)                                                                      \
@@ -280,9 +280,11 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
         STATTN_GEMM3_MFMAS(FA, FB, 3, 4)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (GL) TA::template gload<EDGE>(RA, rsA, offA, g.lda, m0, g.M, ktile((KT) + 4), ke, tid);        \
+        if constexpr (GS_VARIANT == 8) { _Pragma("unroll") for (int q = 0; q < TA::NR; ++q) RA[q] *= 1.0001f; }       \
         STATTN_GEMM3_MFMAS(FA, FB, 4, 5)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (GL) TB::template gload<EDGE>(RB, rsB, offB, g.ldb, n0, g.N, ktile((KT) + 4), ke, tid);        \
+        if constexpr (GS_VARIANT == 8) { _Pragma("unroll") for (int q = 0; q < TB::NR; ++q) RB[q] *= 1.0001f; }       \
         STATTN_GEMM3_MFMAS(FA, FB, 5, 6)                                                                      \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         rd = rd == 2 ? 0 : rd + 1;                                                                            \

@@ -149,6 +149,8 @@ struct STile {
     __device__ static __forceinline__ void sstore(const float (&r)[NR], unsigned char* s, int tid) {
         sstore_part<0>(r, s, tid);
         sstore_part<1>(r, s, tid);
+        sstore_part<2>(r, s, tid);
+        sstore_part<3>(r, s, tid);
     }
 
     // the three bf16 terms of row `row`, k-group kh (k = 8 kh .. 8 kh + 7)
@@ -158,6 +160,37 @@ struct STile {
         for (int t = 0; t < 3; ++t) f[t] = *reinterpret_cast<const bf16x8*>(p + t * PLANE);
     }
 };
+
+// acc[i][j][r]: row = 32 i + (r & 3) + 8 (r >> 2) + 4 kh, column = 32 j + l31 of the wave tile (the 32x32 MFMA C layout)
+template <int MT, int NT>
+__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
+                                         int l31, int kh, float* Cout, int ldc) {
+#pragma unroll
+    for (int i = 0; i < MT; ++i) {
+#pragma unroll
+        for (int j = 0; j < NT; ++j) {
+            const int col = n0 + wn * 32 * NT + j * 32 + l31;
+            const float bias = g.bias ? g.bias[col] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int row = m0 + wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
+                if (row < g.M && g.kslices > 1) {
+                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
+                } else if (row < g.M) {
+                    float v = g.alpha * acc[i][j][r] + bias;
+                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
+                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
+                    if (g.act == 1) v = fast_tanh(v);
+                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
+                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
+                    float* c = g.C + (size_t)row * g.ldc + col;
+                    if (g.accumulate) v += *c;
+                    *c = v;
+                }
+            }
+        }
+    }
+}
 
 template <int MT, int NT, bool AT, bool BT, bool EDGE>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, const int ky) {
@@ -306,31 +339,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
     }
 #endif
 
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * 32 * NT + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < g.M && g.kslices > 1) {
-                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
-                } else if (row < g.M) {
-                    float v = g.alpha * acc[i][j][r] + bias;
-                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
-                    if (g.act == 1) v = fast_tanh(v);
-                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
-                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
-                    float* c = g.C + (size_t)row * g.ldc + col;
-                    if (g.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
+    epilogue<MT, NT>(g, acc, m0, n0, wm, wn, l31, kh, Cout, ldc);
 }
 
 __device__ __forceinline__ int xcd_linear(int bid, int nblk, int remap) {

@@ -65,7 +65,8 @@ typedef struct stattn_options {
                                L / PL / LW are stored in bf16 (the per-step attention kernel reads
                                half the bytes).  Recurrent matmuls, softmaxes and the LSTM stay
                                fp32.  lt_mode 1.  stattn_backward on such a handle is the fp32 backward
-                               pass evaluated at the stored (bf16) activations: mixed-precision training.
+                               pass evaluated at the stored (bf16) activations (its GEMMs as in precision 2):
+                               mixed-precision training.
                                Accuracy: ~1e-3 on attention weights, ~2e-2 on logits, gradients within
                                a few per cent of their scale.
                            2 = fp32 results with the LDS-tiled GEMMs (context projections, x projection,

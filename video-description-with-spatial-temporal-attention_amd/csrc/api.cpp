@@ -236,36 +236,36 @@ int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, c
     int n1 = 0, n2 = 0;
     {   // L = tanh(ctxl . ff_local_W + b)  (:664-665 / :782-783)
         GemmArgs& g = g1[n1++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = ctxl; g.lda = h->Fl; g.B = w.ff_local_W; g.ldb = D; g.C = c.L; g.ldc = D;
         g.M = nv * T * K; g.N = D; g.K = h->Fl; g.bias = w.ff_local_b; g.act = 1;
     }
     {   // M = tanh(ctxm . ff_motion_W + b) (:666-667 / :784-785)
         GemmArgs& g = g1[n1++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = ctxm; g.lda = h->Fm; g.B = w.ff_motion_W; g.ldb = D; g.C = c.Mo; g.ldc = D;
         g.M = nv * T; g.N = D; g.K = h->Fm; g.bias = w.ff_motion_b; g.act = 1;
     }
     {   // pctxg_ (:322)
         GemmArgs& g = g1[n1++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
     }
     if (extra) g1[n1++] = *extra;
     CHK(gemm_group(h, g1, n1));
     {   // pctxl_ (:324)
         GemmArgs& g = g2[n2++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = c.L; g.lda = D; g.B = w.Wcl; g.ldb = D; g.C = c.PL; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D; g.bias = w.bl;
     }
     if (h->opt.lt_mode == 1) {   // LW = L . Wclt  (the :416 projection hoisted out of the time loop)
         GemmArgs& g = g2[n2++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = c.L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = c.LW; g.ldc = D; g.M = nv * T * K; g.N = D; g.K = D;
     }
     {   // pctxm_ (:326)
         GemmArgs& g = g2[n2++];
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = c.Mo; g.lda = D; g.B = w.Wcm; g.ldb = D; g.C = c.PM; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bm;
     }
     CHK(gemm_group(h, g2, n2));
@@ -423,7 +423,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
     if (h->opt.lt_mode == 0) {   // pctxlt = CL.Wclt + blt + pstatelt, tanh, . Ult  (:416-422) as one MFMA GEMM
         Prof pr(h, KC_LTGEMM);
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = io.CL; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = io.plt; g.ldc = D;
         g.M = io.M * io.T; g.N = D; g.K = D; g.bias = w.blt;
         g.rowadd = io.sproj + 3 * (size_t)D; g.ldrow = 4 * D; g.rowgroup = io.T; g.act = 1;
@@ -1446,7 +1446,7 @@ int stattn_forward_train(stattn_handle* h) {
         HIPCHK(h, gemm_bf(h, g));
     } else {
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;                                               // x_ = emb.W + b (:334-335): rides with the projections
+        gemm_defaults(g); g.split = h->opt.precision != 0;                                               // x_ = emb.W + b (:334-335): rides with the projections
         g.A = emb; g.lda = E; g.B = w.W; g.ldb = 4 * D; g.C = xproj; g.ldc = 4 * D;
         g.M = (int)R; g.N = 4 * D; g.K = E; g.bias = w.b;
         CHK(project_context(h, m, T, K, c.G, rawl, rawm, c, &g));
@@ -1517,20 +1517,20 @@ int stattn_forward_train(stattn_handle* h) {
     } else {
         Prof pr_(h, KC_READOUT);
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;      // z1 = (h*d1).Wl1 + bl1 [+ emb]
+        gemm_defaults(g); g.split = h->opt.precision != 0;      // z1 = (h*d1).Wl1 + bl1 [+ emb]
         g.A = hd; g.lda = D; g.B = w.Wl1; g.ldb = E; g.C = h->opt.ctx2out ? z1 : a1; g.ldc = E;
         g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
         if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; g.Cact = tz; g.ldcact = E; }
         HIPCHK(h, gemm_nn(h, g));
         if (h->opt.ctx2out) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
-            gemm_defaults(g); g.split = h->opt.precision == 2;
+            gemm_defaults(g); g.split = h->opt.precision != 0;
             g.A = ctx; g.lda = D; g.B = w.Wl2; g.ldb = E; g.C = a1; g.ldc = E;
             g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E;
             g.Cact = tz; g.ldcact = E;
             HIPCHK(h, gemm_nn(h, g));
         }
-        gemm_defaults(g); g.split = h->opt.precision == 2;      // logit = a.Wo + bo
+        gemm_defaults(g); g.split = h->opt.precision != 0;      // logit = a.Wo + bo
         g.A = a1; g.lda = E; g.B = w.Wo; g.ldb = Vp; g.C = lg; g.ldc = Vp;
         g.M = (int)R; g.N = Vp; g.K = E; g.bias = w.bo;
         HIPCHK(h, gemm_nn(h, g));
@@ -1642,7 +1642,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     auto gemm = [&](bool tA, bool tB, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kd,
                     int accumulate, const float* add = nullptr, int ldadd = 0) -> hipError_t {
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = Kd;
         g.accumulate = accumulate; g.add = add; g.ldadd = ldadd;
         if (!add) { g.ws = ws; g.ws_floats = WS; }
@@ -1689,7 +1689,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (h->opt.lt_mode == 0) {
         CHK(getbuf_t(h, "LW", MTK * D, &LW));
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = LW; g.ldc = D; g.M = (int)MTK; g.N = D; g.K = D;
         HIPCHK(h, launch_gemm(s, g, false, false));
     }
@@ -1728,7 +1728,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         GemmArgs gw[3], gi[2];
         int nw = 0, ni = 0;
         auto set = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int K_) {
-            gemm_defaults(q); q.split = h->opt.precision == 2;
+            gemm_defaults(q); q.split = h->opt.precision != 0;
             q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = K_;
         };
         set(gw[nw++], a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R);
@@ -1892,7 +1892,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         // split-K pass each; as ONE grouped launch of 1536 tiles they fill the chip directly
         GemmArgs gq[6];
         auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int Kd) {
-            gemm_defaults(q); q.split = h->opt.precision == 2;
+            gemm_defaults(q); q.split = h->opt.precision != 0;
             q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = D; q.M = D; q.N = D; q.K = Kd;
         };
         tn(gq[0], Gc, D, dPG, D, G_("decoder_Wcg_att"), (int)MT);
@@ -2015,7 +2015,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
     if (add) HIPCHK(h, hipMemcpyAsync(dadd, add, (size_t)M * N * 4, hipMemcpyHostToDevice, s));
     if (kind == 0 || kind == 4) {
         GemmArgs g;
-        gemm_defaults(g); g.split = h->opt.precision == 2;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
         g.split = kind == 4;
         g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
         g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias ? dbias : nullptr;
@@ -2089,7 +2089,7 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
     HIPCHK(h, launch_uniform(s, dB, (size_t)K * N, 11, 2));
     GemmArgs g;
-    gemm_defaults(g); g.split = h->opt.precision == 2;
+    gemm_defaults(g); g.split = h->opt.precision != 0;
     g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
     g.M = M; g.N = N; g.K = K;
     {   // same split-K workspace the backward pass hands to its weight-gradient GEMMs

@@ -109,3 +109,41 @@ def test_split_handle_gradients_match_autograd_oracle():
     for k in got:
         scale = np.abs(np.asarray(ref['grads'][k])).max()
         assert np.abs(got[k] - ref['grads'][k]).max() <= 1e-4 * scale + 5e-6, k
+
+
+def test_split_and_fp32_handles_agree_at_configs1_size():
+    """BASELINE.json configs[1] at full size (batch 64, T=26, K=8, feat 4096, hidden 1024, vocab 12k, 30 steps), same weights
+    and minibatch on a precision='fp32' and a precision='split' handle: forward quantities agree far inside the 1e-4 bar,
+    every gradient to 5e-5 of its scale (half the bar against the float64 oracle; bias gradients are sums over 13 312 rows), and five optimisation steps follow the same loss trajectory."""
+    import stattn
+    import bench
+    c = bench.CONFIGS["c2"]
+    options = bench.make_options(c)
+    decs = [stattn.Decoder(options, precision=p) for p in ("fp32", "split")]
+    params = bench.fast_params(decs[0].param_shapes(), 1234)
+    batch = bench.synthetic_batch(c, 77)
+    outs, grads, losses = [], [], []
+    for d in decs:
+        d.set_params(params)
+        d.set_batch(**batch)
+        d.set_use_noise(0.0)
+        d.forward_train()
+        outs.append(d.get_forward(logits=True))
+        d.backward(alpha_c=0.70602)
+        grads.append(d.get_grads())
+        tr = []
+        for _ in range(5):
+            d.forward_train(); d.backward(alpha_c=0.70602)
+            tr.append(d.get_loss(1e-4))
+            d.update(decay_c=1e-4, clip_c=10.0)
+        losses.append(tr)
+    a, b = outs
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(a[name] - b[name]).max() < 2e-6, name
+    assert np.abs(a['logit'] - b['logit']).max() < 2e-5
+    np.testing.assert_allclose(a['cost'], b['cost'], rtol=1e-6, atol=1e-5)
+    for k in grads[0]:
+        scale = np.abs(grads[0][k]).max()
+        assert np.abs(grads[0][k] - grads[1][k]).max() <= 5e-5 * scale + 5e-6, k        # floor: the softmax offsets c_* have an exactly-zero gradient
+    np.testing.assert_allclose(losses[0], losses[1], rtol=2e-6)
+    assert losses[0][-1] < losses[0][0]

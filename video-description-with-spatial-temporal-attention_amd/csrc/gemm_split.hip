@@ -67,14 +67,14 @@ __device__ __forceinline__ void split3_pair(float a0, float a1, unsigned& H, uns
 }
 
 // KC: operand stored k-contiguous ([rows][K]); otherwise row-contiguous ([K][rows]).
-template <int BR, bool KC>
+template <int BR, bool KC, int NTH = 256>
 struct STile {
     static constexpr int KGSZ = BR * 16 + 64;        // bytes of one k-group; the pad keeps the 8-byte writes of the
                                                      // k-contiguous pass on 32 distinct banks
     static constexpr int PLANE = 2 * KGSZ;
     static constexpr int BYTES = 3 * PLANE;
-    static constexpr int NR = BR / 16;               // fp32 values per thread and tile
-    static constexpr int KPT = BR / 16;              // row-contiguous pass: consecutive k per thread (8 or 4)
+    static constexpr int NR = BR * 16 / NTH;         // fp32 values per thread and tile
+    static constexpr int KPT = NR;                   // row-contiguous pass: consecutive k per thread (16, 8 or 4)
 
     // Buffer loads: the operand is one resource (SGPRs), the per-thread byte offset is loop-invariant (voff), the k
     // position of a load is a scalar offset -- a tile costs no address arithmetic on the vector ALU, which the split
@@ -89,7 +89,7 @@ struct STile {
         if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NR / 4; ++i) {
-                const int idx = tid + i * 256, rr = idx >> 2, kq = idx & 3;
+                const int idx = tid + i * NTH, rr = idx >> 2, kq = idx & 3;
                 int row = r0 + rr;
                 row = row < rows_total ? row : rows_total - 1;          // clamped rows are never stored
                 off[i] = (unsigned)row * (unsigned)ld * 4u + 16u * kq;
@@ -104,7 +104,7 @@ struct STile {
         if constexpr (KC) {
 #pragma unroll
             for (int i = 0; i < NR / 4; ++i) {
-                const int kq = (tid + i * 256) & 3;
+                const int kq = (tid + i * NTH) & 3;
                 u32x4 v = u32x4{0u, 0u, 0u, 0u};
                 if (!EDGE || k0 + 4 * kq < K) v = __builtin_amdgcn_raw_buffer_load_b128(X, off[i], k0 * 4, 0);
 #pragma unroll
@@ -135,7 +135,7 @@ struct STile {
             for (int q = 0; q < 2; ++q) split3_pair(r[4 * PART + 2 * q], r[4 * PART + 2 * q + 1], h[q], m[q], l[q]);
             unsigned char* d;
             if constexpr (KC) {
-                const int idx = tid + PART * 256, rr = idx >> 2, kq = idx & 3;
+                const int idx = tid + PART * NTH, rr = idx >> 2, kq = idx & 3;
                 d = s + (kq >> 1) * KGSZ + rr * 16 + 8 * (kq & 1);
             } else {
                 const int rr = tid % BR, kq = (tid / BR) * NPARTS + PART;      // k = 4 kq .. 4 kq + 3
@@ -192,12 +192,14 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[
     }
 }
 
-template <int MT, int NT, bool AT, bool BT, bool EDGE>
+// WM x WN waves of (32 MT) x (32 NT) each; block tile (32 MT WM) x (32 NT WN)
+template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
 __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, const int ky) {
     static_assert(MT <= 2 && NT <= 2, "the tile schedule places two operand fetches per side");
-    constexpr int BM = 64 * MT, BN = 64 * NT;
-    using TA = STile<BM, !AT>;
-    using TB = STile<BN, BT>;
+    constexpr int BM = 32 * MT * WM, BN = 32 * NT * WN, NTH = 64 * WM * WN;
+    using TA = STile<BM, !AT, NTH>;
+    using TB = STile<BN, BT, NTH>;
+    static_assert(TA::NPARTS <= 2 && TB::NPARTS <= 2, "two store pieces per operand and tile are scheduled");
     constexpr int STAGE = TA::BYTES + TB::BYTES;
     __shared__ __attribute__((aligned(16))) unsigned char smem[3 * STAGE];       // stage s: A image, then B image
 
@@ -347,14 +349,14 @@ __device__ __forceinline__ int xcd_linear(int bid, int nblk, int remap) {
     return remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
 }
 
-template <int MT, int NT, bool AT, bool BT, bool EDGE>
-__global__ __launch_bounds__(256, MT * NT >= 4 ? 2 : 4) void gemm3_kernel(const GemmArgs g) {
-    gemm3_body<MT, NT, AT, BT, EDGE>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
+template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
+__global__ __launch_bounds__(64 * WM * WN, MT * NT >= 4 ? 2 : 4) void gemm3_kernel(const GemmArgs g) {
+    gemm3_body<MT, NT, WM, WN, AT, BT, EDGE>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
 }
 
 // several problems in one launch; tiles dealt to the XCDs as in gemm2_group_kernel (gemm.hip)
-template <int MT, int NT, bool AT, bool BT, bool EDGE>
-__global__ __launch_bounds__(256, MT * NT >= 4 ? 2 : 4) void gemm3_group_kernel(const GemmGroup G) {
+template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
+__global__ __launch_bounds__(64 * WM * WN, MT * NT >= 4 ? 2 : 4) void gemm3_group_kernel(const GemmGroup G) {
     const int xcd = blockIdx.x % NXCD;
     int j = blockIdx.x / NXCD, p = 0, lin = 0;
     for (; p < G.n; ++p) {
@@ -364,35 +366,35 @@ __global__ __launch_bounds__(256, MT * NT >= 4 ? 2 : 4) void gemm3_group_kernel(
         j -= mine;
     }
     if (p == G.n) return;
-    gemm3_body<MT, NT, AT, BT, EDGE>(G.g[p], lin, 0);
+    gemm3_body<MT, NT, WM, WN, AT, BT, EDGE>(G.g[p], lin, 0);
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int WM, int WN>
 hipError_t launch3(hipStream_t s, dim3 grid, const GemmArgs& g, bool tA, bool tB, bool edge) {
-    const dim3 block(256);
+    const dim3 block(64 * WM * WN);
     if (edge) {
-        if (!tA && !tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, false, false, true>), grid, block, 0, s, g);
-        else if (!tA && tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, false, true, true>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm3_kernel<MT, NT, true, false, true>), grid, block, 0, s, g);
+        if (!tA && !tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, false, false, true>), grid, block, 0, s, g);
+        else if (!tA && tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, false, true, true>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, true, false, true>), grid, block, 0, s, g);
     } else {
-        if (!tA && !tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, false, false, false>), grid, block, 0, s, g);
-        else if (!tA && tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, false, true, false>), grid, block, 0, s, g);
-        else hipLaunchKernelGGL((gemm3_kernel<MT, NT, true, false, false>), grid, block, 0, s, g);
+        if (!tA && !tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, false, false, false>), grid, block, 0, s, g);
+        else if (!tA && tB) hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, false, true, false>), grid, block, 0, s, g);
+        else hipLaunchKernelGGL((gemm3_kernel<MT, NT, WM, WN, true, false, false>), grid, block, 0, s, g);
     }
     return hipGetLastError();
 }
 
-template <int MT, int NT>
+template <int MT, int NT, int WM, int WN>
 hipError_t launch3_group(hipStream_t s, dim3 grid, const GemmGroup& G, bool tA, bool tB, bool edge) {
-    const dim3 block(256);
+    const dim3 block(64 * WM * WN);
     if (edge) {
-        if (!tA && !tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, false, false, true>), grid, block, 0, s, G);
-        else if (!tA && tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, false, true, true>), grid, block, 0, s, G);
-        else hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, true, false, true>), grid, block, 0, s, G);
+        if (!tA && !tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, false, false, true>), grid, block, 0, s, G);
+        else if (!tA && tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, false, true, true>), grid, block, 0, s, G);
+        else hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, true, false, true>), grid, block, 0, s, G);
     } else {
-        if (!tA && !tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, false, false, false>), grid, block, 0, s, G);
-        else if (!tA && tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, false, true, false>), grid, block, 0, s, G);
-        else hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, true, false, false>), grid, block, 0, s, G);
+        if (!tA && !tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, false, false, false>), grid, block, 0, s, G);
+        else if (!tA && tB) hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, false, true, false>), grid, block, 0, s, G);
+        else hipLaunchKernelGGL((gemm3_group_kernel<MT, NT, WM, WN, true, false, false>), grid, block, 0, s, G);
     }
     return hipGetLastError();
 }
@@ -423,7 +425,10 @@ bool gemm_split_supported(const GemmArgs& g, bool tA, bool tB) {
 
 // Tile choice: the 128 x 128 tile does twice the MFMA work per converted operand value, but a problem must offer about
 // two of them per CU; below that the 64 x 64 tile (four times the workgroups, 39 KB of LDS each) finishes sooner.
+// With at least one 256 x 128 tile per CU the eight-wave workgroup (same 64 x 64 per wave, a quarter less split, store
+// and load work per MFMA) is 5-6 % faster still (square 4096: 203 -> 216 TFLOP/s, ff_local 160 -> 168).
 static bool big_tiles(long tiles128) { return tiles128 >= 384; }
+static bool wide_tiles(long tiles256) { return tiles256 >= 256; }
 
 hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
@@ -441,15 +446,18 @@ hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool t
         if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
             g.kslices = ks;
             const int per = ((g.K + ks - 1) / ks + 31) / 32 * 32;
-            hipError_t e = launch3<2, 2>(s, dim3(tiles, ks), g, tA, tB, needs_edge(g, tA, 128, per));
+            hipError_t e = launch3<2, 2, 2, 2>(s, dim3(tiles, ks), g, tA, tB, needs_edge(g, tA, 128, per));
             if (e != hipSuccess) return e;
             return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
         }
     }
-    static const char* force = getenv("STATTN_SPLIT_TILE");      // probing only: "1" = 64 x 64, "2" = 128 x 128
+    static const char* force = getenv("STATTN_SPLIT_TILE");      // probing only: "1" = 64 x 64, "2" = 128 x 128, "3" = 256 x 128
+    const long tiles256 = (long)((g.M + 255) / 256) * (g.N / 128);
+    if (force ? force[0] == '3' : wide_tiles(tiles256))
+        return launch3<2, 2, 4, 2>(s, dim3((unsigned)tiles256), g, tA, tB, needs_edge(g, tA, 256, g.K));
     const bool big = force ? force[0] == '2' : big_tiles(tiles);
-    if (big) return launch3<2, 2>(s, dim3(tiles), g, tA, tB, needs_edge(g, tA, 128, g.K));
-    return launch3<1, 1>(s, dim3(((g.M + 63) / 64) * (g.N / 64)), g, tA, tB, needs_edge(g, tA, 64, g.K));
+    if (big) return launch3<2, 2, 2, 2>(s, dim3(tiles), g, tA, tB, needs_edge(g, tA, 128, g.K));
+    return launch3<1, 1, 2, 2>(s, dim3(((g.M + 63) / 64) * (g.N / 64)), g, tA, tB, needs_edge(g, tA, 64, g.K));
 }
 
 hipError_t launch_gemm_split_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
@@ -457,10 +465,14 @@ hipError_t launch_gemm_split_group(hipStream_t s, const GemmArgs* gs, int n, boo
     if (n == 1) return launch_gemm_split(s, gs[0], tA, tB);
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
     static const char* force = getenv("STATTN_SPLIT_TILE");
-    long tiles128 = 0;
-    for (int i = 0; i < n; ++i) tiles128 += (long)((gs[i].M + 127) / 128) * (gs[i].N / 128);
-    const bool big = force ? force[0] == '2' : big_tiles(tiles128);
-    const int T = big ? 128 : 64;
+    long tiles128 = 0, tiles256 = 0;
+    for (int i = 0; i < n; ++i) {
+        tiles128 += (long)((gs[i].M + 127) / 128) * (gs[i].N / 128);
+        tiles256 += (long)((gs[i].M + 255) / 256) * (gs[i].N / 128);
+    }
+    const bool wide = force ? force[0] == '3' : wide_tiles(tiles256);
+    const bool big = wide || (force ? force[0] == '2' : big_tiles(tiles128));
+    const int T = wide ? 256 : (big ? 128 : 64), TN_ = big ? 128 : 64;      // tile rows, tile columns
     GemmGroup G{};
     bool edge = false;
     int tiles = 0;
@@ -471,13 +483,14 @@ hipError_t launch_gemm_split_group(hipStream_t s, const GemmArgs* gs, int n, boo
         edge = edge || needs_edge(g, tA, T, g.K);
         G.g[i] = g;
         G.tile_start[i] = tiles;
-        tiles += ((g.M + T - 1) / T) * (g.N / T);
+        tiles += ((g.M + T - 1) / T) * (g.N / TN_);
     }
     G.tile_start[n] = tiles; G.n = n;
     int per_xcd = 0;
     for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
-    if (big) return launch3_group<2, 2>(s, dim3(per_xcd * NXCD), G, tA, tB, edge);
-    return launch3_group<1, 1>(s, dim3(per_xcd * NXCD), G, tA, tB, edge);
+    if (wide) return launch3_group<2, 2, 4, 2>(s, dim3(per_xcd * NXCD), G, tA, tB, edge);
+    if (big) return launch3_group<2, 2, 2, 2>(s, dim3(per_xcd * NXCD), G, tA, tB, edge);
+    return launch3_group<1, 1, 2, 2>(s, dim3(per_xcd * NXCD), G, tA, tB, edge);
 }
 
 }  // namespace stattn

@@ -1,0 +1,62 @@
+#!/usr/bin/env python
+"""Randomised parity sweep (GPU): random decoder shapes / option flags / batch shapes, forward quantities and all
+gradients of a handle against the float64 / autograd oracle at the fp32 bar (1e-4), for precision fp32 and split and
+both lt_modes.  usage: fuzz_parity.py [n_cases] [seed].  Prints one line per case and the worst ratios; exit code 1 on
+a violation."""
+import os
+import sys
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import stattn
+from oracle import stattn_oracle as O
+from oracle import stattn_oracle_grad as OG
+
+
+def run(n, seed):
+    rng = np.random.RandomState(seed)
+    worst_f, worst_g, bad = 0.0, 0.0, 0
+    for case in range(n):
+        D = int(rng.choice([64, 128, 192, 256, 320]))
+        dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128, 192])),
+                    n_words=int(rng.randint(20, 1500)), ctxl_dim=int(32 * rng.randint(1, 12)), ctxm_dim=int(32 * rng.randint(1, 12)),
+                    selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
+        B, T, K, t = int(rng.randint(1, 40)), int(rng.randint(1, 30)), int(rng.randint(1, 20)), int(rng.randint(2, 9))
+        lt_mode = int(rng.randint(2))
+        precision = ["fp32", "split"][case % 2]
+        opt = O.default_options(**dims)
+        P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
+        batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=int(rng.randint(1 << 30)))
+        dec = stattn.Decoder(opt, lt_mode=lt_mode, precision=precision)
+        dec.set_params(P)
+        dec.set_batch(**batch)
+        dec.forward_train()
+        out = dec.get_forward(logits=True)
+        ref = O.build_model_forward(O.cast_params(P, np.float64), opt,
+                                    **{k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()})
+        ef = max(np.abs(out[k] - ref[k]).max() for k in ('alphal', 'alphag', 'alpham', 'alphalt'))
+        ef = max(ef, np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max())
+        alpha_c = float(rng.choice([0.0, 0.70602]))
+        dec.backward(alpha_c=alpha_c)
+        got = dec.get_grads()
+        rg = OG.loss_and_grads(P, opt, batch, alpha_c=alpha_c)
+        eg, which = 0.0, ""
+        for k in got:
+            scale = np.abs(np.asarray(rg['grads'][k])).max()
+            r = np.abs(got[k] - rg['grads'][k]).max() / (1e-4 * scale + 5e-6)      # <= 1 passes (zero-gradient floor 5e-6)
+            if r > eg:
+                eg, which = r, k
+        ok = ef < 1e-4 and eg <= 1.0
+        bad += not ok
+        worst_f, worst_g = max(worst_f, ef), max(worst_g, eg)
+        print("%3d %-5s lt%d D=%3d E=%3d V=%4d Fl=%3d Fm=%3d sel=%d p2o=%d c2o=%d B=%2d T=%2d K=%2d t=%d  fwd %.2e  grad %.2f of the bar (%s)%s"
+              % (case, precision, lt_mode, D, dims['dim_word'], dims['n_words'], dims['ctxl_dim'], dims['ctxm_dim'], dims['selector'],
+                 dims['prev2out'], dims['ctx2out'], B, T, K, t, ef, eg, which, "" if ok else "   <-- FAIL"), flush=True)
+        del dec
+    print("cases %d  failures %d  worst forward error %.2e (bar 1e-4)  worst gradient %.2f of its bar" % (n, bad, worst_f, worst_g))
+    return bad
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2024) else 0)

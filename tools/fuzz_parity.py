@@ -58,5 +58,56 @@ def run(n, seed):
     return bad
 
 
+def run_beam(n, seed):
+    """Random sampler configurations: the device-resident batched beam search against the host-driven gen_sample loop over
+    the same handle (identical hypotheses) and against the float64 oracle driver (scores within 1e-4; the best hypothesis
+    may only differ when the oracle's two best scores are closer than that)."""
+    rng = np.random.RandomState(seed)
+    bad = 0
+    for case in range(n):
+        D = int(rng.choice([64, 128, 192]))
+        dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128])), n_words=int(rng.randint(12, 400)),
+                    ctxl_dim=int(32 * rng.randint(1, 6)), ctxm_dim=int(32 * rng.randint(1, 6)),
+                    selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
+        nvid, T, K = int(rng.randint(1, 6)), int(rng.randint(1, 12)), int(rng.randint(1, 10))
+        k, maxlen = int(rng.randint(1, 7)), int(rng.randint(3, 10))
+        precision = ["fp32", "split"][case % 2]
+        opt = dict(O.default_options(**dims), stattn_precision=precision, lt_mode=int(rng.randint(2)))
+        P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
+        P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += float(rng.uniform(0.0, 4.0))     # word 0 = <eos>
+        P64 = O.cast_params(P, np.float64)
+        b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=int(rng.randint(1 << 30)))
+        model = stattn.Attention()
+        tparams = model.init_tparams(P)
+        f_init, f_next = model.build_sampler(tparams, opt, None, None)
+        f_next.device_loop = False
+        res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
+        ok, why = True, ""
+        for v in range(nvid):
+            args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+            s_, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=maxlen)
+            a64 = tuple(a.astype(np.float64) for a in args)
+            sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=k, maxlen=maxlen)
+            bs, bsc = res[v]
+            scr = np.asarray(scr, np.float64)
+            if bs != s_ or not np.allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4):
+                ok, why = False, "device loop != host loop (video %d)" % v
+            elif len(bs) != len(sr) or not np.allclose(sorted(bsc), sorted(scr), rtol=1e-4, atol=1e-4):
+                # a near-tie at the beam boundary may swap which hypothesis survives; accept only if the oracle itself is that close
+                gap = np.min(np.diff(np.sort(scr))) if len(scr) > 1 else 1.0
+                if gap > 2e-4:
+                    ok, why = False, "scores differ from the oracle (video %d)" % v
+            elif bs[int(np.argmin(bsc))] != sr[int(np.argmin(scr))] and (np.sort(scr)[1] - np.sort(scr)[0] if len(scr) > 1 else 1.0) > 2e-4:
+                ok, why = False, "best hypothesis differs (video %d)" % v
+        bad += not ok
+        print("%3d %-5s lt%d D=%3d E=%3d V=%3d sel=%d p2o=%d c2o=%d videos=%d T=%2d K=%2d beam=%d maxlen=%d  %s"
+              % (case, precision, opt['lt_mode'], D, dims['dim_word'], dims['n_words'], dims['selector'], dims['prev2out'], dims['ctx2out'],
+                 nvid, T, K, k, maxlen, "ok" if ok else "FAIL: " + why), flush=True)
+    print("beam cases %d  failures %d" % (n, bad))
+    return bad
+
+
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "beam":
+        sys.exit(1 if run_beam(int(sys.argv[2]) if len(sys.argv) > 2 else 30, int(sys.argv[3]) if len(sys.argv) > 3 else 2024) else 0)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2024) else 0)

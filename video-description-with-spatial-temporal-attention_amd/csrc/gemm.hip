@@ -14,8 +14,7 @@
 // the same k assignment, so the only effect is a permutation of the summation order inside a
 // k-block of 8.  The LDS row stride of a k-contiguous tile is BK+4 dwords: ds_read_b128 is
 // serviced in 16-lane groups and (36*i) mod 64 hits 16 distinct 4-bank slots -> conflict-free.
-#include "kernels.h"
-#include "devmath.h"
+#include "gemm_common.h"
 
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +24,10 @@ namespace stattn {
 
 namespace {
 
+using namespace gemm_common;
+
 constexpr int BK = 32;
 constexpr int KPAD = BK + 4;
-constexpr int NXCD = 8;
 
 // KC: operand stored k-contiguous in memory ([rows][K]); RC: row-contiguous ([K][rows]).
 template <int BR, bool KC>
@@ -227,38 +227,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     }
 #endif
 
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-            const int col = n0 + wn * 32 * TN + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < g.M && g.kslices > 1) {
-                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
-                } else if (row < g.M) {
-                    float v = g.alpha * acc[i][j][r] + bias;
-                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
-                    if (g.act == 1) v = fast_tanh(v);
-                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
-                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
-                    float* c = g.C + (size_t)row * g.ldc + col;
-                    if (g.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
-
-// XCD-aware tile order: block b runs on XCD b % 8; give each XCD a contiguous run of tiles
-// (consecutive tiles share the A row-panel -> L2 hits).  Bijective for any grid size.
-__device__ __forceinline__ int xcd_linear(int bid, int nblk, int remap) {
-    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
-    return remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
+    epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, kh, Cout, ldc);
 }
 
 template <int TM, int TN, bool AT, bool BT, bool EDGE>
@@ -275,15 +244,8 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
 // K = 4096 tiles working 40 % longer than the others.)
 template <int TM, int TN, bool AT, bool BT, bool EDGE>
 __global__ __launch_bounds__(256, 2) void gemm2_group_kernel(const GemmGroup G) {
-    const int xcd = blockIdx.x % NXCD;
-    int j = blockIdx.x / NXCD, p = 0, lin = 0;
-    for (; p < G.n; ++p) {
-        const int tiles = G.tile_start[p + 1] - G.tile_start[p], q8 = tiles / NXCD, r8 = tiles % NXCD;
-        const int mine = q8 + (xcd < r8 ? 1 : 0);
-        if (j < mine) { lin = xcd * q8 + (xcd < r8 ? xcd : r8) + j; break; }
-        j -= mine;
-    }
-    if (p == G.n) return;                                       // padding block of this XCD
+    int p, lin;
+    if (!group_locate(G, blockIdx.x, p, lin)) return;                // padding block of this XCD
     gemm2_body<TM, TN, AT, BT, EDGE>(G.g[p], lin, 0);
 }
 

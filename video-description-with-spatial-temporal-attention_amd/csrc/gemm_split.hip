@@ -23,8 +23,7 @@
 // kinds are brought to that image in the write pass: k-contiguous operands with one 16-byte global load per thread and
 // row (4 lanes cover 64 contiguous bytes of a row), row-contiguous ones ([K][rows]) with 4-byte loads along the rows
 // (a wave reads 256 contiguous bytes per k) so that a thread ends up holding 8 consecutive k of its row.
-#include "kernels.h"
-#include "devmath.h"
+#include "gemm_common.h"
 
 #include <cstdlib>
 
@@ -32,12 +31,13 @@ namespace stattn {
 
 namespace {
 
+using namespace gemm_common;
+
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBK = 16;
-constexpr int NXCD = 8;
 #ifndef GS_VARIANT
 #define GS_VARIANT 0          // tools/gemm_split_probe.hip builds ablations 1..5; the product is 0
 #endif
@@ -160,37 +160,6 @@ struct STile {
         for (int t = 0; t < 3; ++t) f[t] = *reinterpret_cast<const bf16x8*>(p + t * PLANE);
     }
 };
-
-// acc[i][j][r]: row = 32 i + (r & 3) + 8 (r >> 2) + 4 kh, column = 32 j + l31 of the wave tile (the 32x32 MFMA C layout)
-template <int MT, int NT>
-__device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[MT][NT], int m0, int n0, int wm, int wn,
-                                         int l31, int kh, float* Cout, int ldc) {
-#pragma unroll
-    for (int i = 0; i < MT; ++i) {
-#pragma unroll
-        for (int j = 0; j < NT; ++j) {
-            const int col = n0 + wn * 32 * NT + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int row = m0 + wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                if (row < g.M && g.kslices > 1) {
-                    Cout[(size_t)row * ldc + col] = acc[i][j][r];
-                } else if (row < g.M) {
-                    float v = g.alpha * acc[i][j][r] + bias;
-                    if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-                    if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
-                    if (g.act == 1) v = fast_tanh(v);
-                    if (g.Cact) g.Cact[(size_t)row * g.ldcact + col] = v;
-                    if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
-                    float* c = g.C + (size_t)row * g.ldc + col;
-                    if (g.accumulate) v += *c;
-                    *c = v;
-                }
-            }
-        }
-    }
-}
 
 // WM x WN waves of (32 MT) x (32 NT) each; block tile (32 MT WM) x (32 NT WN)
 template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
@@ -344,11 +313,6 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
     epilogue<MT, NT>(g, acc, m0, n0, wm, wn, l31, kh, Cout, ldc);
 }
 
-__device__ __forceinline__ int xcd_linear(int bid, int nblk, int remap) {
-    const int xcd = bid % NXCD, q8 = nblk / NXCD, r8 = nblk % NXCD;
-    return remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD : bid;
-}
-
 template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
 __global__ __launch_bounds__(64 * WM * WN, MT * NT >= 4 ? 2 : 4) void gemm3_kernel(const GemmArgs g) {
     gemm3_body<MT, NT, WM, WN, AT, BT, EDGE>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
@@ -357,15 +321,8 @@ __global__ __launch_bounds__(64 * WM * WN, MT * NT >= 4 ? 2 : 4) void gemm3_kern
 // several problems in one launch; tiles dealt to the XCDs as in gemm2_group_kernel (gemm.hip)
 template <int MT, int NT, int WM, int WN, bool AT, bool BT, bool EDGE>
 __global__ __launch_bounds__(64 * WM * WN, MT * NT >= 4 ? 2 : 4) void gemm3_group_kernel(const GemmGroup G) {
-    const int xcd = blockIdx.x % NXCD;
-    int j = blockIdx.x / NXCD, p = 0, lin = 0;
-    for (; p < G.n; ++p) {
-        const int tiles = G.tile_start[p + 1] - G.tile_start[p], q8 = tiles / NXCD, r8 = tiles % NXCD;
-        const int mine = q8 + (xcd < r8 ? 1 : 0);
-        if (j < mine) { lin = xcd * q8 + (xcd < r8 ? xcd : r8) + j; break; }
-        j -= mine;
-    }
-    if (p == G.n) return;
+    int p, lin;
+    if (!group_locate(G, blockIdx.x, p, lin)) return;
     gemm3_body<MT, NT, WM, WN, AT, BT, EDGE>(G.g[p], lin, 0);
 }
 

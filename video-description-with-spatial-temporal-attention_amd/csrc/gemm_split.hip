@@ -1,28 +1,31 @@
 // fp32 GEMM on the bf16 matrix cores of gfx950 ("split" GEMM, GemmArgs::split).
 //
 // The fp32-input MFMA of CDNA4 runs at 1/16 of the bf16 rate (157 against 2516 TFLOP/s dense).  An fp32 number is
-// EXACTLY the sum of three bf16 numbers -- a = a0 + a1 + a2, each term the next 8 significant bits (bf16 keeps the
-// fp32 exponent range, so nothing under- or overflows) -- hence
+// EXACTLY the sum of three bf16 numbers -- a = a0 + a1 + a2 with a0 = bf16(a) rounded to nearest, a1 = bf16(a - a0),
+// a2 = a - a0 - a1 (bf16 keeps the fp32 exponent range, so nothing under- or overflows) -- hence
 //     a.b = a0b0 + (a0b1 + a1b0) + (a0b2 + a1b1 + a2b0) + [a1b2 + a2b1 + a2b2].
 // Every bf16 x bf16 product is exact in fp32 and the MFMA accumulates in fp32.  This kernel issues the SIX products
-// outside the bracket; the bracket is at most 2^-23 |a.b| per product, the size of ONE fp32 rounding of that
-// product, i.e. what any fp32 dot product already commits per term.  Measured against float64 the result is as
-// close as the fp32-MFMA kernel's (tests/test_gpu_split.py).  Six bf16 MFMAs per k-block of 16 cost 6 x 32 cycles
-// for 32x32x16 multiply-adds against 8 x 64 cycles on the fp32 pipe: the roof is 2516 / 6 = 419 TFLOP/s of fp32 work.
+// outside the bracket; with |a1| <= 2^-9 |a| and |a2| <= 2^-17 |a| the bracket is below 2^-25 |a.b| per product, with
+// random sign: less than ONE fp32 rounding of that product, which any fp32 dot product commits per term anyway.
+// Measured against float64 the result is as close as the fp32-MFMA kernel's (tests/test_gpu_split.py).  Six bf16 MFMAs
+// per k-block of 16 cost 6 x 32 cycles for 32x32x16 multiply-adds against 8 x 64 cycles on the fp32 pipe: the roof is
+// 2516 / 6 = 419 TFLOP/s of fp32 work.
 //
 // Same problem description, transposes and epilogue as gemm.hip (model_attention.py:322-335, 416, 664-667, 687-705
-// and their gradients); selected per handle (stattn_options.precision = 2), never silently.
+// and their gradients); selected per handle (stattn_options.precision = 2; also the backward GEMMs of bf16 handles),
+// never silently.  Operand shapes the kernel does not take (N % 128 != 0, unaligned k-contiguous operands, operands
+// of 2 GB or more) run on the fp32-MFMA kernel.
 //
-// Tiling: workgroup = 4 waves (2 x 2), block tile 128 x 128, BK = 16 (one MFMA k-block), wave tile 64 x 64 = 2 x 2
-// accumulators of 32 x 32.  Operands are read from global memory as fp32 four tiles ahead, split in registers
-// (truncation: and / sub / and / sub per value, v_perm_b32 to pair them) while the MFMAs of the current tile run, and
-// written as three bf16 planes to an LDS ring of three stages; MFMA operands are fetched one tile ahead; one
-// workgroup barrier per tile.
+// Tiling: WM x WN waves of 64 x 64 (32 x 32 in the small configuration) = 2 x 2 accumulators of 32 x 32 each; block
+// tile 64 x 64 (2 x 2 waves of 32 x 32), 128 x 128 (2 x 2) or 256 x 128 (4 x 2: eight waves), BK = 16 (one MFMA
+// k-block).  Operands are read from global memory as fp32 four tiles ahead, split in registers (v_cvt_pk_bf16_f32,
+// shift / and, subtract) while the MFMAs of the current tile run, and written as three bf16 planes to an LDS ring of
+// three stages; MFMA operands are fetched one tile ahead; one workgroup barrier per tile.
 // LDS image of a plane: [k-group of 8][row][8 bf16]: a lane's MFMA operand (8 consecutive k of one row) is one
 // 16-byte read and the 16 lanes of a ds_read_b128 group read consecutive rows = 256 contiguous bytes.  Both operand
 // kinds are brought to that image in the write pass: k-contiguous operands with one 16-byte global load per thread and
 // row (4 lanes cover 64 contiguous bytes of a row), row-contiguous ones ([K][rows]) with 4-byte loads along the rows
-// (a wave reads 256 contiguous bytes per k) so that a thread ends up holding 8 consecutive k of its row.
+// (a wave reads 256 contiguous bytes per k) so that a thread ends up holding consecutive k of its row.
 #include "gemm_common.h"
 
 #include <cstdlib>
@@ -39,7 +42,7 @@ typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int SBK = 16;
 #ifndef GS_VARIANT
-#define GS_VARIANT 0          // tools/gemm_split_probe.hip builds ablations 1..5; the product is 0
+#define GS_VARIANT 0          // tools/gemm_split_probe.hip builds ablations 1..8; the product is 0
 #endif
 
 // the upper halves of two fp32 words as one dword (low half = first value)

@@ -75,7 +75,8 @@ typedef struct stattn_options {
                                and six of the nine term products are accumulated in fp32 (the dropped
                                three are below one fp32 rounding of the product).  Same accuracy
                                against float64 as precision 0 (tests/test_gpu_split.py), ~2x the GEMM
-                               rate.  Everything else is the precision-0 path; both lt_modes.      */
+                               rate.  Everything else is the precision-0 path; both lt_modes.  (Operands must
+                               be finite: an infinite value yields NaN in the split.)              */
     int32_t reserved[4];
 } stattn_options;
 

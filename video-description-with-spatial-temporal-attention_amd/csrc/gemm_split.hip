@@ -10,7 +10,8 @@
 // Measured against float64 the result is as close as the fp32-MFMA kernel's (tests/test_gpu_split.py).  Six bf16 MFMAs
 // per k-block of 16 cost 6 x 32 cycles for 32x32x16 multiply-adds against 8 x 64 cycles on the fp32 pipe: the roof is
 // 2516 / 6 = 419 TFLOP/s of fp32 work.  Not IEEE in two corners that the decoder never visits: an infinite operand gives
-// NaN (inf - inf in the split) where fp32 gives inf, and values below the normal range may be flushed by the matrix core.
+// NaN (inf - inf in the split) where fp32 gives inf -- as does a finite one within 0.4 % of FLT_MAX, whose first term rounds
+// to infinity -- and values below the normal range may be flushed by the matrix core.
 //
 // Same problem description, transposes and epilogue as gemm.hip (model_attention.py:322-335, 416, 664-667, 687-705
 // and their gradients); selected per handle (stattn_options.precision = 2; also the backward GEMMs of bf16 handles),

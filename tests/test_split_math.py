@@ -1,5 +1,6 @@
 """The arithmetic claim behind csrc/gemm_split.hip (precision='split'), checked in numpy on the CPU: an fp32 value is
-EXACTLY the sum of three bf16 terms obtained by round-to-nearest of successive remainders, and the six term products the
+EXACTLY the sum of three bf16 terms obtained by round-to-nearest of successive remainders (for |a| in [1e-33, 3.38e38]:
+below, the third term falls into the bf16 subnormals; above, the first rounds to infinity), and the six term products the
 kernel accumulates miss the exact product by less than one fp32 rounding."""
 import numpy as np
 
@@ -22,7 +23,7 @@ def split3(a):
 def _samples(n, seed):
     rng = np.random.RandomState(seed)
     a = rng.standard_normal(n).astype(np.float32) * np.exp(rng.uniform(-30, 30, n)).astype(np.float32)
-    edge = np.array([1.0, -1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0e38, 1.2e-38, 0.0, 255.5, 0.1, 16777215.0], np.float32)
+    edge = np.array([1.0, -1.0, 1.0 + 2.0 ** -23, 1.0 - 2.0 ** -24, 3.0e38, 1.0e-30, 0.0, 255.5, 0.1, 16777215.0], np.float32)
     return np.concatenate([a, edge])
 
 

@@ -11,7 +11,7 @@
 // per k-block of 16 cost 6 x 32 cycles for 32x32x16 multiply-adds against 8 x 64 cycles on the fp32 pipe: the roof is
 // 2516 / 6 = 419 TFLOP/s of fp32 work.  Not IEEE in two corners that the decoder never visits: an infinite operand gives
 // NaN (inf - inf in the split) where fp32 gives inf -- as does a finite one within 0.4 % of FLT_MAX, whose first term rounds
-// to infinity -- and values below the normal range may be flushed by the matrix core.
+// to infinity -- and below about 1e-33 the third term falls into the bf16 subnormals (lost or flushed).
 //
 // Same problem description, transposes and epilogue as gemm.hip (model_attention.py:322-335, 416, 664-667, 687-705
 // and their gradients); selected per handle (stattn_options.precision = 2; also the backward GEMMs of bf16 handles),

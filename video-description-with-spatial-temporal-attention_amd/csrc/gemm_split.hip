@@ -31,6 +31,7 @@
 #include "gemm_common.h"
 
 #include <cstdlib>
+#include <cstring>
 
 namespace stattn {
 
@@ -400,15 +401,37 @@ hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool t
     if (!gemm_split_supported(g, tA, tB)) return hipErrorInvalidValue;
     const int tiles = ((g.M + 127) / 128) * (g.N / 128);
     if (g.ws && !g.bias && !g.add && !g.rowadd && !g.mul && !g.act && !g.Cact && tiles < 384 && g.K >= 1024) {
-        // deterministic split-K for the weight-gradient shapes (few tiles, long K), as in gemm.hip
-        int ks = (512 + tiles - 1) / tiles;
-        if (ks > g.K / 512) ks = g.K / 512;
-        if (ks > 32) ks = 32;
-        while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
+        // Deterministic split-K for the weight-gradient shapes (few tiles, long K), as in gemm.hip.  The slice count and the
+        // tile are chosen together with a small cost model fitted to a sweep over the decoder's shapes (slices 1..16 x both
+        // tiles): a CU runs two 128 x 128 workgroups at once, each then taking 2 u per k-step pair, or one alone (1.24 u:
+        // a lone workgroup leaves the matrix pipe idle more often), or one 256 x 128 workgroup = the work of two in
+        // 1.8 u; per-CU time = that x K / slices (+ a fixed 512 k-steps' worth per workgroup for prologue, epilogue and
+        // the reduction).  One slice too many starts another round: da = dlogit.Wo^T ran 9 slices of 60 tiles = 540
+        // workgroups for 512 slots (165 us; 8 slices of 32 wide tiles: 128-139 us).
+        const int t256 = ((g.M + 255) / 256) * (g.N / 128);
+        int kmax = g.K / 512;
+        if (kmax > 32) kmax = 32;
+        while (kmax > 1 && (size_t)kmax * g.M * g.N > g.ws_floats) --kmax;
+        int ks = 1;
+        bool wide = false;
+        double best = 1e30;
+        for (int c = 0; c < 2; ++c) {
+            for (int k = 2; k <= kmax; ++k) {
+                const int n = ((c ? t256 : tiles) * k + 255) / 256;                      // workgroups on the fullest CU
+                const double per_cu = c ? 1.8 * n : (n == 1 ? 1.24 : (double)n);
+                const double cost = per_cu * ((double)g.K / k + 512.0);
+                if (cost < best * 0.999) { best = cost; ks = k; wide = c != 0; }
+            }
+        }
+        if (const char* fk = getenv("STATTN_SPLIT_KS")) {                 // probing only: "<slices>[w]"
+            ks = atoi(fk); wide = fk[strlen(fk) - 1] == 'w';
+            if (ks > kmax) ks = kmax;
+        }
         if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
             g.kslices = ks;
             const int per = ((g.K + ks - 1) / ks + 31) / 32 * 32;
-            hipError_t e = launch3<2, 2, 2, 2>(s, dim3(tiles, ks), g, tA, tB, needs_edge(g, tA, 128, per));
+            hipError_t e = wide ? launch3<2, 2, 4, 2>(s, dim3(t256, ks), g, tA, tB, needs_edge(g, tA, 256, per))
+                                : launch3<2, 2, 2, 2>(s, dim3(tiles, ks), g, tA, tB, needs_edge(g, tA, 128, per));
             if (e != hipSuccess) return e;
             return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
         }

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Randomised parity sweep (GPU): random decoder shapes / option flags / batch shapes, forward quantities and all
 gradients of a handle against the float64 / autograd oracle at the fp32 bar (1e-4), for precision fp32 and split and
-both lt_modes.  usage: fuzz_parity.py [n_cases] [seed].  Prints one line per case and the worst ratios; exit code 1 on
+both lt_modes.  usage: fuzz_parity.py [n_cases] [seed] | large [n] [seed] | beam [n] [seed].  Prints one line per case and the worst ratios; exit code 1 on
 a violation."""
 import os
 import sys
@@ -14,15 +14,24 @@ from oracle import stattn_oracle as O
 from oracle import stattn_oracle_grad as OG
 
 
-def run(n, seed):
+def run(n, seed, large=False):
+    """large: production-sized dimensions (D up to 1024, vocabulary up to 12 000, up to 64 rows): the row-panel kernels,
+    the big GEMM tiles and the split softmax paths that the small cases do not reach."""
     rng = np.random.RandomState(seed)
     worst_f, worst_g, bad = 0.0, 0.0, 0
     for case in range(n):
-        D = int(rng.choice([64, 128, 192, 256, 320]))
-        dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128, 192])),
-                    n_words=int(rng.randint(20, 1500)), ctxl_dim=int(32 * rng.randint(1, 12)), ctxm_dim=int(32 * rng.randint(1, 12)),
-                    selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
-        B, T, K, t = int(rng.randint(1, 40)), int(rng.randint(1, 30)), int(rng.randint(1, 20)), int(rng.randint(2, 9))
+        if large:
+            D = int(rng.choice([512, 768, 1024]))
+            dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([256, 512])),
+                        n_words=int(rng.randint(3000, 12001)), ctxl_dim=int(64 * rng.randint(4, 33)), ctxm_dim=int(64 * rng.randint(4, 33)),
+                        selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
+            B, T, K, t = int(rng.randint(17, 65)), int(rng.randint(4, 27)), int(rng.randint(2, 13)), int(rng.randint(3, 8))
+        else:
+            D = int(rng.choice([64, 128, 192, 256, 320]))
+            dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128, 192])),
+                        n_words=int(rng.randint(20, 1500)), ctxl_dim=int(32 * rng.randint(1, 12)), ctxm_dim=int(32 * rng.randint(1, 12)),
+                        selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
+            B, T, K, t = int(rng.randint(1, 40)), int(rng.randint(1, 30)), int(rng.randint(1, 20)), int(rng.randint(2, 9))
         lt_mode = int(rng.randint(2))
         precision = ["fp32", "split"][case % 2]
         opt = O.default_options(**dims)
@@ -110,4 +119,6 @@ def run_beam(n, seed):
 if __name__ == "__main__":
     if len(sys.argv) > 1 and sys.argv[1] == "beam":
         sys.exit(1 if run_beam(int(sys.argv[2]) if len(sys.argv) > 2 else 30, int(sys.argv[3]) if len(sys.argv) > 3 else 2024) else 0)
+    if len(sys.argv) > 1 and sys.argv[1] == "large":
+        sys.exit(1 if run(int(sys.argv[2]) if len(sys.argv) > 2 else 8, int(sys.argv[3]) if len(sys.argv) > 3 else 2024, large=True) else 0)
     sys.exit(1 if run(int(sys.argv[1]) if len(sys.argv) > 1 else 40, int(sys.argv[2]) if len(sys.argv) > 2 else 2024) else 0)

@@ -457,6 +457,30 @@ def gen_sample(f_init_fn, f_next_fn, ctxg_0, ctxg_mask, ctxl_0, ctxl_mask, ctxm_
     return sample, sample_score, [next_state], [next_memory]               # one-element lists (n_layers_lstm = 1, :980-994)
 
 
+def sampler_closures(params, options, out_dtype=np.float32, draw_seed=None):
+    """(f_init, f_next) closures over this oracle with the calling convention of the compiled Theano functions
+    (model_attention.py:791-795, :845-848): outputs in `out_dtype` (floatX = float32 in the reference), `sample`
+    int64.  With `draw_seed` the returned sample is an inverse-CDF draw from the probabilities (stand-in for the
+    multinomial of :841; seeded numpy stream, not MRG) instead of the arg-max.  Used to drive gen_sample drivers --
+    the reference's own (tests/golden/make_ref_fixtures.py), this file's, and the product's host loop -- with
+    identical numbers."""
+    rng = np.random.RandomState(draw_seed) if draw_seed is not None else None
+    f64 = lambda a: None if a is None else np.asarray(a, np.float64)
+
+    def fi(ctxg, ctxg_mask):
+        g, h0, c0 = f_init(params, options, f64(ctxg), f64(ctxg_mask))
+        return [np.asarray(ctxg), h0.astype(out_dtype), c0.astype(out_dtype)]
+
+    def fn(x, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask, h, c):
+        probs, sample, h1, c1 = f_next(params, options, np.asarray(x, np.int64), f64(ctxg), f64(ctxg_mask), f64(ctxl),
+                                       None, f64(ctxm), None, f64(h), f64(c))
+        if rng is not None:
+            u = rng.uniform(size=(probs.shape[0], 1))
+            sample = np.minimum((np.cumsum(probs, axis=1) < u).sum(1), probs.shape[1] - 1).astype(np.int64)
+        return [probs.astype(out_dtype), sample, h1.astype(out_dtype), c1.astype(out_dtype)]
+    return fi, fn
+
+
 # ---------------------------------------------------------------------------
 # synthetic MSVD-shaped inputs (SURVEY section 8d)
 # ---------------------------------------------------------------------------

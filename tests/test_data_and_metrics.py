@@ -113,7 +113,9 @@ def test_sample_files_match_oracle_beam_search(tmp_path):
     sv2, st2 = metrics.generate_sample_gpu_single_process('attention', None, opt, eng, model, f_init, f_next,
                                                           save_dir=str(tmp_path / 'dev'), beam=3, whichset='both',
                                                           batched=True, tparams=tparams)
-    assert (sv, st) == (sv2, st2) and len(sv) == 3 and len(st) == 2
+    assert (sv, st) == (sv2, st2) and list(sv) == vids[:3] and list(st) == vids[3:]       # build_sample_pairs, metrics.py:79-83
+    assert all(v == [{'image_id': vid, 'caption': v[0]['caption']}] for d in (sv, st) for vid, v in d.items())
+    sv, st = [[v[0]['caption'] for v in d.values()] for d in (sv, st)]
     for d in ('host', 'dev'):
         assert open(os.path.join(str(tmp_path), d, 'valid_samples.txt')).read() == '\n'.join(sv) + '\n'
         assert open(os.path.join(str(tmp_path), d, 'test_samples.txt')).read().splitlines() == st

@@ -633,3 +633,40 @@ def test_next_sample_is_a_multinomial_draw_and_seedable(stattn_mod, O):
     f_init, f_next = model.build_sampler(tparams, opt, None, None)
     s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, g, gm, l, None, m, None, opt, None, 1, maxlen=6, stochastic=True)
     assert 1 <= len(s) <= 6 and sc > 0
+
+
+# ------------------------------------------------------------------ reference-EXECUTED gen_sample (tests/golden/ref_gen_sample.npz)
+@pytest.mark.parametrize("device_loop", [True, False])
+def test_reference_executed_gen_sample_on_the_hip_path(stattn_mod, O, device_loop):
+    """The fixture holds what the reference's OWN gen_sample (model_attention.py:852-994, executed in the build container by
+    tests/golden/make_ref_fixtures.py) returned around the oracle's f_init / f_next.  Here the product's gen_sample runs
+    around the HIP f_init / f_next -- as the device-side beam search and as the host-driven loop -- and must return the
+    same hypotheses in the same order, scores and final states within the fp32 bar."""
+    import json
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    fx = np.load(os.path.join(gold, 'ref_gen_sample.npz'))
+    cases = [c for c in json.loads(str(fx['cases'])) if not c['stochastic']]
+    P32 = dict(np.load(os.path.join(gold, 'params.npz')))
+    opt = O.default_options(dim=64, dim_word=64, n_words=37, ctxg_dim=64, ctxl_dim=32, ctxm_dim=32, ctxglm_dim=64)
+    model = stattn_mod.Attention()
+    n_eos = 0
+    for scale, bias in sorted(set((c['logit_scale'], c['eos_bias']) for c in cases)):
+        P = dict(P32)
+        P['ff_logit_W'] = P['ff_logit_W'] * np.float32(scale)
+        P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += np.float32(bias)
+        tparams = model.init_tparams(P)
+        f_init, f_next = model.build_sampler(tparams, opt, None, None)
+        f_next.device_loop = device_loop
+        for c in cases:
+            if (c['logit_scale'], c['eos_bias']) != (scale, bias):
+                continue
+            v, tag = c['video'], c['tag']
+            args = (fx['ctxg'][v], fx['mask_ctxg'][v], fx['ctxl'][v], fx['mask_ctxl'][v], fx['ctxm'][v], fx['mask_ctxm'][v])
+            s, sc, hs, cs = model.gen_sample(tparams, f_init, f_next, *args, opt, None, c['k'], c['maxlen'])
+            want = [row[:n].tolist() for row, n in zip(fx[tag + '_sample'], fx[tag + '_len'])]
+            assert [[int(w) for w in x] for x in s] == want, (c, s, want)
+            np.testing.assert_allclose(np.asarray(sc, np.float32), fx[tag + '_score'], rtol=0, atol=TOL * (1 + c['maxlen']))
+            assert len(hs) == 1 and hs[0].shape == fx[tag + '_state'].shape, (c, hs[0].shape)
+            assert np.abs(hs[0] - fx[tag + '_state']).max() < TOL and np.abs(cs[0] - fx[tag + '_memory']).max() < TOL
+            n_eos += sum(1 for x in want if x[-1] == 0)
+    assert n_eos >= 60

@@ -115,5 +115,15 @@ def load_params(path, params):
     return params
 
 
+def generate_minibatch_idx(dataset_size, minibatch_size):
+    """common.py:287-301: consecutive index lists of `minibatch_size`, the remainder as a last, shorter one."""
+    assert dataset_size >= minibatch_size
+    full = dataset_size - dataset_size % minibatch_size
+    idx = [list(range(s, s + minibatch_size)) for s in range(0, full, minibatch_size)]
+    if full < dataset_size:
+        idx.append(list(range(full, dataset_size)))
+    return idx
+
+
 def flatten_list_of_list(l):
     return [item for sublist in l for item in sublist]

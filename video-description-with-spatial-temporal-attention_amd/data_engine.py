@@ -68,13 +68,27 @@ def prepare_data(engine, IDs):
     return x, x_mask, yg, engine.get_ctxg_mask(yg), yl, engine.get_ctxl_mask(yl), ym, engine.get_ctxm_mask(ym)
 
 
+def sub_frames(frames, n_frames):
+    """get_sub_frames (data_engine.py:117-135) for array features: a video with fewer than `n_frames` frames is padded
+    with all-zero frames (pad_frames, :83-91; the mask rule then reads them as padding), any other one is cut into
+    `n_frames` nearly equal runs (numpy.array_split) and the first frame of each run is kept (:93-100)."""
+    frames = numpy.asarray(frames)
+    n = len(frames)
+    if n < n_frames:
+        return numpy.concatenate([frames, numpy.zeros((n_frames - n,) + frames.shape[1:], frames.dtype)], axis=0)
+    return frames[[run[0] for run in numpy.array_split(numpy.arange(n), n_frames)]]
+
+
 class MemoryEngine(object):
     """The slice of `Movie2Caption` (data_engine.py:9-256) the decoder path touches, over in-memory data:
     features[vid] = (global (T, ctxg_dim), local (T, K, ctxl_dim), motion (T, ctxm_dim)) float32 arrays and
-    captions[vid] = [{'cap_id': str, 'tokenized': 'a man is ...'}, ...]."""
+    captions[vid] = [{'cap_id': str, 'tokenized': 'a man is ...'}, ...].  With `n_frames` (the reference's K, config.py:47)
+    the arrays are whole videos of any length and every access goes through `sub_frames`, like the reference's
+    _filter_googlenet / _filter_rcnn / _filter_c3d (:39-60)."""
 
     def __init__(self, features, captions, worddict, n_words, maxlen=None, signature='youtube2text',
-                 train_ids=(), valid_ids=(), test_ids=()):
+                 train_ids=(), valid_ids=(), test_ids=(), n_frames=None):
+        self.K = n_frames
         self.signature = signature
         self.CAP = captions
         self.worddict = worddict
@@ -88,14 +102,17 @@ class MemoryEngine(object):
         self.ctxg_dim, self.ctxl_dim, self.ctxm_dim = g.shape[-1], l.shape[-1], m.shape[-1]
         self.train_ids, self.valid_ids, self.test_ids = list(train_ids), list(valid_ids), list(test_ids)
 
+    def get_sub_frames(self, frames, jpegs=False):
+        return frames if self.K is None else sub_frames(frames, self.K)
+
     def get_video_global_features(self, vid):
-        return self._features[vid][0]
+        return self.get_sub_frames(self._features[vid][0])
 
     def get_video_local_features(self, vid):
-        return self._features[vid][1]
+        return self.get_sub_frames(self._features[vid][1])
 
     def get_video_motion_features(self, vid):
-        return self._features[vid][2]
+        return self.get_sub_frames(self._features[vid][2])
 
     def get_ctxg_mask(self, ctxg):
         return ctx_mask(ctxg, self.ctxg_dim)
@@ -111,7 +128,8 @@ class MemoryEngine(object):
         ids = {'valid': self.valid_ids, 'test': self.test_ids, 'train': self.train_ids}[whichset]
         out = ([], [], [], [], [], [])
         for vid in ids:
-            g, l, m = self._features[vid]
+            g, l, m = (self.get_video_global_features(vid), self.get_video_local_features(vid),
+                       self.get_video_motion_features(vid))
             for lst, v in zip(out, (g, self.get_ctxg_mask(g), l, self.get_ctxl_mask(l), m, self.get_ctxm_mask(m))):
                 lst.append(v)
         return out

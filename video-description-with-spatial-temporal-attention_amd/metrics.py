@@ -6,6 +6,7 @@
 Scoring those files (BLEU/METEOR/CIDEr through coco-caption, metrics.py:147-176) needs Java and the ground-truth
 pickle and is out of scope; this module stops at the sample files and returns the captions."""
 import os
+from collections import OrderedDict
 
 import numpy
 
@@ -23,6 +24,14 @@ def seqs2words(caps, word_idict):
             words.append(word_idict[1] if w > len(word_idict) else word_idict[w])
         out.append(' '.join(words))
     return out
+
+
+def build_sample_pairs(samples, vidIDs):
+    """metrics.py:79-83: what coco-caption's scorer is fed -- {vidID: [{'image_id': vidID, 'caption': text}]}."""
+    pairs = OrderedDict()
+    for sample, vid in zip(samples, vidIDs):
+        pairs[vid] = [{'image_id': vid, 'caption': sample}]
+    return pairs
 
 
 def sample_split(engine, model, f_init, f_next, options, whichset, beam=5, maxlen=MAXLEN, batched=False, tparams=None):
@@ -47,7 +56,8 @@ def sample_split(engine, model, f_init, f_next, options, whichset, beam=5, maxle
 def generate_sample_gpu_single_process(model_type, model_archive, options, engine, model, f_init, f_next,
                                        save_dir='./samples', beam=5, whichset='both', batched=False, tparams=None):
     """Same positional arguments as metrics.py:103-107.  Writes <save_dir>/valid_samples.txt and/or test_samples.txt and
-    returns (samples_valid, samples_test) as lists of strings (None for a split that was not requested)."""
+    returns (samples_valid, samples_test) like the reference (:148-152): per split an OrderedDict vidID ->
+    [{'image_id', 'caption'}] (build_sample_pairs); a split that was not requested, or that is empty, stays None / [] ."""
     os.makedirs(save_dir, exist_ok=True)
     samples = {'valid': None, 'test': None}
     for split in ('valid', 'test'):
@@ -56,4 +66,5 @@ def generate_sample_gpu_single_process(model_type, model_archive, options, engin
             samples[split] = seqs2words(ids, engine.word_idict)
             with open(os.path.join(save_dir, '%s_samples.txt' % split), 'w') as f:
                 f.write('\n'.join(samples[split]) + '\n')
-    return samples['valid'], samples['test']
+    ids = {'valid': engine.valid_ids, 'test': engine.test_ids}
+    return tuple(build_sample_pairs(samples[sp], ids[sp]) if samples[sp] else samples[sp] for sp in ('valid', 'test'))

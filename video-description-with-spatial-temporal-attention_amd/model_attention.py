@@ -70,6 +70,7 @@ class Attention(object):
         self.layers = {'ff': ('param_init_fflayer', 'fflayer'),
                        'lstm_cond': ('param_init_lstm_cond', 'lstm_cond_layer')}
         self._options = None
+        self.engine = None                # the reference's train() hangs its data engine here (:1067); pred_probs reads it
         self.device = 0
         self.stream = None
 
@@ -392,9 +393,20 @@ class Attention(object):
 
     # ---------------------------------------------------------------- teacher-forced scoring
     def pred_probs(self, batches, f_log_probs, verbose=False):
-        """Teacher-forced scoring of a split with the contract of model_attention.py:996-1032: `batches` yields
-        prepare_data() 8-tuples, f_log_probs returns -cost per caption.  Returns (mean NLL per caption,
-        perplexity = 2 ** (sum NLL / number of words / ln 2))."""
+        """Teacher-forced scoring of a split with the contract of model_attention.py:996-1032: f_log_probs returns -cost
+        per caption; returns (mean NLL per caption, perplexity = 2 ** (sum NLL / number of words / ln 2)).
+        `batches` is either the reference's `whichset` ('train' / 'valid' / 'test': the caption tags and minibatch index
+        lists of `self.engine`, each minibatch assembled by prepare_data, :1003-1017) or any iterable of prepare_data()
+        8-tuples."""
+        if isinstance(batches, str):
+            try:
+                from . import data_engine
+            except ImportError:
+                import data_engine
+            if batches not in ('train', 'valid', 'test'):
+                raise NotImplementedError()
+            tags, index_lists = getattr(self.engine, batches), getattr(self.engine, 'kf_' + batches)
+            batches = (data_engine.prepare_data(self.engine, [tags[i] for i in index]) for index in index_lists)
         nll, nwords = [], 0.0
         for batch in batches:
             if batch[0] is None:                 # prepare_data found no usable caption (data_engine.py:318)

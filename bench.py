@@ -414,6 +414,26 @@ def main():
     rowsteps = c["B"] * c["t"] * args.steps * world
     value = rowsteps / dt
 
+    # ---- what a scaling run has to prove about itself (train mode): the RCCL communicator really spans `world` ranks,
+    # which overlap mode ran, and what the exchange costs the step -- HIP events on the compute stream around the wait in
+    # stattn_allreduce_grads, three extra steps outside the timed region (reading the events synchronises), max over ranks
+    comm = None
+    if train:
+        exposed = []
+        for _ in range(3):
+            step_fn()
+            exposed.append(dec.comm_stats()["exposed_ms"])
+        st = dec.comm_stats()
+        comm = dict(rccl_ranks=st["ranks"], comm_overlap=st["overlap"], comm_regions=st["regions"],
+                    allreduce_exposed_ms=float(np.mean(exposed)), rccl_library=dec.comm_library_path())
+        if world > 1:
+            tt = torch.tensor([comm["allreduce_exposed_ms"], float(st["ranks"])], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            comm["allreduce_exposed_ms"] = float(tt[0].item())
+            tt = torch.tensor([float(st["ranks"])], dtype=torch.float64)
+            dist.all_reduce(tt, op=dist.ReduceOp.MIN)
+            comm["rccl_ranks"] = int(tt.item())           # the smallest communicator any rank reports
+
     # ---- rooflines, timed live with HIP events on the library's stream (forward pass: that is where the per-class events live)
     dec.set_profiling(True)
     for _ in range(3):
@@ -421,6 +441,16 @@ def main():
     kms = dec.kernel_ms()
     gms = dec.gemm_launch_ms()
     dec.set_profiling(False)
+    bgms, bkms = [], {}
+    if train:                                         # the same for the backward pass: every GEMM launch + the reverse-scan kernels
+        dec.set_profiling(True)
+        for _ in range(3):
+            dec.forward_train()
+            dec.backward(nll_scale=1.0 / (c["B"] * world), alpha_c=0.70602)
+            if world > 1:
+                dec.allreduce_grads()                 # (collective: every rank runs the same three passes)
+        bgms, bkms = dec.bwd_gemm_launch_ms(), dec.bwd_kernel_ms()
+        dec.set_profiling(False)
     B, T, K, D, E, F, V, t = c["B"], c["T"], c["K"], c["D"], c["E"], c["F"], c["V"], c["t"]
     Vp = (V + 127) // 128 * 128
     bf16 = args.precision == "bf16"
@@ -487,6 +517,39 @@ def main():
             "%s %s" % (gname if len(l_) == 1 else ggroup, " + ".join("%dx%dx%d" % x_[1:] for x_ in l_)),
             sum(2.0 * m_ * n_ * k_ for _, m_, n_, k_ in l_), ms)
     step_ms = sum(kms[k_][0] for k_ in ("hproj", "spatial", "lt_gemm", "temporal", "lstm"))
+    bwd_step_ms = None
+    if train and bgms:
+        # LDS-tiled GEMM launches of one backward pass in launch order (csrc/api_backward.cpp): (name, kind, [(M, N, K), ...])
+        Fm = F
+        MTK, MT = BTK, BT
+        bl = [("da=dlogit.Wo^T", "NT", [(R, E, Vp)])]
+        if os.environ.get("STATTN_GEMM_NOGROUP"):
+            bl += [("dWo", "TN", [(E, Vp, R)]), ("dWl1", "TN", [(D, E, R)])] + ([("dWl2", "TN", [(D, E, R)])] if options["ctx2out"] else [])
+            bl += [("dhd", "NT", [(R, D, E)])] + ([("dctx_r", "NT", [(R, D, E)])] if options["ctx2out"] else [])
+        else:
+            bl += [("dWo+dWl1+dWl2", "TN", [(E, Vp, R), (D, E, R)] + ([(D, E, R)] if options["ctx2out"] else [])),
+                   ("dhd+dctx_r", "NT", [(R, D, E)] + ([(R, D, E)] if options["ctx2out"] else []))]
+        bl += [("dWcl=L^T.dPL", "TN", [(D, D, MTK)]), ("dWclt=L^T.dLW", "TN", [(D, D, MTK)]),
+               ("dU=H^T.dpre", "TN", [(D, 4 * D, R)]), ("dWc=ctx^T.dpre", "TN", [(D, 4 * D, R)])]
+        if os.environ.get("STATTN_GEMM_NOGROUP"):
+            bl += [("dWcg", "TN", [(D, D, MT)]), ("dWcm", "TN", [(D, D, MT)])] + [("dWd%d" % i, "TN", [(D, D, R)]) for i in range(4)]
+        else:
+            bl += [("dWcg+dWcm+4xdWd", "TN", [(D, D, MT)] * 2 + [(D, D, R)] * 4)]
+        bl += [("dW=emb^T.dpre", "TN", [(E, 4 * D, R)]), ("dff_state_W", "TN", [(D, D, B)]), ("dff_memory_W", "TN", [(D, D, B)]),
+               ("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
+               ("dMo+=dPM.Wcm^T", "NT", [(MT, D, D)]), ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)]), ("demb=dpre.W^T", "NT", [(R, E, 4 * D)])]
+        for (nm, kind, shapes), ms in zip(bl, bgms):
+            kernels["bwd_gemm_" + nm] = mfma("%s %s %s" % (gname.replace("false,false", kind) if len(shapes) == 1 else ggroup + " " + kind,
+                                                           kind, " + ".join("%dx%dx%d" % x_ for x_ in shapes)),
+                                             sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in shapes), ms)
+        # the reverse-scan chain (one launch of each per decoder step) and the deferred context-gradient kernel
+        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel", B * T * D * (4.0 * 3 * K + 4.0 * 3), bkms["spatial_bwd"][0], "spatial_bwd")
+        kernels["bwd_panel_dctx_dhU"] = mfma("dpre.[Wc^T|U^T] (panel_kernel, K-split)", 2.0 * B * 4 * D * 2 * D, bkms["panel_dctx_dhU"][0], 8.0 * D * D * 4)
+        kernels["bwd_panel_dhW"] = mfma("dsproj.[Wd*]^T (panel_kernel, K-split)", 2.0 * B * 4 * D * D, bkms["panel_dhW"][0], 4.0 * D * D * 4)
+        for nm in ("lstm_bwd", "temporal_bwd", "reduce_T"):
+            kernels["bwd_" + nm] = dict(kernel=nm, bound="latency", ms_per_launch=bkms[nm][0])
+        kernels["bwd_ctxgrad"] = hbm("ctxgrad_kernel", 4.0 * (B * T * K * D * 5.0 + c["t"] * B * T * D * 2.0), bkms["ctxgrad"][0], "ctxgrad")
+        bwd_step_ms = sum(bkms[k_][0] for k_ in ("lstm_bwd", "panel_dctx_dhU", "temporal_bwd", "spatial_bwd", "reduce_T", "panel_dhW"))
     if args.kernel_breakdown and rank == 0:
         print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)
 
@@ -503,6 +566,10 @@ def main():
                roofline=roofline, roofline_hbm=roofline_hbm, kernels=kernels,
                decoder_step_us=step_ms * 1e3,       # sum of the per-step kernel classes (HIP events, includes the record gaps)
                kernel_ms={k: v[0] for k, v in kms.items()})
+    if bwd_step_ms is not None:
+        out["reverse_step_us"] = bwd_step_ms * 1e3      # the six launches of one reverse-scan step
+    if comm:
+        out.update(comm)
     if args.precision == "fp32" and world == 1 and not args.no_split and args.h2d == "none":
         # The same workload with precision='split' (fp32 results, the big GEMMs on the bf16 matrix cores with exactly
         # split operands: csrc/gemm_split.hip), reported beside the headline, never as it.

@@ -233,44 +233,33 @@ int stattn_comm_info(const stattn_handle* h, int* rank, int* nranks);   /* nrank
 int stattn_comm_set_overlap(stattn_handle* h, int enable);
 /* SUM the flat gradient buffer over the ranks (finishes the overlapped reduce); stream-ordered between
  * stattn_backward and stattn_update.  Without a communicator (or with one rank) it only marks the gradient final.
- * stattn_update refuses to run on an un-reduced gradient when the handle belongs to a multi-rank communicator. */
+ * stattn_update refuses to run on an un-reduced gradient when the handle belongs to a multi-rank communicator.
+ * Rule while regions are in flight (overlap on, between stattn_backward and this call): the gradient buffer belongs
+ * to the side stream -- stattn_get_grad and stattn_update return STATTN_ESTATE, a second stattn_backward first waits
+ * for the collectives, and a consumer of stattn_grad_buffer_dev must call this function before touching the buffer. */
 int stattn_allreduce_grads(stattn_handle* h);
+/* What a scaling run needs to prove about itself: ranks of the communicator (0: none), the overlap mode in force,
+ * how many regions the last stattn_backward handed to the side stream, and the milliseconds the compute stream spent
+ * inside the last stattn_allreduce_grads (HIP events on the compute stream: the whole collective without overlap,
+ * only the un-hidden tail with it).  Any pointer may be NULL; exposed_ms synchronises with that all-reduce. */
+int stattn_comm_stats(stattn_handle* h, int* nranks, int* overlap, int* regions, float* exposed_ms);
+/* path of the RCCL shared object that was bound ("" before the first stattn_comm_* call or when none was found):
+ * one already loaded in the process (torch's) is preferred over a second copy from the loader path */
+const char* stattn_comm_library_path(void);
 /* copy rank `root`'s parameters to every rank (replicas must start identical) */
 int stattn_broadcast_params(stattn_handle* h, int root);
 /* SUM `n` host floats over the ranks in place (reported cost, counters); n <= 64 */
 int stattn_allreduce_scalars(stattn_handle* h, float* vals, int n);
 
-/* ---- kernel-level entry points (used by tests/ and bench.py to check and time the
- *      building blocks in isolation; not part of the reference surface) ------------- */
-/* C[M,N] = act(alpha * op(A).op(B) + bias[n] + add[m,n]);  host pointers.
- * transA: A given as [K,M]; transB: B given as [N,K]; act: 0 none, 1 tanh.
- * Runs the LDS-tiled fp32 MFMA kernel (kind=0), the register-streaming skinny
- * kernel (kind=1), the bf16-MFMA kernel (kind=2: no transA, alpha = 1, K % 8 == 0) or the row-panel kernel of the
- * per-step GEMMs (kind=3: M <= 512, N % 16 == 0, K % 16 == 0, no transA, alpha = 1; B is repacked on the device).  Constraints: N % 64 == 0, K % 16 == 0 (kind 1: K % 16 == 0, no trans). */
-int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K,
-                    float alpha, const float* A, const float* B, const float* bias,
-                    const float* add, int act, float* C);
-/* Time `iters` launches of the big GEMM on device-resident random data; returns the
- * average milliseconds per launch measured with HIP events on the handle's stream. */
-int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K,
-                         int iters, float* ms_per_launch);
-/* Debug counters.  which = 0: hipGraph replays (two decoded words each) in the last stattn_beam_search
- * -- 0 means the word sequence was launched eagerly (capture refused, profiling on, STATTN_BEAM_NOGRAPH). */
-long stattn_dbg_counter(const stattn_handle* h, int which);
-/* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
- * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,
- * 11 / 21 / 22 = register-staged workgroup tile (64*TM) x (64*TN), 84 = 256 x 128 with direct global->LDS
- * staging (edge-free shapes only) -- the LDS tile size sweep of BASELINE configs[3]. */
-int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch);
-/* Same for the register-streaming skinny kernel: `nseg` segments of [M,K].[K,N]; variant 0 = product kernel,
- * other values are reserved. */
-int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,
-                           float* ms_per_launch);
+/* ---- measurement hooks (bench.py's per-kernel rooflines) -------------------------------------------- */
 /* Average duration (ms) of the named kernel class over the last stattn_forward_train
  * when profiling is enabled: 0 = spatial attention, 1 = state projections, 2 = local-
  * temporal GEMM, 3 = temporal fuse, 4 = lstm, 5 = prologue scope (sum), 6 = readout scope (sum), 7 = every plain (NN) launch of the
  * LDS-tiled GEMM in the forward pass; 8 + i = the i-th of those launches alone (i < 16, in launch order: ff_local,
- * ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits). */
+ * ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits);
+ * over the last stattn_backward: 24 + i = the i-th LDS-tiled GEMM launch of the pass (i < 24, launch order: da, readout weight
+ * gradients, readout input gradients, ... ), 48 .. 54 = lstm_bwd, panel dctx|dhU, temporal_bwd, spatial_bwd, reduce_T, panel dhW
+ * (one launch per reverse-scan step each) and the deferred ctxgrad kernel. */
 int stattn_set_profiling(stattn_handle* h, int enable);
 int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches);
 

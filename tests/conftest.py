@@ -25,3 +25,23 @@ def pytest_collection_modifyitems(config, items):
     for it in items:
         if "gpu" in it.keywords:
             it.add_marker(skip)
+
+
+# Every GPU parity test of these modules runs twice: on a precision = 0 handle (fp32-input MFMA, the headline
+# configuration) and on a precision = 2 one (the same fp32 GEMMs as three-term bf16 operands on the bf16 matrix cores,
+# DESIGN.md section 12) -- same oracle, same fp32 tolerances.  A handle created with an explicit `precision=` keeps it.
+BOTH_PRECISIONS = {"test_gpu_parity", "test_gpu_backward", "test_gpu_edge_shapes", "test_data_and_metrics"}
+
+
+@pytest.fixture(autouse=True)
+def stattn_precision(request, monkeypatch):
+    p = getattr(request, "param", None)
+    if p is not None:
+        monkeypatch.setenv("STATTN_PRECISION", p)
+    return p
+
+
+def pytest_generate_tests(metafunc):
+    mod = metafunc.module.__name__.rsplit(".", 1)[-1]
+    if mod in BOTH_PRECISIONS and metafunc.definition.get_closest_marker("gpu") and "STATTN_PRECISION" not in os.environ:
+        metafunc.parametrize("stattn_precision", ["fp32", "split"], indirect=True)

@@ -78,17 +78,24 @@ _SIGNATURES = {
     "stattn_allreduce_grads": (C.c_int, [_H]),
     "stattn_broadcast_params": (C.c_int, [_H, C.c_int]),
     "stattn_allreduce_scalars": (C.c_int, [_H, _F, C.c_int]),
+    "stattn_comm_stats": (C.c_int, [_H, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int), _F]),
+    "stattn_comm_library_path": (C.c_char_p, []),
+    "stattn_set_profiling": (C.c_int, [_H, C.c_int]),
+    "stattn_get_kernel_ms": (C.c_int, [_H, C.c_int, _F, C.POINTER(C.c_int)]),
+}
+
+# csrc/stattn_dbg.h: development entry points (kernels in isolation for tests/ and tools/), not the drop-in surface
+_DBG_SIGNATURES = {
     "stattn_dbg_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float,
                                   _F, _F, _F, _F, C.c_int, _F]),
     "stattn_dbg_time_gemm": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_counter": (C.c_long, [_H, C.c_int]),
     "stattn_dbg_time_gemm_bf16": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_time_skinny": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
-    "stattn_set_profiling": (C.c_int, [_H, C.c_int]),
-    "stattn_get_kernel_ms": (C.c_int, [_H, C.c_int, _F, C.POINTER(C.c_int)]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+DEBUG_SYMBOLS = tuple(_DBG_SIGNATURES)
 
 
 def load_library():
@@ -101,7 +108,7 @@ def load_library():
         raise NativeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C %s/csrc`).  stattn has no CPU fallback." % (path, _HERE))
     lib = C.CDLL(path)
-    for name, (res, args) in _SIGNATURES.items():
+    for name, (res, args) in list(_SIGNATURES.items()) + list(_DBG_SIGNATURES.items()):
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
         fn.restype = res
         fn.argtypes = args
@@ -512,6 +519,17 @@ class Decoder(object):
         self._chk(self._lib.stattn_comm_info(self._h, C.byref(r), C.byref(n)))
         return r.value, n.value
 
+    def comm_stats(self):
+        """{'ranks', 'overlap', 'regions', 'exposed_ms'} of the last backward / all-reduce pair: ranks of the RCCL
+        communicator (0: none), overlap mode, regions of the gradient buffer that were summed on the side stream while
+        backward still ran, and the time the compute stream spent inside stattn_allreduce_grads (HIP events)."""
+        n = C.c_int(); ov = C.c_int(); rg = C.c_int(); ms = C.c_float()
+        self._chk(self._lib.stattn_comm_stats(self._h, C.byref(n), C.byref(ov), C.byref(rg), C.byref(ms)))
+        return dict(ranks=n.value, overlap=ov.value, regions=rg.value, exposed_ms=float(ms.value))
+
+    def comm_library_path(self):
+        return self._lib.stattn_comm_library_path().decode()
+
     def comm_set_overlap(self, mode):
         """0 = one all-reduce after backward, 1 = regions reduced while backward runs (default), 2 = same, forced
         even in a one-rank communicator (test hook)."""
@@ -583,4 +601,25 @@ class Decoder(object):
             self._chk(self._lib.stattn_get_kernel_ms(self._h, len(KERNEL_CLASSES) + i, C.byref(ms), C.byref(n)))
             if n.value:
                 out.append(ms.value)
+        return out
+
+    BWD_KERNELS = ("lstm_bwd", "panel_dctx_dhU", "temporal_bwd", "spatial_bwd", "reduce_T", "panel_dhW", "ctxgrad")
+
+    def bwd_gemm_launch_ms(self):
+        """Average duration of every LDS-tiled GEMM launch of a backward pass (profiling on), in launch order."""
+        out = []
+        for i in range(24):
+            ms = C.c_float(); n = C.c_int()
+            self._chk(self._lib.stattn_get_kernel_ms(self._h, len(KERNEL_CLASSES) + 16 + i, C.byref(ms), C.byref(n)))
+            if n.value:
+                out.append(ms.value)
+        return out
+
+    def bwd_kernel_ms(self):
+        """(avg ms, launches) of the kernels of a reverse-scan step and of the deferred context-gradient kernel."""
+        out = OrderedDict()
+        for i, name in enumerate(self.BWD_KERNELS):
+            ms = C.c_float(); n = C.c_int()
+            self._chk(self._lib.stattn_get_kernel_ms(self._h, len(KERNEL_CLASSES) + 16 + 24 + i, C.byref(ms), C.byref(n)))
+            out[name] = (ms.value, n.value)
         return out

@@ -1,0 +1,445 @@
+// C ABI of libstattn.so, part 4: hand-written BPTT of the training loss, loss value, clip + Adadelta
+// (model_attention.py:1129-1147, 1193-1203; common.py:178-195).
+#include "steps.h"
+
+extern "C" {
+
+// ---- backward pass, optimizer (model_attention.py:1129-1147, 1193-1203; common.py:178-195) ---------
+int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_fwd) return fail(h, STATTN_ESTATE, "backward: no forward pass has run on the staged batch");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int t = h->t, m = h->m, T = h->T, K = h->K, D = h->D, E = h->E, V = h->V, Vp = h->Vp, Fl = h->Fl, Fm = h->Fm;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    const size_t R = (size_t)t * m, MT = (size_t)m * T, MTK = MT * K;
+    auto G_ = [&](const char* n) { return h->d_grads + h->params[h->pindex[n]].off; };
+
+    // forward tensors
+    int64_t* dx = (int64_t*)h->bufs[bcur(h, "x")].p;
+    float *dmask = findbuf(h, bcur(h, "mask").c_str()), *Gc = findbuf(h, bcur(h, "G").c_str()), *rawl = findbuf(h, bcur(h, "rawl").c_str()), *rawm = findbuf(h, bcur(h, "rawm").c_str()),
+          *L = findbuf(h, "L"), *Mo = findbuf(h, "Mo"), *PG = findbuf(h, "PG"), *PL = findbuf(h, "PL"), *PM = findbuf(h, "PM"),
+          *LW = findbuf(h, "LW"), *mean = findbuf(h, "mean"), *emb = findbuf(h, "emb"), *hs = findbuf(h, "hs"),
+          *cs = findbuf(h, "cs"), *hd = findbuf(h, "hd"), *ctx = findbuf(h, "ctx"), *csum = findbuf(h, "csum"),
+          *sel = findbuf(h, "sel"), *al = findbuf(h, "alphal"), *ag = findbuf(h, "alphag"), *am = findbuf(h, "alpham"),
+          *alt = findbuf(h, "alphalt"), *CL = findbuf(h, "CL"), *gates = findbuf(h, "gates"), *sproj = findbuf(h, "sproj"),
+          *a1 = findbuf(h, "a1"), *tz = findbuf(h, "tz"), *lg = findbuf(h, "logits"), *pr = findbuf(h, "probs"),
+          *dp = findbuf(h, "dp"), *d1 = findbuf(h, "d1"), *d2 = findbuf(h, "d2");
+
+    // backward workspaces
+    float *da, *dhd, *dctx_r, *demb, *rg, *rm, *rlt, *rl, *sqg, *sqm, *sqlt, *sql, *UT, *WcT, *WdT, *dpre, *dsproj, *dcsum,
+          *dselpre, *deg, *dem, *delt, *del, *dplt, *dslp, *dc, *dhp0, *dhp1, *dctxP, *dhUP, *dhWP, *dPL, *dL, *dLW, *dPG,
+          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg, *da_raw, *dsgp, *dsmp;
+    const int KZ1 = 8, KZ2 = 16;
+    const size_t WS = (size_t)16 << 20;
+    CHK(getbuf_t(h, "b_da", R * E, &da));
+    CHK(getbuf_t(h, "b_dhd", R * D, &dhd));
+    CHK(getbuf_t(h, "b_dctx_r", R * D, &dctx_r));
+    CHK(getbuf_t(h, "b_demb", R * E, &demb));
+    CHK(getbuf_t(h, "b_rg", MT, &rg)); CHK(getbuf_t(h, "b_rm", MT, &rm)); CHK(getbuf_t(h, "b_rlt", MT, &rlt));
+    CHK(getbuf_t(h, "b_rl", MTK, &rl));
+    CHK(getbuf_t(h, "b_sqg", MT, &sqg)); CHK(getbuf_t(h, "b_sqm", MT, &sqm)); CHK(getbuf_t(h, "b_sqlt", MT, &sqlt));
+    CHK(getbuf_t(h, "b_sql", MTK, &sql));
+    CHK(getbuf_t(h, "b_UT", (size_t)4 * D * D, &UT));
+    CHK(getbuf_t(h, "b_WcT", (size_t)4 * D * D, &WcT));
+    CHK(getbuf_t(h, "b_WdT", (size_t)4 * D * D, &WdT));
+    CHK(getbuf_t(h, "b_dpre", R * 4 * D, &dpre));
+    CHK(getbuf_t(h, "b_dsproj", R * 4 * D, &dsproj));
+    CHK(getbuf_t(h, "b_dcsum", R * D, &dcsum));
+    CHK(getbuf_t(h, "b_dselpre", R, &dselpre));
+    CHK(getbuf_t(h, "b_deg", R * T, &deg)); CHK(getbuf_t(h, "b_dem", R * T, &dem)); CHK(getbuf_t(h, "b_delt", R * T, &delt));
+    CHK(getbuf_t(h, "b_del", R * T * K, &del));
+    CHK(getbuf_t(h, "b_dplt", R * T * D, &dplt));
+    CHK(getbuf_t(h, "b_dslp", MT * D, &dslp));
+    CHK(getbuf_t(h, "b_dsgp", MT * D, &dsgp));
+    CHK(getbuf_t(h, "b_dsmp", MT * D, &dsmp));
+    CHK(getbuf_t(h, "b_da_raw", 3 * MT, &da_raw));
+    CHK(getbuf_t(h, "b_dc", (size_t)m * D, &dc));
+    CHK(getbuf_t(h, "b_dhp0", (size_t)m * D, &dhp0)); CHK(getbuf_t(h, "b_dhp1", (size_t)m * D, &dhp1));
+    CHK(getbuf_t(h, "b_dctxP", (size_t)KZ1 * m * D, &dctxP));
+    CHK(getbuf_t(h, "b_dhUP", (size_t)KZ1 * m * D, &dhUP));
+    CHK(getbuf_t(h, "b_dhWP", (size_t)KZ2 * m * D, &dhWP));
+    CHK(getbuf_t(h, "b_dPL", MTK * D, &dPL)); CHK(getbuf_t(h, "b_dL", MTK * D, &dL)); CHK(getbuf_t(h, "b_dLW", MTK * D, &dLW));
+    CHK(getbuf_t(h, "b_dPG", MT * D, &dPG)); CHK(getbuf_t(h, "b_dPM", MT * D, &dPM)); CHK(getbuf_t(h, "b_dMo", MT * D, &dMo));
+    CHK(getbuf_t(h, "b_pUl", MT * D, &pUl)); CHK(getbuf_t(h, "b_pUlt", MT * D, &pUlt));
+    CHK(getbuf_t(h, "b_pUg", MT * D, &pUg)); CHK(getbuf_t(h, "b_pUm", MT * D, &pUm));
+    CHK(getbuf_t(h, "b_cpart", (size_t)256 * (size_t)(Vp > 4 * D ? Vp : 4 * D), &cpart));
+    CHK(getbuf_t(h, "b_ws", WS, &ws));
+    CHK(getbuf_t(h, "b_dph0", (size_t)m * D, &dph0)); CHK(getbuf_t(h, "b_dpc0", (size_t)m * D, &dpc0));
+    CHK(getbuf_t(h, "b_lossreg", 4, &lossreg));
+
+    auto gemm = [&](bool tA, bool tB, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kd,
+                    int accumulate, const float* add = nullptr, int ldadd = 0) -> hipError_t {
+        GemmArgs g;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
+        g.A = A; g.lda = lda; g.B = B; g.ldb = ldb; g.C = C; g.ldc = ldc; g.M = M; g.N = N; g.K = Kd;
+        g.accumulate = accumulate; g.add = add; g.ldadd = ldadd;
+        if (!add) { g.ws = ws; g.ws_floats = WS; }
+        const int seq = h->bwd_seq++;
+        Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
+        return launch_gemm(s, g, tA, tB);
+    };
+    auto gemm_grp = [&](const GemmArgs* gs, int n, bool tA, bool tB) -> hipError_t {
+        const int seq = h->bwd_seq++;
+        Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
+        return launch_gemm_group(s, gs, n, tA, tB);
+    };
+    h->bwd_seq = 0;
+
+    // bias gradients (column sums) are collected and run as ONE batched launch pair at the end of the pass: their
+    // sources stay untouched until then
+    ColsumBatch csb{};
+    float* cspart;
+    CHK(getbuf_t(h, "b_cspart", COLSUM_BATCH_PART_FLOATS, &cspart));
+#define CSADD(X, LD, ROWS, N, DST, ACC, RW)                                                                      \
+    do { if (!colsum_batch_add(csb, X, LD, ROWS, N, DST, ACC, RW)) return fail(h, STATTN_EINVAL, "backward: colsum batch overflow"); } while (0)
+
+    // A region [first, before) of the flat gradient buffer is final: run its collected bias sums, then (data
+    // parallel with overlap) start summing it over the ranks on the side stream -- comm.cpp
+    auto region_done = [&](const char* first, const char* before) -> int {
+        if (csb.n) { HIPCHK(h, launch_colsum_batch(s, csb, cspart)); csb = ColsumBatch{}; }
+        const size_t lo = h->params[h->pindex[first]].off;
+        const size_t hi = before ? h->params[h->pindex[before]].off : h->nflat;
+        return comm_reduce_range(h, lo, hi - lo);
+    };
+    CHK(comm_backward_begins(h));
+    // every gradient array is written in full by its GEMM / column sum; only Wemb is written row-wise (the rows of the
+    // words of this batch), so only that region is cleared (the padding between arrays was zeroed at creation)
+    HIPCHK(h, hipMemsetAsync(G_("Wemb"), 0, h->params[h->pindex["ff_state_W"]].off * sizeof(float), s));
+
+    // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout
+    // only as a = tanh(z) * d2.  The backward pass is the fp32 one, evaluated at those stored activations: they are widened
+    // (exactly) into fp32 buffers, tanh(z) is recovered from a and the dropout multiplier, everything else was fp32 anyway.
+    if (h->opt.precision == 1) {
+        float *L32, *PL32, *LW32;
+        CHK(getbuf_t(h, "b_L32", MTK * D, &L32)); CHK(getbuf_t(h, "b_PL32", MTK * D, &PL32)); CHK(getbuf_t(h, "b_LW32", MTK * D, &LW32));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(L), L32, MTK * D));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(PL), PL32, MTK * D));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(LW), LW32, MTK * D));
+        L = L32; PL = PL32; LW = LW32;
+        HIPCHK(h, launch_unmul(s, a1, d2, tz, R * E));
+    }
+
+    // lt_mode 0 ran CL.Wclt per step in the forward pass (the reference's summation order, :416).  Its derivative is the
+    // same function as lt_mode 1's: <dplt.Wclt^T, L_k> = <dplt, L_k.Wclt> and sum_s CL_s^T.dplt_s = L^T.(sum_s alpha dplt_s),
+    // so the backward pass uses the hoisted form for both: LW = L.Wclt is formed here once (27.9 GFLOP at C2).
+    if (h->opt.lt_mode == 0) {
+        CHK(getbuf_t(h, "LW", MTK * D, &LW));
+        GemmArgs g;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
+        g.A = L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = LW; g.ldc = D; g.M = (int)MTK; g.N = D; g.K = D;
+        HIPCHK(h, launch_gemm(s, g, false, false));
+    }
+
+    // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
+    const bool reg = alpha_c > 0.f;
+    if (reg) {
+        HIPCHK(h, launch_alpha_reg(s, ag, rg, sqg, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, am, rm, sqm, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, alt, rlt, sqlt, t, MT, alpha_c / T));
+        HIPCHK(h, launch_alpha_reg(s, al, rl, sql, t, MTK, alpha_c / (T * K)));
+        MultiSumArgs ms{};
+        const float* srcs[4] = {sqg, sqm, sqlt, sql};
+        for (int i = 0; i < 4; ++i) {
+            ms.src[i] = srcs[i]; ms.n[i] = i < 3 ? MT : MTK; ms.dst[i] = lossreg + i;
+            ms.scale[i] = i < 3 ? alpha_c / T : alpha_c / (T * K);
+        }
+        ms.count = 4;
+        HIPCHK(h, launch_multi_sum(s, ms, cpart));
+    } else {
+        HIPCHK(h, hipMemsetAsync(lossreg, 0, 4 * sizeof(float), s));
+    }
+
+    // ---- softmax / NLL and readout (:687-715), all (t*m) rows at once
+    HIPCHK(h, launch_dlogit(s, pr, Vp, dx, dmask, nll_scale, lg, Vp, (int)R, V, Vp));           // dlogit overwrites logits
+    CSADD(lg, Vp, (int)R, Vp, G_("ff_logit_b"), 0, nullptr);
+    HIPCHK(h, gemm(false, true, lg, Vp, w.Wo, Vp, da, E, (int)R, E, Vp, 0));                     // da = dlogit Wo^T
+    HIPCHK(h, launch_tanh_bwd(s, da, tz, d2, da, R * E));                                        // dz (in place)
+    float* dz = da;
+    CSADD(dz, E, (int)R, E, G_("ff_logit_lstm_b"), 0, nullptr);
+    if (h->opt.ctx2out) CSADD(dz, E, (int)R, E, G_("ff_logit_ctxglm_b"), 0, nullptr);
+    {   // the three readout weight gradients (K = t*m rows) in one grouped launch: dWo = a^T dlogit (1504 tiles) carries
+        // dWl1 = hd^T dz and dWl2 = ctx^T dz (128 tiles each, a split-K pass each on their own); likewise the two
+        // input gradients dhd = dz Wl1^T, dctx = dz Wl2^T
+        static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
+        GemmArgs gw[3], gi[2];
+        int nw = 0, ni = 0;
+        auto set = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int K_) {
+            gemm_defaults(q); q.split = h->opt.precision != 0;
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = K_;
+        };
+        set(gw[nw++], a1, E, lg, Vp, G_("ff_logit_W"), Vp, E, Vp, (int)R);
+        set(gw[nw++], hd, D, dz, E, G_("ff_logit_lstm_W"), E, D, E, (int)R);
+        set(gi[ni++], dz, E, w.Wl1, E, dhd, D, (int)R, D, E);
+        if (h->opt.ctx2out) {
+            set(gw[nw++], ctx, D, dz, E, G_("ff_logit_ctxglm_W"), E, D, E, (int)R);
+            set(gi[ni++], dz, E, w.Wl2, E, dctx_r, D, (int)R, D, E);
+        }
+        if (nogroup) {
+            for (int i = 0; i < nw; ++i) HIPCHK(h, gemm(true, false, gw[i].A, gw[i].lda, gw[i].B, gw[i].ldb, gw[i].C, gw[i].ldc, gw[i].M, gw[i].N, gw[i].K, 0));
+            for (int i = 0; i < ni; ++i) HIPCHK(h, gemm(false, true, gi[i].A, gi[i].lda, gi[i].B, gi[i].ldb, gi[i].C, gi[i].ldc, gi[i].M, gi[i].N, gi[i].K, 0));
+        } else {
+            HIPCHK(h, gemm_grp(gw, nw, true, false));
+            HIPCHK(h, gemm_grp(gi, ni, false, true));
+        }
+    }
+    CHK(region_done("ff_logit_lstm_W", nullptr));     // final before the reverse scan even starts
+
+    // ---- transposed recurrent weights of the reverse scan: packed panels (row-panel kernels) or plain transposed
+    // copies (skinny kernels)
+    BwdPanels bp{};
+    const bool panels = use_panels(h, m);
+    int kz1 = KZ1, kz2 = KZ2;
+    float *dpre_pk = nullptr, *dsproj_pk = nullptr;
+    if (panels) {
+        CHK(pack_bwd_panels(h, &bp));
+        CHK(getbuf_t(h, "pk_dpre", packed_rows_floats(m, 4 * D), &dpre_pk));
+        CHK(getbuf_t(h, "pk_dsproj", packed_rows_floats(m, 4 * D), &dsproj_pk));
+        if (m % 16) {     // rows past m of the last m-tile are read (and ignored): keep them finite
+            HIPCHK(h, hipMemsetAsync(dpre_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
+            HIPCHK(h, hipMemsetAsync(dsproj_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
+        }
+        // K split so that the launch fills the chip: 2 D / 16 column tiles (dctx | dhU), D / 16 (dhW)
+        kz1 = 256 / (2 * D / 16); kz1 = kz1 < 1 ? 1 : (kz1 > KZ1 ? KZ1 : kz1);
+        kz2 = 256 / (D / 16); kz2 = kz2 < 1 ? 1 : (kz2 > KZ2 ? KZ2 : kz2);
+    } else {
+        HIPCHK(h, launch_transpose(s, w.U, 4 * D, UT, D, D, 4 * D));
+        HIPCHK(h, launch_transpose(s, w.Wc, 4 * D, WcT, D, D, 4 * D));
+        const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
+        for (int i = 0; i < 4; ++i) HIPCHK(h, launch_transpose(s, Wd[i], D, WdT + (size_t)i * D * D, D, D, D));
+    }
+
+    // ---- reverse scan
+    float* dhp_in = dhp0; float* dhp_out = dhp1;
+    for (int st = t - 1; st >= 0; --st) {
+        const size_t r0 = (size_t)st * m;
+        const bool last = (st == t - 1);
+        {
+            LstmBwdArgs a{};
+            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = kz1; a.dhW = dhWP; a.nW = kz2;
+            a.dselpre = dselpre + (r0 + m); a.W_sel = h->opt.selector ? w.W_sel : nullptr;
+            a.dhd = dhd + r0 * D; a.d1 = d1 + r0 * D; a.gates = gates + r0 * 4 * D;
+            a.c_prev = cs + r0 * D; a.c_new = cs + (r0 + m) * D; a.mask = dmask + r0; a.dp = dp + r0 * 3 * D;
+            a.dc = dc; a.dpre = dpre + r0 * 4 * D; a.dpre_pk = dpre_pk; a.dh_pass_out = dhp_out; a.M = m; a.D = D; a.last = last ? 1 : 0;
+            Prof pr(h, KC_KB0 + KB_LSTM);
+            HIPCHK(h, launch_lstm_bwd(s, a));
+        }
+        if (panels) {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
+            PnArgs a{};
+            a.M = m; a.nseg = 2; a.kz = kz1; a.part_stride = (size_t)m * D;
+            for (int i = 0; i < 2; ++i) {
+                PnSeg& sg = a.seg[i];
+                pn_seg_defaults(sg);
+                sg.npairs = 1; sg.p[0] = PnPair{dpre_pk, 4 * D, i == 0 ? bp.WcT : bp.UT, 4 * D, 1};
+                sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
+            }
+            Prof pr(h, KC_KB0 + KB_PANEL1);
+            HIPCHK(h, launch_panel(s, a));
+        } else {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
+            SkArgs a{};
+            a.M = m; a.nseg = 2; a.kz = KZ1; a.part_stride = (size_t)m * D;
+            for (int i = 0; i < 2; ++i) {
+                SkSeg& sg = a.seg[i];
+                skinny_seg_defaults(sg);
+                sg.npairs = 1; sg.p[0] = SkPair{dpre + r0 * 4 * D, i == 0 ? WcT : UT, 4 * D, D, 4 * D, 0};
+                sg.C = i == 0 ? dctxP : dhUP; sg.ldc = D; sg.N = D;
+            }
+            HIPCHK(h, launch_skinny(s, a));
+        }
+        {
+            TemporalBwdArgs a{};
+            a.dctxP = dctxP; a.nP = kz1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
+            a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.CL = CL + r0 * T * D;
+            a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
+            a.has_sel = h->opt.selector ? 1 : 0;
+            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0; a.da_raw = da_raw; a.M = m; a.T = T; a.D = D;
+            Prof pr(h, KC_KB0 + KB_TBWD);
+            HIPCHK(h, launch_temporal_bwd(s, a));
+        }
+        {
+            SpatialBwdArgs a{};
+            a.PL = PL; a.L = L; a.LW = LW; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
+            a.dcsum = dcsum + r0 * D; a.alphal = al + r0 * T * K;
+            a.PG = PG; a.PM = PM; a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T; a.da_raw = da_raw;
+            a.Ug = w.Ug; a.Um = w.Um;
+            a.deg = deg + r0 * T; a.dem = dem + r0 * T; a.delt = delt + r0 * T; a.dsgp = dsgp; a.dsmp = dsmp;
+            a.rl = reg ? rl : nullptr; a.Ul = w.Ul; a.Ult = w.Ult; a.blt = w.blt;
+            a.dplt = dplt + r0 * T * D; a.del = del + r0 * T * K; a.dslp = dslp; a.M = m; a.T = T; a.K = K; a.D = D;
+            Prof pr(h, KC_KB0 + KB_SPATIAL);
+            HIPCHK(h, launch_spatial_bwd(s, a));
+        }
+        {
+            Prof pr(h, KC_KB0 + KB_REDUCE);
+            HIPCHK(h, launch_reduce_T(s, dslp, dsgp, dsmp, dplt + r0 * T * D, dsproj + r0 * 4 * D, 4 * D, m, T, D, dsproj_pk));
+        }
+        if (panels) {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
+            PnArgs a{};
+            a.M = m; a.nseg = 1; a.kz = kz2; a.part_stride = (size_t)m * D;
+            PnSeg& sg = a.seg[0];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{dsproj_pk, 4 * D, bp.WdT, 4 * D, 1};
+            sg.C = dhWP; sg.ldc = D; sg.N = D;
+            Prof pr(h, KC_KB0 + KB_PANEL2);
+            HIPCHK(h, launch_panel(s, a));
+        } else {   // dhW = [dsl|dsg|dsm|dslt] . [Wdl|Wdg|Wdm|Wdlt]^T
+            SkArgs a{};
+            a.M = m; a.nseg = 1; a.kz = KZ2; a.part_stride = (size_t)m * D;
+            SkSeg& sg = a.seg[0];
+            skinny_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = SkPair{dsproj + r0 * 4 * D, WdT, 4 * D, D, 4 * D, 0};
+            sg.C = dhWP; sg.ldc = D; sg.N = D;
+            HIPCHK(h, launch_skinny(s, a));
+        }
+        float* tmp = dhp_in; dhp_in = dhp_out; dhp_out = tmp;
+    }
+    // ---- deferred gradients.  Ordered by region of the flat buffer (= dict order) so that a data-parallel rank can
+    // hand each region to the overlapped all-reduce as soon as it is final: decoder_* first (its 76 MB travel while
+    // the F->D projection gradients -- the largest GEMM of the pass -- are computed), then ff_*, then Wemb.
+    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, kz1, dhWP, kz2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
+                                dph0, dpc0, m, D));
+    {
+        CtxGradArgs a{};
+        a.PL = PL; a.LW = LW; a.PG = PG; a.PM = PM; a.sproj = sproj; a.dcsum = dcsum; a.dplt = dplt;
+        a.alphal = al; a.del = del; a.alt = alt; a.delt = delt; a.am = am; a.deg = deg; a.dem = dem;
+        a.Ul = w.Ul; a.Ult = w.Ult; a.Ug = w.Ug; a.Um = w.Um; a.blt = w.blt;
+        a.dPL = dPL; a.dL = dL; a.dLW = dLW; a.dPG = dPG; a.dPM = dPM; a.dMo = dMo;
+        a.pUl = pUl; a.pUlt = pUlt; a.pUg = pUg; a.pUm = pUm; a.S = t; a.M = m; a.T = T; a.K = K; a.D = D;
+        Prof pr(h, KC_KB0 + KB_CTXGRAD);
+        HIPCHK(h, launch_ctxgrad(s, a));
+    }
+    // -- region decoder_*
+    CSADD(pUl, D, (int)MT, D, G_("decoder_Ul_att"), 0, nullptr);
+    CSADD(pUlt, D, (int)MT, D, G_("decoder_Ult_att"), 0, nullptr);
+    CSADD(pUg, D, (int)MT, D, G_("decoder_Ug_att"), 0, nullptr);
+    CSADD(pUm, D, (int)MT, D, G_("decoder_Um_att"), 0, nullptr);
+    {   // scalar biases of the four attention scorers (+ the selector bias): full sums, one launch
+        MultiSumArgs ms{};
+        const float* srcs[5] = {del, delt, deg, dem, dselpre};
+        const size_t ns[5] = {R * T * K, R * T, R * T, R * T, R};
+        const char* names[5] = {"decoder_cl_att", "decoder_clt_att", "decoder_cg_att", "decoder_cm_att", "decoder_b_sel"};
+        ms.count = h->opt.selector ? 5 : 4;
+        for (int i = 0; i < ms.count; ++i) { ms.src[i] = srcs[i]; ms.n[i] = ns[i]; ms.dst[i] = G_(names[i]); ms.scale[i] = 1.f; }
+        HIPCHK(h, launch_multi_sum(s, ms, cpart));
+    }
+    CSADD(dsproj + 3 * (size_t)D, 4 * D, (int)R, D, G_("decoder_blt_att"), 0, nullptr);   // sum_{s,b,t} dplt = sum_{s,b} dslt (reduce_T already summed over t)
+    if (h->opt.selector) {
+        CSADD(hs, D, (int)R, D, G_("decoder_W_sel"), 0, dselpre);   // h_prev^T . dselpre
+    }
+    // attention pre-projections (:322-326) and the hoisted L.Wclt
+    HIPCHK(h, gemm(true, false, L, D, dPL, D, G_("decoder_Wcl_att"), D, D, D, (int)MTK, 0));
+    CSADD(dPL, D, (int)MTK, D, G_("decoder_bl_att"), 0, nullptr);
+    HIPCHK(h, gemm(true, false, L, D, dLW, D, G_("decoder_Wclt_att"), D, D, D, (int)MTK, 0));
+    CSADD(dPG, D, (int)MT, D, G_("decoder_bg_att"), 0, nullptr);
+    CSADD(dPM, D, (int)MT, D, G_("decoder_bm_att"), 0, nullptr);
+    // recurrent weights: one batched TN GEMM over all (t*m) rows each
+    HIPCHK(h, gemm(true, false, hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R, 0));
+    HIPCHK(h, gemm(true, false, ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R, 0));
+    {   // the six D x D weight gradients with a short K (frames or steps x rows): 256 tiles each -- alone they needed a
+        // split-K pass each; as ONE grouped launch of 1536 tiles they fill the chip directly
+        GemmArgs gq[6];
+        auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int Kd) {
+            gemm_defaults(q); q.split = h->opt.precision != 0;
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = D; q.M = D; q.N = D; q.K = Kd;
+        };
+        tn(gq[0], Gc, D, dPG, D, G_("decoder_Wcg_att"), (int)MT);
+        tn(gq[1], Mo, D, dPM, D, G_("decoder_Wcm_att"), (int)MT);
+        const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
+        for (int i = 0; i < 4; ++i) tn(gq[2 + i], hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), (int)R);
+        static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
+        if (nogroup) { for (const GemmArgs& q : gq) HIPCHK(h, gemm(true, false, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 0)); }
+        else HIPCHK(h, gemm_grp(gq, 6, true, false));
+    }
+    HIPCHK(h, gemm(true, false, emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R, 0));
+    CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
+    CHK(region_done("decoder_W", "ff_logit_lstm_W"));
+    // -- region ff_*: initial state (:657-660), then back through tanh(ff_local), tanh(ff_motion) (:664-667)
+    HIPCHK(h, gemm(true, false, mean, D, dph0, D, G_("ff_state_W"), D, D, D, m, 0));
+    CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
+    HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
+    CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
+    HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
+    HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+    HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
+    HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
+    CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);
+    HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
+    HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
+    HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
+    CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
+    CHK(region_done("ff_state_W", "decoder_W"));
+    // -- region Wemb: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
+    // (dz is copied in first and the product accumulated onto it: without an `add` operand the 1920 x 512 x 4096 problem
+    // -- 240 tiles of 64 x 64 -- may be cut along K, which fills the chip)
+    if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, h->opt.prev2out ? 1 : 0));
+    {
+        const EmbedPlan pl = device_embed_plan(h, h->cur_set);
+        float* epart;
+        CHK(getbuf_t(h, "b_embpart", (size_t)(pl.npieces > 0 ? pl.npieces : 1) * E, &epart));
+        HIPCHK(h, launch_embed_bwd(s, pl, demb, G_("Wemb"), epart, E, m));
+    }
+    CHK(region_done("Wemb", "ff_state_W"));
+#undef CSADD
+    h->have_bwd = true;
+    return STATTN_OK;
+}
+
+int stattn_get_loss(stattn_handle* h, float nll_scale, float decay_c, float* loss) {
+    if (!h || !loss) return STATTN_EINVAL;
+    if (!h->have_bwd) return fail(h, STATTN_ESTATE, "get_loss: call stattn_backward first (it evaluates the regulariser)");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    std::vector<float> cost(h->m);
+    float regv4[4] = {0.f, 0.f, 0.f, 0.f}, p2 = 0.f;
+    float *part, *sc;
+    CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
+    CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
+    if (decay_c > 0.f) {   // decay_c * sum ||theta||^2 (:1130-1136); two_decay = 0 leaves the buffer unchanged
+        HIPCHK(h, launch_decay_sumsq(s, h->d_params, h->d_params, 0.f, h->nflat, part, 1024));
+        HIPCHK(h, launch_sum_all(s, part, 1024, sc, 1.f, 0));
+        HIPCHK(h, hipMemcpyAsync(&p2, sc, sizeof(float), hipMemcpyDeviceToHost, s));
+    }
+    HIPCHK(h, hipMemcpyAsync(cost.data(), findbuf(h, "cost"), (size_t)h->m * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(regv4, findbuf(h, "b_lossreg"), 4 * sizeof(float), hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    double tot = 0.0;
+    for (float c : cost) tot += c;
+    const double regv = (double)regv4[0] + regv4[1] + regv4[2] + regv4[3];
+    *loss = (float)(nll_scale * tot + regv + (double)decay_c * p2);
+    return STATTN_OK;
+}
+
+int stattn_update(stattn_handle* h, float decay_c, float clip_c) {
+    if (!h) return STATTN_EINVAL;
+    if (!h->have_bwd) return fail(h, STATTN_ESTATE, "update: no fresh gradient (call stattn_backward; one update per backward)");
+    if ((h->comm && h->comm_nranks > 1 && !h->grads_reduced) || comm_pending(h))
+        return fail(h, STATTN_ESTATE, "update: this rank belongs to a %d-rank communicator: call stattn_allreduce_grads first", h->comm_nranks);
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    if (!h->d_rg2) {
+        HIPCHK(h, hipMalloc((void**)&h->d_rg2, h->nflat * sizeof(float)));
+        HIPCHK(h, hipMalloc((void**)&h->d_ru2, h->nflat * sizeof(float)));
+        HIPCHK(h, hipMemsetAsync(h->d_rg2, 0, h->nflat * sizeof(float), s));
+        HIPCHK(h, hipMemsetAsync(h->d_ru2, 0, h->nflat * sizeof(float), s));
+    }
+    float *part, *sc;
+    CHK(getbuf_t(h, "u_part", (size_t)1024, &part));
+    CHK(getbuf_t(h, "u_scalar", (size_t)4, &sc));
+    // || g + 2 decay_c theta ||^2 (:1130-1136) in a fixed two-stage order; decay + clip + Adadelta in one pass
+    HIPCHK(h, launch_decay_sumsq(s, h->d_grads, h->d_params, 2.f * decay_c, h->nflat, part, 1024));
+    HIPCHK(h, launch_sum_all(s, part, 1024, sc, 1.f, 0));
+    HIPCHK(h, launch_adadelta(s, h->d_params, h->d_grads, h->d_rg2, h->d_ru2, h->nflat, sc, clip_c, 2.f * decay_c));
+    h->ck_proj = false; h->have_fwd = false; h->have_bwd = false;
+    return STATTN_OK;
+}
+
+int stattn_reset_optimizer(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    if (h->d_rg2) {
+        HIPCHK(h, hipMemsetAsync(h->d_rg2, 0, h->nflat * sizeof(float), h->stream));
+        HIPCHK(h, hipMemsetAsync(h->d_ru2, 0, h->nflat * sizeof(float), h->stream));
+    }
+    return STATTN_OK;
+}
+
+}  // extern "C"

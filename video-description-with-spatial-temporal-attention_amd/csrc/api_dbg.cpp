@@ -1,0 +1,195 @@
+// Development entry points (csrc/stattn_dbg.h): kernels run and timed in isolation by tests/ and tools/.
+#include "steps.h"
+#include "stattn_dbg.h"
+
+extern "C" {
+
+// ---- kernel-level entry points ------------------------------------------------------
+int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, int N, int K, float alpha,
+                    const float* A, const float* B, const float* bias, const float* add, int act, float* C) {
+    if (!h || !A || !B || !C || M <= 0 || N <= 0 || K <= 0) return fail(h, STATTN_EINVAL, "dbg_gemm: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    float *dA, *dB, *dC, *dbias, *dadd;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N, &dC));
+    CHK(getbuf_t(h, "dbg_bias", (size_t)N, &dbias));
+    CHK(getbuf_t(h, "dbg_add", (size_t)M * N, &dadd));
+    HIPCHK(h, hipMemcpyAsync(dA, A, (size_t)M * K * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(dB, B, (size_t)K * N * 4, hipMemcpyHostToDevice, s));
+    if (bias) HIPCHK(h, hipMemcpyAsync(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
+    if (add) HIPCHK(h, hipMemcpyAsync(dadd, add, (size_t)M * N * 4, hipMemcpyHostToDevice, s));
+    if (kind == 0 || kind == 4) {
+        GemmArgs g;
+        gemm_defaults(g); g.split = h->opt.precision != 0;
+        g.split = kind == 4;
+        g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
+        g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias ? dbias : nullptr;
+        if (add) { g.add = dadd; g.ldadd = N; }
+        g.act = act;
+        if (g.split && !gemm_split_supported(g, transA != 0, transB != 0))
+            return fail(h, STATTN_EINVAL, "split kernel: N % 128 == 0, k-contiguous operands 16-byte aligned");
+        hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else if (kind == 2) {
+        // bf16-MFMA kernel: operands rounded to bf16 on the device, B kept k-contiguous ([N][K])
+        if (transA || alpha != 1.f || K % 8 != 0) return fail(h, STATTN_EINVAL, "bf16 kernel: no transA, alpha must be 1, K % 8 == 0");
+        uint16_t *bA, *bB;
+        CHK(getbuf_t(h, "dbg_bA", (size_t)M * K, &bA));
+        CHK(getbuf_t(h, "dbg_bB", (size_t)K * N, &bB));
+        HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
+        if (transB) HIPCHK(h, launch_cvt_bf16(s, dB, bB, (size_t)K * N));
+        else HIPCHK(h, launch_cvt_bf16_t(s, dB, N, bB, K, K, N));
+        GemmBfArgs g{};
+        g.A = bA; g.lda = K; g.B = bB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
+        g.bias = bias ? dbias : nullptr;
+        if (add) { g.add = dadd; g.ldadd = N; }
+        g.act = act; g.rowgroup = 1;
+        hipError_t e = launch_gemm_bf16(s, g);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else if (kind == 3) {
+        // row-panel kernel: B repacked on the device (transB: the operand is B^T, packed straight from B [N][K])
+        if (transA || alpha != 1.f || !panel_supported(M) || N % 16 || K % 16)
+            return fail(h, STATTN_EINVAL, "panel kernel: no transA, alpha must be 1, M <= 512, N and K multiples of 16");
+        float* P;
+        CHK(getbuf_t(h, "dbg_P", (size_t)K * N, &P));
+        CHK(pack(h, dB, transB ? K : N, transB ? 1 : 0, K, N / 16, PN_COLS_PLAIN, P));
+        PnArgs a{};
+        a.M = M; a.nseg = 1;
+        PnSeg& sg = a.seg[0];
+        pn_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = PnPair{dA, K, P, K};
+        sg.C = dC; sg.ldc = N; sg.N = N; sg.bias = bias ? dbias : nullptr;
+        if (add) { sg.add = dadd; sg.ldadd = N; }
+        sg.act = act;
+        hipError_t e = launch_panel(s, a);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    } else {
+        if (transA || transB) return fail(h, STATTN_EINVAL, "skinny kernel has no transposed variants");
+        SkArgs a{};
+        a.M = M; a.nseg = 1;
+        SkSeg& sg = a.seg[0];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{dA, dB, K, N, K, 0};
+        sg.C = dC; sg.ldc = N; sg.N = N; sg.bias = bias ? dbias : nullptr;
+        if (add) { sg.add = dadd; sg.ldadd = N; }
+        sg.act = act; sg.scale = 1.f;
+        if (alpha != 1.f) return fail(h, STATTN_EINVAL, "skinny kernel: alpha must be 1");
+        hipError_t e = launch_skinny(s, a);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+    }
+    HIPCHK(h, hipMemcpyAsync(C, dC, (size_t)M * N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    return STATTN_OK;
+}
+
+int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N, int K, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(h, STATTN_EINVAL, "dbg_time_gemm: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB, *dC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N, &dC));
+    // uniform [-1,1) operands: full-range signs (never time a GEMM on zeros -- DVFS inflates the clock)
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N, 11, 2));
+    GemmArgs g;
+    gemm_defaults(g); g.split = h->opt.precision != 0;
+    g.A = dA; g.lda = transA ? M : K; g.B = dB; g.ldb = transB ? K : N; g.C = dC; g.ldc = N;
+    g.M = M; g.N = N; g.K = K;
+    {   // same split-K workspace the backward pass hands to its weight-gradient GEMMs
+        float* ws;
+        CHK(getbuf_t(h, "b_ws", (size_t)16 << 20, &ws));
+        g.ws = ws; g.ws_floats = (size_t)16 << 20;
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+    HIPCHK(h, hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+    HIPCHK(h, hipEventRecord(b, s));
+    HIPCHK(h, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || !ms_per_launch) return fail(h, STATTN_EINVAL, "dbg_time_gemm_bf16: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB;
+    uint16_t *bA, *bB, *bC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N, &dB));
+    CHK(getbuf_t(h, "dbg_bA", (size_t)M * K, &bA));
+    CHK(getbuf_t(h, "dbg_bB", (size_t)K * N, &bB));
+    CHK(getbuf_t(h, "dbg_bC", (size_t)M * N, &bC));
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N, 11, 2));
+    HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
+    HIPCHK(h, launch_cvt_bf16(s, dB, bB, (size_t)K * N));
+    GemmBfArgs g{};
+    g.A = bA; g.lda = K; g.B = bB; g.ldb = K; g.Cb = bC; g.ldcb = N; g.M = M; g.N = N; g.K = K; g.rowgroup = 1; g.tile = tile;
+    for (int i = 0; i < 2; ++i) {
+        hipError_t e = launch_gemm_bf16(s, g);
+        if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_time_gemm_bf16: %s", hipGetErrorString(e));
+    }
+    hipEvent_t a, b;
+    HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
+    HIPCHK(h, hipEventRecord(a, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm_bf16(s, g));
+    HIPCHK(h, hipEventRecord(b, s));
+    HIPCHK(h, hipEventSynchronize(b));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+long stattn_dbg_counter(const stattn_handle* h, int which) {
+    if (!h) return -1;
+    if (which == 0) return h->beam_graph_replays;
+    return -1;
+}
+
+int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters, float* ms_per_launch) {
+    if (!h || M <= 0 || N <= 0 || K <= 0 || iters <= 0 || nseg < 1 || nseg > 6 || !ms_per_launch)
+        return fail(h, STATTN_EINVAL, "dbg_time_skinny: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    float *dA, *dB, *dC;
+    CHK(getbuf_t(h, "dbg_A", (size_t)M * K, &dA));
+    CHK(getbuf_t(h, "dbg_B", (size_t)K * N * nseg, &dB));
+    CHK(getbuf_t(h, "dbg_C", (size_t)M * N * nseg, &dC));
+    HIPCHK(h, launch_uniform(s, dA, (size_t)M * K, 11, 1));
+    HIPCHK(h, launch_uniform(s, dB, (size_t)K * N * nseg, 11, 2));
+    SkArgs a{};
+    a.M = M; a.nseg = nseg;
+    for (int i = 0; i < nseg; ++i) {
+        SkSeg& sg = a.seg[i];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{dA, dB + (size_t)i * K * N, K, N, K, (variant & 16) ? (size_t)K * 64 : 0};
+        sg.C = dC + (size_t)i * N; sg.ldc = N * nseg; sg.N = N;
+    }
+    for (int i = 0; i < 2; ++i) HIPCHK(h, launch_skinny(s, a));
+    hipEvent_t e0, e1;
+    HIPCHK(h, hipEventCreate(&e0)); HIPCHK(h, hipEventCreate(&e1));
+    HIPCHK(h, hipEventRecord(e0, s));
+    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_skinny(s, a));
+    HIPCHK(h, hipEventRecord(e1, s));
+    HIPCHK(h, hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIPCHK(h, hipEventElapsedTime(&ms, e0, e1));
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    *ms_per_launch = ms / iters;
+    return STATTN_OK;
+}
+
+}  // extern "C"

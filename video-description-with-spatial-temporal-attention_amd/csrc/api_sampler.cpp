@@ -1,0 +1,537 @@
+// C ABI of libstattn.so, part 2: the sampler -- f_init / f_next (model_attention.py:719-850) and gen_sample run on the
+// device for many videos at once (stattn_beam_search, :852-994).
+#include "steps.h"
+
+extern "C" {
+
+// ---- sampler ------------------------------------------------------------------------
+int stattn_f_init(stattn_handle* h, const float* ctxg, const float* ctxg_mask, int T, float* out_h0, float* out_c0) {
+    if (!h || !ctxg || !ctxg_mask || T <= 0 || !out_h0 || !out_c0) return fail(h, STATTN_EINVAL, "f_init: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int D = h->D;
+    float *G, *mk, *mean, *h0, *c0;
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    CHK(getbuf_t(h, "fi_G", (size_t)T * D, &G));
+    CHK(getbuf_t(h, "fi_mask", (size_t)T, &mk));
+    CHK(getbuf_t(h, "fi_mean", (size_t)D, &mean));
+    CHK(getbuf_t(h, "fi_h0", (size_t)D, &h0));
+    CHK(getbuf_t(h, "fi_c0", (size_t)D, &c0));
+    HIPCHK(h, hipMemcpyAsync(G, ctxg, (size_t)T * D * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    HIPCHK(h, hipMemcpyAsync(mk, ctxg_mask, (size_t)T * sizeof(float), hipMemcpyHostToDevice, h->stream));
+    CHK(init_state(h, 1, T, G, mk, mean, h0, c0));
+    HIPCHK(h, hipMemcpyAsync(out_h0, h0, D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipMemcpyAsync(out_c0, c0, D * sizeof(float), hipMemcpyDeviceToHost, h->stream));
+    HIPCHK(h, hipStreamSynchronize(h->stream));
+    return STATTN_OK;
+}
+
+// Buffers of the resident video of the sampler: raw features and their projections.
+static int video_buffers(stattn_handle* h, int T, int K, CtxPtrs* c, float** rawl, float** rawm) {
+    const int D = h->D;
+    CHK(getbuf_t(h, "sv_G", (size_t)T * D, &c->G));
+    CHK(getbuf_t(h, "sv_rawl", (size_t)T * K * h->Fl, rawl));
+    CHK(getbuf_t(h, "sv_rawm", (size_t)T * h->Fm, rawm));
+    CHK(getbuf_t(h, "sv_L", (size_t)T * K * D, &c->L));
+    CHK(getbuf_t(h, "sv_Mo", (size_t)T * D, &c->Mo));
+    CHK(getbuf_t(h, "sv_PG", (size_t)T * D, &c->PG));
+    CHK(getbuf_t(h, "sv_PL", (size_t)T * K * D, &c->PL));
+    CHK(getbuf_t(h, "sv_PM", (size_t)T * D, &c->PM));
+    CHK(getbuf_t(h, "sv_LW", h->opt.lt_mode == 1 ? (size_t)T * K * D : 1, &c->LW));
+    return STATTN_OK;
+}
+
+// upload (when host features are given) and project the sampler's video
+static int stage_video(stattn_handle* h, const float* ctxg, const float* ctxl, const float* ctxm, int T, int K, CtxPtrs* c) {
+    float *rawl, *rawm;
+    hipStream_t s = h->stream;
+    if (ctxg) {
+        if (h->ck_valid && (h->ck_T != T || h->ck_K != K)) HIPCHK(h, hipStreamSynchronize(s));   // buffers may be reallocated
+        CHK(video_buffers(h, T, K, c, &rawl, &rawm));
+        HIPCHK(h, hipMemcpyAsync(c->G, ctxg, (size_t)T * h->D * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(rawl, ctxl, (size_t)T * K * h->Fl * sizeof(float), hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(rawm, ctxm, (size_t)T * h->Fm * sizeof(float), hipMemcpyHostToDevice, s));
+        h->ck_T = T; h->ck_K = K; h->ck_valid = true; h->ck_proj = false;
+    } else {
+        if (!h->ck_valid) return fail(h, STATTN_ESTATE, "f_next: no resident video (pass the features or call stattn_set_video)");
+        if (h->ck_T != T || h->ck_K != K)
+            return fail(h, STATTN_EINVAL, "f_next: the resident video is (T=%d,K=%d), the call says (T=%d,K=%d)", h->ck_T, h->ck_K, T, K);
+        CHK(video_buffers(h, T, K, c, &rawl, &rawm));
+    }
+    if (!h->ck_proj) {    // new features, or the parameters changed since the last projection
+        CHK(project_context(h, 1, T, K, c->G, rawl, rawm, *c));
+        h->ck_proj = true;
+    }
+    return STATTN_OK;
+}
+
+int stattn_set_video(stattn_handle* h, const float* ctxg, const float* ctxl, const float* ctxm, int T, int K) {
+    if (!h || !ctxg || !ctxl || !ctxm || T <= 0 || K <= 0) return fail(h, STATTN_EINVAL, "set_video: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    CtxPtrs c{};
+    CHK(stage_video(h, ctxg, ctxl, ctxm, T, K, &c));
+    HIPCHK(h, hipStreamSynchronize(h->stream));     // the host arrays are borrowed for the call only
+    return STATTN_OK;
+}
+
+int stattn_f_next(stattn_handle* h, const int64_t* x, int m, const float* ctxg, const float* ctxg_mask,
+                  const float* ctxl, const float* ctxl_mask, const float* ctxm, const float* ctxm_mask, int T, int K,
+                  const float* h_in, const float* c_in, float* out_probs, int64_t* out_sample, float* out_h, float* out_c,
+                  float* out_alphal, float* out_alphag, float* out_alpham, float* out_alphalt, float* out_logits) {
+    (void)ctxg_mask; (void)ctxl_mask; (void)ctxm_mask;   // unused by the reference graph too (:848)
+    const bool resident = !ctxg && !ctxl && !ctxm;
+    if (!h || !x || m <= 0 || (!resident && (!ctxg || !ctxl || !ctxm)) || T <= 0 || K <= 0 || !h_in || !c_in)
+        return fail(h, STATTN_EINVAL, "f_next: bad argument");
+    for (int r = 0; r < m; ++r)        // Wemb[x] raises IndexError in the reference (:803-804); -1 marks the first word
+        if (x[r] < -1 || x[r] >= h->V) return fail(h, STATTN_EINVAL, "f_next: word index %lld outside [-1, %d)", (long long)x[r], h->V);
+    HIPCHK(h, hipSetDevice(h->device));
+    const int D = h->D, E = h->E, V = h->V, Vp = h->Vp;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    // (no leading synchronise: every call ends with one, and the buffers below are only touched in stream order)
+
+    // --- the video.  Host features given: uploaded and projected on EVERY call, like the reference graph
+    // (:782-788) -- no content guessing.  All three NULL: the video staged by stattn_set_video (or by the last call
+    // that passed features) is reused; its projections are redone only if the parameters changed since.
+    CtxPtrs c{};
+    CHK(stage_video(h, ctxg, ctxl, ctxm, T, K, &c));
+
+    // --- step buffers
+    int64_t *dx, *dargmax; int* vid;
+    float *hp, *cp, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *ho, *co, *hd, *a1, *lg, *pr;
+    // inputs {h | c | x} and outputs {h' | c' | probs} are each one device block mirrored by one pinned host block
+    const size_t in_floats = (size_t)2 * m * D + 2 * (size_t)m;                 // x: m int64 = 2m floats, 8-byte aligned
+    const size_t out_floats = (size_t)2 * m * D + (size_t)m * Vp;
+    float *d_in, *d_out;
+    CHK(getbuf_t(h, "sn_in", in_floats, &d_in));
+    CHK(getbuf_t(h, "sn_out", out_floats, &d_out));
+    hp = d_in; cp = d_in + (size_t)m * D; dx = reinterpret_cast<int64_t*>(d_in + (size_t)2 * m * D);
+    if ((in_floats + out_floats) * 4 > h->pin_io_bytes) {
+        if (h->pin_io) { (void)hipHostFree(h->pin_io); h->pin_io = nullptr; h->pin_io_bytes = 0; }
+        HIPCHK(h, hipHostMalloc(&h->pin_io, (in_floats + out_floats) * 4, hipHostMallocDefault));
+        h->pin_io_bytes = (in_floats + out_floats) * 4;
+    }
+    float* p_in = static_cast<float*>(h->pin_io);
+    float* p_out = p_in + in_floats;
+    CHK(getbuf_t(h, "sn_argmax", (size_t)m, &dargmax));
+    CHK(getbuf_t(h, "sn_vid", (size_t)m, &vid));
+    CHK(getbuf_t(h, "sn_emb", (size_t)m * E, &emb));
+    CHK(getbuf_t(h, "sn_sproj", (size_t)m * 4 * D, &sproj));
+    CHK(getbuf_t(h, "sn_preh", (size_t)m * 4 * D, &preh));
+    CHK(getbuf_t(h, "sn_dp", (size_t)m * 3 * D, &dp));
+    CHK(getbuf_t(h, "sn_al", (size_t)m * T * K, &al));
+    CHK(getbuf_t(h, "sn_CL", (size_t)m * T * D, &CL));
+    CHK(getbuf_t(h, "sn_eg", (size_t)m * T, &eg));
+    CHK(getbuf_t(h, "sn_em", (size_t)m * T, &em));
+    CHK(getbuf_t(h, "sn_elt", (size_t)m * T, &elt));
+    CHK(getbuf_t(h, "sn_plt", h->opt.lt_mode == 0 ? (size_t)m * T * D : 1, &plt));
+    CHK(getbuf_t(h, "sn_ag", (size_t)m * T, &ag));
+    CHK(getbuf_t(h, "sn_am", (size_t)m * T, &am));
+    CHK(getbuf_t(h, "sn_alt", (size_t)m * T, &alt));
+    CHK(getbuf_t(h, "sn_ctx", (size_t)m * D, &ctx));
+    ho = d_out; co = d_out + (size_t)m * D;
+    CHK(getbuf_t(h, "sn_hd", (size_t)m * D, &hd));
+    CHK(getbuf_t(h, "sn_a1", (size_t)m * E, &a1));
+    CHK(getbuf_t(h, "sn_lg", (size_t)m * Vp, &lg));
+    pr = d_out + (size_t)2 * m * D;
+
+    memcpy(p_in, h_in, (size_t)m * D * sizeof(float));
+    memcpy(p_in + (size_t)m * D, c_in, (size_t)m * D * sizeof(float));
+    memcpy(p_in + (size_t)2 * m * D, x, (size_t)m * sizeof(int64_t));
+    HIPCHK(h, hipMemcpyAsync(d_in, p_in, in_floats * 4, hipMemcpyHostToDevice, s));
+    if (h->sn_m != m || h->sn_dp != dp || h->sn_vid != vid) {   // constant across the calls of a decode loop
+        HIPCHK(h, launch_iota(s, vid, m, 0));                   // every hypothesis attends to video 0 (:786-788)
+        HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)m * 3 * D)); // sampler runs with use_noise = 0 (:469-472)
+        h->sn_m = m; h->sn_dp = dp; h->sn_vid = vid;
+    }
+    HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, m, E, V, 0));    // :803-804
+
+    StepIO io{};
+    io.M = m; io.T = T; io.K = K; io.c = c; io.vid = vid;
+    io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
+    io.dp = dp; io.mask = nullptr; io.d1 = nullptr;
+    io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
+    io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
+    io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+    io.pn = nullptr;              // a handful of rows per call: the 64-column skinny kernels (no repacking per call)
+    CHK(run_step(h, io));
+
+    {   // readout (:817-838): a = 0.5 * tanh(0.5h.Wl1 + bl1 [+ emb] [+ ctx.Wl2 + bl2]); logit = a.Wo + bo
+        SkArgs a{};
+        a.M = m; a.nseg = 1;
+        SkSeg& sg = a.seg[0];
+        skinny_seg_defaults(sg);
+        sg.npairs = 1; sg.p[0] = SkPair{hd, w.Wl1, D, E, D, 0};
+        if (h->opt.ctx2out) { sg.p[1] = SkPair{ctx, w.Wl2, D, E, D, 0}; sg.npairs = 2; sg.bias2 = w.bl2; }
+        sg.bias = w.bl1;
+        if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+        sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+        HIPCHK(h, launch_skinny(s, a));
+        SkArgs b{};
+        b.M = m; b.nseg = 1;
+        SkSeg& so = b.seg[0];
+        skinny_seg_defaults(so);
+        so.npairs = 1; so.p[0] = SkPair{a1, w.Wo, E, Vp, E, 0};
+        so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+        HIPCHK(h, launch_skinny(s, b));
+        HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, dargmax, m, V));   // :840
+    }
+
+    // {h' | c' | probs} in one transfer to pinned memory; rows of probs are unpadded on the way to the caller
+    HIPCHK(h, hipMemcpyAsync(p_out, d_out, (out_probs ? out_floats : (size_t)2 * m * D) * 4, hipMemcpyDeviceToHost, s));
+    if (out_logits) HIPCHK(h, hipMemcpy2DAsync(out_logits, (size_t)V * 4, lg, (size_t)Vp * 4, (size_t)V * 4, m, hipMemcpyDeviceToHost, s));
+    if (out_alphal) HIPCHK(h, hipMemcpyAsync(out_alphal, al, (size_t)m * T * K * 4, hipMemcpyDeviceToHost, s));
+    if (out_alphag) HIPCHK(h, hipMemcpyAsync(out_alphag, ag, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    if (out_alpham) HIPCHK(h, hipMemcpyAsync(out_alpham, am, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    if (out_alphalt) HIPCHK(h, hipMemcpyAsync(out_alphalt, alt, (size_t)m * T * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    if (out_h) memcpy(out_h, p_out, (size_t)m * D * 4);
+    if (out_c) memcpy(out_c, p_out + (size_t)m * D, (size_t)m * D * 4);
+    if (out_probs)
+        for (int r = 0; r < m; ++r) memcpy(out_probs + (size_t)r * V, p_out + (size_t)2 * m * D + (size_t)r * Vp, (size_t)V * 4);
+
+    if (out_sample) {
+        // next_sample = multinomial(next_probs).argmax(1) (:841): inverse-CDF draw with the library's own
+        // generator (bit-parity with Theano's MRG stream is not a goal).  Without probs: arg-max.
+        if (out_probs) {
+            for (int r = 0; r < m; ++r) {
+                h->host_rng ^= h->host_rng << 13; h->host_rng ^= h->host_rng >> 7; h->host_rng ^= h->host_rng << 17;
+                const double u = (double)(h->host_rng >> 11) * (1.0 / 9007199254740992.0);
+                double acc = 0.0; int64_t pick = V - 1;
+                const float* p = out_probs + (size_t)r * V;
+                int j = 0;
+                for (; j + 64 <= V; j += 64) {          // whole chunks first (the inner sum vectorises), then the hit chunk
+                    float cs = 0.f;
+                    for (int q = 0; q < 64; ++q) cs += p[j + q];
+                    if (u < acc + (double)cs) break;
+                    acc += (double)cs;
+                }
+                for (; j < V; ++j) { acc += p[j]; if (u < acc) { pick = j; break; } }
+                out_sample[r] = pick;
+            }
+        } else {
+            HIPCHK(h, hipMemcpy(out_sample, dargmax, (size_t)m * sizeof(int64_t), hipMemcpyDeviceToHost));
+        }
+    }
+    return STATTN_OK;
+}
+
+// ---- batched beam search: gen_sample (model_attention.py:852-994) for many videos at once, on the device ----
+// raw features of `nvid` videos -> HBM (shared by stattn_beam_stage and stattn_beam_search)
+static int beam_stage_impl(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                           const float* ctxm, int T, int K) {
+    hipStream_t s = h->stream;
+    const int D = h->D;
+    const size_t nG = (size_t)nvid * T * D, nL = (size_t)nvid * T * K * h->Fl, nM = (size_t)nvid * T * h->Fm;
+    float *G, *rawl, *rawm, *mG;
+    HIPCHK(h, hipStreamSynchronize(s));
+    CHK(getbuf_t(h, "bs_G", nG, &G)); CHK(getbuf_t(h, "bs_rawl", nL, &rawl)); CHK(getbuf_t(h, "bs_rawm", nM, &rawm));
+    CHK(getbuf_t(h, "bs_mG", (size_t)nvid * T, &mG));
+    HIPCHK(h, hipMemcpyAsync(G, ctxg, nG * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(mG, ctxg_mask, (size_t)nvid * T * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(rawl, ctxl, nL * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipMemcpyAsync(rawm, ctxm, nM * 4, hipMemcpyHostToDevice, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    h->bk_n = nvid; h->bk_T = T; h->bk_K = K; h->bk_valid = true;
+    return STATTN_OK;
+}
+
+int stattn_beam_stage(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                      const float* ctxm, int T, int K) {
+    if (!h || nvid <= 0 || !ctxg || !ctxg_mask || !ctxl || !ctxm || T <= 0 || K <= 0)
+        return fail(h, STATTN_EINVAL, "beam_stage: bad argument");
+    HIPCHK(h, hipSetDevice(h->device));
+    return beam_stage_impl(h, nvid, ctxg, ctxg_mask, ctxl, ctxm, T, K);
+}
+
+int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                       const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
+                       int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count) {
+    const bool resident = !ctxg && !ctxg_mask && !ctxl && !ctxm;
+    if (!h || nvid <= 0 || (!resident && (!ctxg || !ctxg_mask || !ctxl || !ctxm)) || T <= 0 || K <= 0 || k < 1 || k > 8 ||
+        maxlen < 1 || !out_tokens || !out_scores || !out_lens || !out_count)
+        return fail(h, STATTN_EINVAL, "beam_search: bad argument (1 <= k <= 8)");
+    HIPCHK(h, hipSetDevice(h->device));
+    const int D = h->D, E = h->E, V = h->V, Vp = h->Vp;
+    const Weights& w = h->w;
+    hipStream_t s = h->stream;
+    HIPCHK(h, hipStreamSynchronize(s));
+    const int M = nvid * k, L0 = maxlen;
+    const size_t nG = (size_t)nvid * T * D, nL = (size_t)nvid * T * K * h->Fl, nM = (size_t)nvid * T * h->Fm, nLd = (size_t)nvid * T * K * D;
+
+    // host features given: staged on every call (no content guessing); all four NULL: the videos staged by
+    // stattn_beam_stage are decoded again (benchmarks, repeated decoding with new parameters)
+    if (!resident) CHK(beam_stage_impl(h, nvid, ctxg, ctxg_mask, ctxl, ctxm, T, K));
+    else if (!h->bk_valid || h->bk_n != nvid || h->bk_T != T || h->bk_K != K)
+        return fail(h, STATTN_ESTATE, "beam_search: no staged videos of this shape (call stattn_beam_stage)");
+    CtxPtrs c{};
+    float *rawl, *rawm, *mG, *mean, *h0, *c0;
+    CHK(getbuf_t(h, "bs_G", nG, &c.G)); CHK(getbuf_t(h, "bs_rawl", nL, &rawl)); CHK(getbuf_t(h, "bs_rawm", nM, &rawm));
+    CHK(getbuf_t(h, "bs_mG", (size_t)nvid * T, &mG));
+    CHK(getbuf_t(h, "bs_L", nLd, &c.L)); CHK(getbuf_t(h, "bs_Mo", nG, &c.Mo)); CHK(getbuf_t(h, "bs_PG", nG, &c.PG));
+    CHK(getbuf_t(h, "bs_PL", nLd, &c.PL)); CHK(getbuf_t(h, "bs_PM", nG, &c.PM));
+    CHK(getbuf_t(h, "bs_LW", h->opt.lt_mode == 1 ? nLd : 1, &c.LW));
+    CHK(getbuf_t(h, "bs_mean", (size_t)nvid * D, &mean)); CHK(getbuf_t(h, "bs_h0", (size_t)nvid * D, &h0));
+    CHK(getbuf_t(h, "bs_c0", (size_t)nvid * D, &c0));
+    CHK(project_context(h, nvid, T, K, c.G, rawl, rawm, c));       // once per video, not once per word
+    CHK(init_state(h, nvid, T, c.G, mG, mean, h0, c0));            // f_init (:880)
+
+    int *vid, *live_k, *dead_k, *tok[2], *fin_tok, *fin_len;
+    int64_t* next_w;
+    float *hp, *cp, *ho, *co, *hd, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *a1, *lg, *pr,
+          *score[2], *fin_score;
+    CHK(getbuf_t(h, "bs_vid", (size_t)M, &vid));
+    CHK(getbuf_t(h, "bs_live", (size_t)nvid, &live_k)); CHK(getbuf_t(h, "bs_dead", (size_t)nvid, &dead_k));
+    CHK(getbuf_t(h, "bs_tok0", (size_t)M * L0, &tok[0])); CHK(getbuf_t(h, "bs_tok1", (size_t)M * L0, &tok[1]));
+    CHK(getbuf_t(h, "bs_fin_tok", (size_t)M * L0, &fin_tok)); CHK(getbuf_t(h, "bs_fin_len", (size_t)M, &fin_len));
+    CHK(getbuf_t(h, "bs_fin_score", (size_t)M, &fin_score));
+    CHK(getbuf_t(h, "bs_score0", (size_t)M, &score[0])); CHK(getbuf_t(h, "bs_score1", (size_t)M, &score[1]));
+    CHK(getbuf_t(h, "bs_next_w", (size_t)M, &next_w));
+    int* d_step;
+    CHK(getbuf_t(h, "bs_step", (size_t)1, &d_step));
+    float *end_h, *end_c; int* end_rows;
+    CHK(getbuf_t(h, "bs_end_h", (size_t)M * D, &end_h)); CHK(getbuf_t(h, "bs_end_c", (size_t)M * D, &end_c));
+    CHK(getbuf_t(h, "bs_end_rows", (size_t)nvid, &end_rows));
+    float* tk_cost; int* tk_idx;
+    CHK(getbuf_t(h, "bs_tk_cost", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_cost));
+    CHK(getbuf_t(h, "bs_tk_idx", (size_t)nvid * beam_topk_splits(nvid) * 8, &tk_idx));
+    CHK(getbuf_t(h, "bs_hp", (size_t)M * D, &hp)); CHK(getbuf_t(h, "bs_cp", (size_t)M * D, &cp));
+    CHK(getbuf_t(h, "bs_ho", (size_t)M * D, &ho)); CHK(getbuf_t(h, "bs_co", (size_t)M * D, &co));
+    CHK(getbuf_t(h, "bs_hd", (size_t)M * D, &hd)); CHK(getbuf_t(h, "bs_emb", (size_t)M * E, &emb));
+    CHK(getbuf_t(h, "bs_sproj", (size_t)M * 4 * D, &sproj)); CHK(getbuf_t(h, "bs_preh", (size_t)M * 4 * D, &preh));
+    CHK(getbuf_t(h, "bs_dp", (size_t)M * 3 * D, &dp));
+    CHK(getbuf_t(h, "bs_al", (size_t)M * T * K, &al)); CHK(getbuf_t(h, "bs_CL", (size_t)M * T * D, &CL));
+    CHK(getbuf_t(h, "bs_eg", (size_t)M * T, &eg)); CHK(getbuf_t(h, "bs_em", (size_t)M * T, &em)); CHK(getbuf_t(h, "bs_elt", (size_t)M * T, &elt));
+    CHK(getbuf_t(h, "bs_plt", h->opt.lt_mode == 0 ? (size_t)M * T * D : 1, &plt));
+    CHK(getbuf_t(h, "bs_ag", (size_t)M * T, &ag)); CHK(getbuf_t(h, "bs_am", (size_t)M * T, &am)); CHK(getbuf_t(h, "bs_alt", (size_t)M * T, &alt));
+    CHK(getbuf_t(h, "bs_ctx", (size_t)M * D, &ctx)); CHK(getbuf_t(h, "bs_a1", (size_t)M * E, &a1));
+    CHK(getbuf_t(h, "bs_lg", (size_t)M * Vp, &lg)); CHK(getbuf_t(h, "bs_pr", (size_t)M * Vp, &pr));
+
+    // initial beam: one live hypothesis per video (row v*k), empty, score 0, next word -1 (:871-893)
+    {
+        std::vector<int> hv(M), one(nvid, 1);
+        std::vector<int64_t> nw(M, -1);
+        for (int i = 0; i < M; ++i) hv[i] = i / k;
+        HIPCHK(h, hipMemcpyAsync(vid, hv.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(live_k, one.data(), (size_t)nvid * 4, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipMemcpyAsync(next_w, nw.data(), (size_t)M * 8, hipMemcpyHostToDevice, s));
+        HIPCHK(h, hipStreamSynchronize(s));     // the host vectors go out of scope
+    }
+    HIPCHK(h, hipMemsetAsync(dead_k, 0, (size_t)nvid * 4, s));
+    HIPCHK(h, hipMemsetAsync(score[0], 0, (size_t)M * 4, s));
+    HIPCHK(h, hipMemsetAsync(hp, 0, (size_t)M * D * 4, s));
+    HIPCHK(h, hipMemsetAsync(cp, 0, (size_t)M * D * 4, s));
+    HIPCHK(h, hipMemcpy2DAsync(hp, (size_t)k * D * 4, h0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, hipMemcpy2DAsync(cp, (size_t)k * D * 4, c0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
+    HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)M * 3 * D));
+
+    // one decoded word = a fixed sequence of 10 kernel launches whose arguments depend on the word index only through
+    // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
+    FwdPanels pn{};
+    const bool panels = use_panels(h, M, 1) && Vp % 16 == 0;
+    float *hp_pk = nullptr, *ctx_pk = nullptr, *emb_pk = nullptr, *hd_pk = nullptr, *a1_pk = nullptr;
+    if (panels) {
+        CHK(pack_fwd_panels(h, &pn, true));
+        // packed-A copies of every activation that feeds a row-panel GEMM, written by the kernel that produces it
+        CHK(getbuf_t(h, "bs_hp_pk", packed_rows_floats(M, D), &hp_pk)); CHK(getbuf_t(h, "bs_ctx_pk", packed_rows_floats(M, D), &ctx_pk));
+        CHK(getbuf_t(h, "bs_emb_pk", packed_rows_floats(M, E), &emb_pk)); CHK(getbuf_t(h, "bs_hd_pk", packed_rows_floats(M, D), &hd_pk));
+        CHK(getbuf_t(h, "bs_a1_pk", packed_rows_floats(M, E), &a1_pk));
+        for (float* q : {ctx_pk, hd_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, D) * sizeof(float), s));
+        for (float* q : {emb_pk, a1_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, E) * sizeof(float), s));
+        HIPCHK(h, launch_pack_rows(s, hp, D, M, D, hp_pk));          // initial states; later words: beam_update's gather
+    }
+    // first word: no previous word, zero embedding (:803-804); afterwards beam_update writes the embedding of the
+    // word it selects (no lookup launch inside the loop)
+    HIPCHK(h, hipMemsetAsync(emb, 0, (size_t)M * E * sizeof(float), s));
+    int* d_ticket;
+    CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
+    HIPCHK(h, hipMemsetAsync(d_ticket, 0, sizeof(int), s));
+    auto enqueue_word = [&](int parity) -> int {
+        StepIO io{};
+        io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
+        io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
+        io.dp = dp; io.mask = nullptr; io.d1 = nullptr;
+        io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
+        io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
+        io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+        io.pn = panels ? &pn : nullptr;
+        io.h_prev_pk = hp_pk; io.h_out_pk = nullptr; io.ctx_pk = ctx_pk; io.emb_pk = emb_pk; io.hd_pk = hd_pk;
+        CHK(run_step(h, io));
+        if (panels) {      // readout (:817-838) on the row-panel kernel
+            PnArgs a{};
+            a.M = M; a.nseg = 1;
+            PnSeg& sg = a.seg[0];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{hd_pk, D, pn.Wl1, D, 1};
+            if (h->opt.ctx2out) { sg.p[1] = PnPair{ctx_pk, D, pn.Wl2, D, 1}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.Cpk = a1_pk;
+            sg.bias = w.bl1;
+            if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+            sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+            HIPCHK(h, launch_panel(s, a));
+            PnArgs b{};
+            b.M = M; b.nseg = 1;
+            PnSeg& so = b.seg[0];
+            pn_seg_defaults(so);
+            so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
+            so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+            HIPCHK(h, launch_panel(s, b));
+            HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
+        } else {
+            SkArgs a{};
+            a.M = M; a.nseg = 1;
+            SkSeg& sg = a.seg[0];
+            skinny_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = SkPair{hd, w.Wl1, D, E, D, 0};
+            if (h->opt.ctx2out) { sg.p[1] = SkPair{ctx, w.Wl2, D, E, D, 0}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.bias = w.bl1;
+            if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+            sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+            HIPCHK(h, launch_skinny(s, a));
+            SkArgs b{};
+            b.M = M; b.nseg = 1;
+            SkSeg& so = b.seg[0];
+            skinny_seg_defaults(so);
+            so.npairs = 1; so.p[0] = SkPair{a1, w.Wo, E, Vp, E, 0};
+            so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+            HIPCHK(h, launch_skinny(s, b));
+            HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
+        }
+        BeamArgs ba{};
+        ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = d_step;
+        ba.suppress_eos = suppress_eos;
+        ba.live_k = live_k; ba.dead_k = dead_k; ba.hyp_score = score[parity]; ba.hyp_score_out = score[parity ^ 1];
+        ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
+        ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
+        ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
+        ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
+        ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
+        HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
+        HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
+        return STATTN_OK;
+    };
+    HIPCHK(h, hipMemsetAsync(d_step, 0, sizeof(int), s));
+
+    // The launch-bound inner loop is captured once as a hipGraph of TWO words (even + odd parity) and replayed; the
+    // host only comes back every 8 words to see whether every video has finished.  Falls back to eager launches if
+    // the capture is refused (or STATTN_BEAM_NOGRAPH is set, for A/B runs).
+    hipGraphExec_t gexec = nullptr;
+    static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
+    h->beam_graph_replays = 0;
+    // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos,
+                                  (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
+    for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
+                          (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,
+                          (const void*)tok[0], (const void*)tok[1],
+                          (const void*)fin_tok, (const void*)fin_len, (const void*)fin_score, (const void*)score[0],
+                          (const void*)score[1], (const void*)next_w, (const void*)hp, (const void*)cp, (const void*)ho,
+                          (const void*)co, (const void*)hd, (const void*)emb, (const void*)sproj, (const void*)preh, (const void*)dp,
+                          (const void*)al, (const void*)CL, (const void*)eg, (const void*)em, (const void*)elt, (const void*)plt,
+                          (const void*)ag, (const void*)am, (const void*)alt, (const void*)ctx, (const void*)a1, (const void*)lg,
+                          (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
+                          (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
+                          (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows, (const void*)hp_pk,
+                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket})
+        sig.push_back((uintptr_t)q);
+    if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
+        gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is
+    } else if (!nograph && !h->profiling && L0 >= 2) {
+        if (h->beam_gexec) { (void)hipGraphExecDestroy(h->beam_gexec); h->beam_gexec = nullptr; }
+        hipGraph_t graph = nullptr;
+        bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
+        if (ok) {
+            const int r0 = enqueue_word(0), r1 = r0 == STATTN_OK ? enqueue_word(1) : r0;
+            const hipError_t e = hipStreamEndCapture(s, &graph);
+            ok = r0 == STATTN_OK && r1 == STATTN_OK && e == hipSuccess && graph != nullptr;
+        }
+        if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (graph) (void)hipGraphDestroy(graph);
+        if (!ok) { gexec = nullptr; (void)hipGetLastError(); }
+        else { h->beam_gexec = gexec; h->beam_gsig = sig; }
+    }
+    int steps_run = 0;
+    int rc_loop = STATTN_OK;
+    for (int st = 0; st < L0;) {
+        if (gexec && st + 2 <= L0) {
+            if (hipGraphLaunch(gexec, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
+            st += 2;
+            ++h->beam_graph_replays;
+        } else {
+            rc_loop = enqueue_word(st & 1);
+            if (rc_loop != STATTN_OK) break;
+            st += 1;
+        }
+        steps_run = st;
+        if (!suppress_eos && (st & 7) == 0 && st < L0) {           // early exit once every video has finished
+            std::vector<int> lv(nvid);
+            if (hipMemcpyAsync(lv.data(), live_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s) != hipSuccess ||
+                hipStreamSynchronize(s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: live-count readback failed"); break; }
+            bool any = false;
+            for (int x : lv) any = any || x > 0;
+            if (!any) break;
+        }
+    }
+    if (rc_loop != STATTN_OK) return rc_loop;
+    // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
+    {
+        std::vector<int> lv(nvid), dv(nvid), ftok((size_t)M * L0), flen(M), ltok((size_t)M * L0);
+        std::vector<float> fsc(M), lsc(M);
+        const int fb = steps_run & 1;     // buffers written by the last executed step
+        HIPCHK(h, hipMemcpyAsync(lv.data(), live_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(dv.data(), dead_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(ftok.data(), fin_tok, (size_t)M * L0 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(flen.data(), fin_len, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(fsc.data(), fin_score, (size_t)M * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(ltok.data(), tok[fb], (size_t)M * L0 * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipMemcpyAsync(lsc.data(), score[fb], (size_t)M * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(h, hipStreamSynchronize(s));
+        for (size_t i = 0; i < (size_t)M * L0; ++i) out_tokens[i] = -1;
+        for (int v = 0; v < nvid; ++v) {
+            int n = 0;
+            for (int j = 0; j < dv[v] && n < k; ++j, ++n) {
+                const int ln = flen[v * k + j];
+                for (int i = 0; i < ln; ++i) out_tokens[((size_t)v * k + n) * L0 + i] = ftok[((size_t)v * k + j) * L0 + i];
+                out_lens[v * k + n] = ln; out_scores[v * k + n] = fsc[v * k + j];
+            }
+            for (int j = 0; j < lv[v] && n < k; ++j, ++n) {
+                for (int i = 0; i < steps_run; ++i) out_tokens[((size_t)v * k + n) * L0 + i] = ltok[((size_t)v * k + j) * L0 + i];
+                out_lens[v * k + n] = steps_run; out_scores[v * k + n] = lsc[v * k + j];
+            }
+            out_count[v] = n;
+            for (int j = n; j < k; ++j) { out_lens[v * k + j] = 0; out_scores[v * k + j] = 0.f; }
+        }
+        // what stattn_beam_final_state hands out: videos whose loop ended early (live count 0) keep the rows saved by
+        // beam_update; the others ran to maxlen and return the gathered states of their live hypotheses (:979-985)
+        h->bf_nvid = nvid; h->bf_k = k; h->bf_live = lv; h->bf_fb = fb;
+    }
+    return STATTN_OK;
+}
+
+int stattn_beam_final_state(stattn_handle* h, float* out_h, float* out_c, int32_t* out_rows) {
+    if (!h || !out_h || !out_c || !out_rows) return fail(h, STATTN_EINVAL, "beam_final_state: bad argument");
+    if (h->bf_nvid <= 0) return fail(h, STATTN_ESTATE, "beam_final_state: no beam search has run");
+    HIPCHK(h, hipSetDevice(h->device));
+    hipStream_t s = h->stream;
+    const int nvid = h->bf_nvid, k = h->bf_k, D = h->D;
+    const size_t n = (size_t)nvid * k * D;
+    std::vector<float> eh(n), ec(n), lh(n), lc(n);
+    std::vector<int> er(nvid);
+    HIPCHK(h, hipMemcpyAsync(eh.data(), findbuf(h, "bs_end_h"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(ec.data(), findbuf(h, "bs_end_c"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(er.data(), findbuf(h, "bs_end_rows"), (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(lh.data(), findbuf(h, "bs_hp"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipMemcpyAsync(lc.data(), findbuf(h, "bs_cp"), n * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(h, hipStreamSynchronize(s));
+    memset(out_h, 0, n * 4); memset(out_c, 0, n * 4);
+    for (int v = 0; v < nvid; ++v) {
+        const bool ended = h->bf_live[v] == 0;
+        const int rows = ended ? er[v] : h->bf_live[v];
+        out_rows[v] = rows;
+        const size_t o = (size_t)v * k * D;
+        memcpy(out_h + o, (ended ? eh.data() : lh.data()) + o, (size_t)rows * D * 4);
+        memcpy(out_c + o, (ended ? ec.data() : lc.data()) + o, (size_t)rows * D * 4);
+    }
+    return STATTN_OK;
+}
+
+}  // extern "C"

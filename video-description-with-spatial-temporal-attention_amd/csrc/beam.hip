@@ -90,7 +90,10 @@ __global__ __launch_bounds__(256) void beam_topk_part_kernel(const BeamArgs a, i
             for (int wd = w0 + tid; wd < w1; wd += 256) {
                 float pr = p[wd];
                 if (a.suppress_eos && wd == 0) pr = 0.f;
-                list_insert(lc, li, hs - logf(pr), j * V + wd);   // hyp_scores[:,None] - log(next_p)  (:921), float32
+                float cst = hs - logf(pr);                        // hyp_scores[:,None] - log(next_p)  (:921), float32
+                if (cst != cst) cst = INFINITY;                   // NaN sorts last like in numpy's argsort (behind every finite
+                                                                  // cost, ties by index) instead of never being selected
+                list_insert(lc, li, cst, j * V + wd);
             }
         }
         block_select(lc, li, n, s_cost, s_idx, s_owner, res_c, res_i);
@@ -121,7 +124,9 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
     }
     __syncthreads();
     if (tid == 0) {
-        const int n = nsel;
+        int n = nsel;
+        for (int r = 0; r < nsel; ++r)                         // fewer candidates than slots (live * V < k - dead): argsort()[:n]
+            if (res_i[r] == 0x7fffffff) { n = r; break; }      // is simply shorter (:923); never index with the sentinel
         int dead = a.dead_k[v], nl = 0;
         for (int r = 0; r < n; ++r) {
             const int ti = res_i[r] / V, wi = res_i[r] % V;    // trans_indices = ranks_flat // voc_size, word_indices = % (:926-927)
@@ -140,7 +145,7 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
             }
         }
         s_n = n; s_ended = 0; s_rows = a.live_k[v];
-        if (n > 0) {
+        if (nsel > 0) {
             a.dead_k[v] = dead;
             const int live = (nl < 1 || dead >= k) ? 0 : nl;   // :974-977
             a.live_k[v] = live;

@@ -26,18 +26,26 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Broadcast)(const void*, void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    std::string err;
+    std::string err, path;
 };
 
+// Resolution order: (1) an RCCL this process ALREADY carries (RTLD_NOLOAD: torch ships its own librccl.so under
+// torch/lib and a second copy of the library in one process would mean two sets of IPC / topology state), (2) the
+// loader path, (3) the ROCm install.  The file that was taken is reported by stattn_comm_library_path() and printed
+// once to stderr by the first stattn_comm_init, so a scaling log shows which RCCL ran.
 Rccl* rccl() {
     static Rccl r;
     if (r.lib || !r.err.empty()) return &r;
-    const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    const char* names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
     for (const char* n : names) {
-        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (r.lib) break;
     }
-    if (!r.lib) { r.err = std::string("cannot load librccl.so.1: ") + dlerror(); return &r; }
+    for (const char* n : names) {
+        if (r.lib) break;
+        r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL);
+    }
+    if (!r.lib) { r.err = std::string("cannot load librccl.so: ") + dlerror(); return &r; }
     auto sym = [&](const char* n) { void* p = dlsym(r.lib, n); if (!p && r.err.empty()) r.err = std::string("librccl lacks ") + n; return p; };
     r.GetUniqueId = reinterpret_cast<decltype(r.GetUniqueId)>(sym("ncclGetUniqueId"));
     r.CommInitRank = reinterpret_cast<decltype(r.CommInitRank)>(sym("ncclCommInitRank"));
@@ -45,7 +53,9 @@ Rccl* rccl() {
     r.AllReduce = reinterpret_cast<decltype(r.AllReduce)>(sym("ncclAllReduce"));
     r.Broadcast = reinterpret_cast<decltype(r.Broadcast)>(sym("ncclBroadcast"));
     r.GetErrorString = reinterpret_cast<decltype(r.GetErrorString)>(sym("ncclGetErrorString"));
-    if (!r.err.empty()) { dlclose(r.lib); r.lib = nullptr; }
+    if (!r.err.empty()) { dlclose(r.lib); r.lib = nullptr; return &r; }
+    Dl_info info{};
+    r.path = (dladdr(reinterpret_cast<void*>(r.AllReduce), &info) && info.dli_fname) ? info.dli_fname : "(unknown)";
     return &r;
 }
 
@@ -66,21 +76,34 @@ namespace stattn_detail {
 int comm_reduce_range(stattn_handle* h, size_t off, size_t n) {
     // (comm_overlap == 2: also with a single rank -- how the event / side-stream path is exercised on a one-GPU box)
     if (!h->comm || !h->comm_overlap || n == 0 || (h->comm_nranks < 2 && h->comm_overlap != 2)) return STATTN_OK;
-    HIPCHK(h, hipEventRecord(h->comm_ready, h->stream));
-    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, h->comm_ready, 0));
+    hipEvent_t ready = h->comm_ready[h->comm_regions & 3];         // an event of its own per region of a pass
+    ++h->comm_regions;
+    HIPCHK(h, hipEventRecord(ready, h->stream));
+    HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ready, 0));
     NCCLCHK(h, rccl()->AllReduce(h->d_grads + off, h->d_grads + off, n, ncclFloat32, ncclSum,
                                  static_cast<ncclComm_t>(h->comm), h->comm_stream));
     h->comm_covered += n;
     return STATTN_OK;
 }
 
-void comm_backward_begins(stattn_handle* h) { h->comm_covered = 0; h->grads_reduced = false; }
+// A new backward pass is about to rewrite the gradient buffer.  If the previous pass handed regions to the side stream
+// and nobody called stattn_allreduce_grads since, those collectives may still be running in place on the same buffer:
+// the compute stream waits for them first.
+int comm_backward_begins(stattn_handle* h) {
+    if (comm_pending(h)) {
+        HIPCHK(h, hipEventRecord(h->comm_done, h->comm_stream));
+        HIPCHK(h, hipStreamWaitEvent(h->stream, h->comm_done, 0));
+    }
+    h->comm_covered = 0; h->comm_regions = 0; h->grads_reduced = false; h->comm_timed = false;
+    return STATTN_OK;
+}
 
 void comm_release(stattn_handle* h) {
     if (h->comm) { (void)rccl()->CommDestroy(static_cast<ncclComm_t>(h->comm)); h->comm = nullptr; }
     if (h->comm_stream) { (void)hipStreamDestroy(h->comm_stream); h->comm_stream = nullptr; }
-    if (h->comm_ready) { (void)hipEventDestroy(h->comm_ready); h->comm_ready = nullptr; }
-    if (h->comm_done) { (void)hipEventDestroy(h->comm_done); h->comm_done = nullptr; }
+    for (hipEvent_t& e : h->comm_ready) if (e) { (void)hipEventDestroy(e); e = nullptr; }
+    for (hipEvent_t* e : {&h->comm_done, &h->comm_t0, &h->comm_t1}) if (*e) { (void)hipEventDestroy(*e); *e = nullptr; }
+    h->comm_covered = 0; h->comm_regions = 0; h->comm_timed = false;
     h->comm_nranks = 1; h->comm_rank = 0;
 }
 
@@ -108,15 +131,33 @@ int stattn_comm_init(stattn_handle* h, int rank, int nranks, const void* id_byte
     HIPCHK(h, hipSetDevice(h->device));
     ncclUniqueId id;
     memcpy(&id, id_bytes, sizeof id);
+    // stream and events first: a handle never holds a communicator without them
+    auto make = [&]() -> int {
+        HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
+        for (hipEvent_t& e : h->comm_ready) HIPCHK(h, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreateWithFlags(&h->comm_done, hipEventDisableTiming));
+        HIPCHK(h, hipEventCreate(&h->comm_t0));
+        HIPCHK(h, hipEventCreate(&h->comm_t1));
+        return STATTN_OK;
+    };
+    if (int rc = make()) { comm_release(h); return rc; }
     ncclComm_t c = nullptr;
-    NCCLCHK(h, r->CommInitRank(&c, nranks, id, rank));
+    const ncclResult_t e = r->CommInitRank(&c, nranks, id, rank);
+    if (e != ncclSuccess) {
+        comm_release(h);
+        return fail(h, STATTN_EHIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, r->GetErrorString(e));
+    }
     h->comm = c; h->comm_rank = rank; h->comm_nranks = nranks;
-    HIPCHK(h, hipStreamCreateWithFlags(&h->comm_stream, hipStreamNonBlocking));
-    HIPCHK(h, hipEventCreateWithFlags(&h->comm_ready, hipEventDisableTiming));
-    HIPCHK(h, hipEventCreateWithFlags(&h->comm_done, hipEventDisableTiming));
     static const char* noov = getenv("STATTN_COMM_NO_OVERLAP");
     h->comm_overlap = noov ? 0 : 1;
+    static bool said = false;
+    if (!said && rank == 0) { said = true; fprintf(stderr, "stattn: RCCL from %s, %d rank(s)\n", r->path.c_str(), nranks); }
     return STATTN_OK;
+}
+
+const char* stattn_comm_library_path(void) {
+    Rccl* r = rccl();
+    return r->lib ? r->path.c_str() : "";
 }
 
 int stattn_comm_destroy(stattn_handle* h) {
@@ -147,6 +188,9 @@ int stattn_allreduce_grads(stattn_handle* h) {
     if (h->grads_reduced) return fail(h, STATTN_ESTATE, "allreduce_grads: this gradient has already been summed over the ranks");
     if (!h->comm || (h->comm_nranks < 2 && h->comm_covered == 0)) { h->grads_reduced = true; return STATTN_OK; }   // single rank: the sum is the buffer
     HIPCHK(h, hipSetDevice(h->device));
+    // comm_t0 .. comm_t1 on the compute stream bracket what the step actually pays for the exchange: the whole
+    // collective when nothing was overlapped, otherwise only the wait for the tail of the side stream
+    HIPCHK(h, hipEventRecord(h->comm_t0, h->stream));
     if (h->comm_covered == 0) {
         // nothing was overlapped: ONE collective over the whole buffer on the compute stream
         NCCLCHK(h, rccl()->AllReduce(h->d_grads, h->d_grads, h->nflat, ncclFloat32, ncclSum, static_cast<ncclComm_t>(h->comm), h->stream));
@@ -157,7 +201,25 @@ int stattn_allreduce_grads(stattn_handle* h) {
         HIPCHK(h, hipEventRecord(h->comm_done, h->comm_stream));
         HIPCHK(h, hipStreamWaitEvent(h->stream, h->comm_done, 0));
     }
+    HIPCHK(h, hipEventRecord(h->comm_t1, h->stream));
+    h->comm_timed = true;
     h->grads_reduced = true;
+    return STATTN_OK;
+}
+
+int stattn_comm_stats(stattn_handle* h, int* nranks, int* overlap, int* regions, float* exposed_ms) {
+    if (!h) return STATTN_EINVAL;
+    if (nranks) *nranks = h->comm ? h->comm_nranks : 0;
+    if (overlap) *overlap = h->comm ? h->comm_overlap : 0;
+    if (regions) *regions = h->comm_regions;
+    if (exposed_ms) {
+        *exposed_ms = 0.f;
+        if (h->comm_timed) {
+            HIPCHK(h, hipSetDevice(h->device));
+            HIPCHK(h, hipEventSynchronize(h->comm_t1));
+            HIPCHK(h, hipEventElapsedTime(exposed_ms, h->comm_t0, h->comm_t1));
+        }
+    }
     return STATTN_OK;
 }
 

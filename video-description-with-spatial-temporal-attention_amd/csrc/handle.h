@@ -45,6 +45,12 @@ struct DevBuf {
 
 enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_COUNT };
 constexpr int KC_GEMM_SEQ = 16;      // the first 16 plain GEMM launches of a forward pass are also timed one by one
+constexpr int KC_BWD_SEQ = 24;       // every LDS-tiled GEMM launch of a backward pass, in launch order
+// kernels of one reverse-scan step and the deferred context-gradient kernel
+enum KBwd { KB_LSTM = 0, KB_PANEL1, KB_TBWD, KB_SPATIAL, KB_REDUCE, KB_PANEL2, KB_CTXGRAD, KB_COUNT };
+constexpr int KC_BWD0 = KC_COUNT + KC_GEMM_SEQ;            // first backward-GEMM slot
+constexpr int KC_KB0 = KC_BWD0 + KC_BWD_SEQ;               // first reverse-scan kernel slot
+constexpr int KC_TOTAL = KC_KB0 + KB_COUNT;
 
 struct Weights {   // device pointers into the flat parameter buffer
     float *Wemb, *ff_state_W, *ff_state_b, *ff_memory_W, *ff_memory_b, *ff_local_W, *ff_local_b,
@@ -97,6 +103,8 @@ struct stattn_handle {
     // deterministic embedding gradient: per batch set, the plan built from the token ids (kernels.h EmbedPlan)
     struct EmbPlanHost { int npieces = 0, nwords = 0, nmulti = 0, ntok = 0; } emb_plan[2];
     void* pin_plan[2] = {nullptr, nullptr}; size_t pin_plan_bytes[2] = {0, 0};   // pinned staging of the plan (stattn_prefetch_batch)
+    hipEvent_t plan_ev[2] = {nullptr, nullptr};   // copy stream: "the H2D copy out of pin_plan[set] has finished"
+    bool plan_ev_valid[2] = {false, false};
 
     // sampler: the resident video (stattn_set_video, or the last f_next call that passed host features).
     // ck_valid: raw features are in HBM; ck_proj: their projections match the current parameters
@@ -123,8 +131,9 @@ struct stattn_handle {
     struct EvPair { hipEvent_t a, b; int cls; };
     std::vector<EvPair> ev_used;
     std::vector<hipEvent_t> ev_pool;
-    double k_ms[KC_COUNT + KC_GEMM_SEQ] = {0};
-    int k_n[KC_COUNT + KC_GEMM_SEQ] = {0};
+    double k_ms[KC_TOTAL] = {0};
+    int k_n[KC_TOTAL] = {0};
+    int bwd_seq = 0;                      // index of the next LDS-tiled GEMM launch within the current backward pass
     int gemm_seq = 0;                     // index of the next plain GEMM launch within the current forward pass
 
     // data parallel (comm.cpp): RCCL communicator of this rank, a side stream for the bucketed gradient reduce
@@ -132,8 +141,11 @@ struct stattn_handle {
     int comm_rank = 0, comm_nranks = 1;
     int comm_overlap = 1;                 // reduce buckets on comm_stream while backward still computes
     hipStream_t comm_stream = nullptr;
-    hipEvent_t comm_ready = nullptr;      // main stream: "this bucket's gradients are final"
+    hipEvent_t comm_ready[4] = {nullptr, nullptr, nullptr, nullptr};   // main stream: "this region's gradients are final" (one per region)
+    int comm_regions = 0;                 // regions handed over in the current backward pass
     hipEvent_t comm_done = nullptr;       // comm stream: "every bucket issued so far has been reduced"
+    hipEvent_t comm_t0 = nullptr, comm_t1 = nullptr;   // compute stream, timed: around the wait inside stattn_allreduce_grads
+    bool comm_timed = false;              // comm_t0 / comm_t1 bracket the last all-reduce
     size_t comm_covered = 0;              // floats of the gradient buffer already handed to the overlapped reduce
     bool grads_reduced = false;           // the gradient buffer holds the SUM over ranks
 };
@@ -189,7 +201,10 @@ inline float* findbuf(stattn_handle* h, const char* name) {
 
 // comm.cpp
 int comm_reduce_range(stattn_handle* h, size_t off, size_t n);
-void comm_backward_begins(stattn_handle* h);
+int comm_backward_begins(stattn_handle* h);
 void comm_release(stattn_handle* h);
+// region all-reduces of the last backward are (possibly) still running on the side stream and stattn_allreduce_grads
+// has not ordered the compute stream behind them: the gradient buffer must not be read, updated from or rewritten
+inline bool comm_pending(const stattn_handle* h) { return h->comm && h->comm_covered != 0 && !h->grads_reduced; }
 
 }  // namespace stattn_detail

@@ -56,18 +56,38 @@ def exchange_token(make_token, rank, world, group=None, path=None):
         return box[0]
     if path is None:
         raise RuntimeError("exchange_token needs an initialised torch.distributed group or a shared file path")
+    # File rendezvous.  Rank 0 writes the token atomically, every other rank acknowledges with `<path>.ack<rank>`, and
+    # rank 0 removes all files once every rank has read: a finished run leaves nothing behind that a later run could
+    # mistake for its own token.  A run that CRASHED in between can: give every run a fresh `path`, or set
+    # STATTN_RENDEZVOUS_ID (folded into the file name) in the launcher.
     import time
+    run_id = os.environ.get("STATTN_RENDEZVOUS_ID")
+    if run_id:
+        path = "%s.%s" % (path, run_id)
     if rank == 0:
+        for f in ["%s.ack%d" % (path, r) for r in range(1, world)]:
+            if os.path.exists(f):
+                os.remove(f)
         tok = make_token()
         with open(path + ".tmp", "wb") as f:
             f.write(tok)
         os.replace(path + ".tmp", path)
+        for _ in range(6000):
+            if all(os.path.exists("%s.ack%d" % (path, r)) for r in range(1, world)):
+                break
+            time.sleep(0.01)
+        else:
+            raise RuntimeError("rendezvous: not every rank picked up %s" % path)
+        for f in [path] + ["%s.ack%d" % (path, r) for r in range(1, world)]:
+            os.remove(f)
         return tok
     for _ in range(6000):
         if os.path.exists(path):
             with open(path, "rb") as f:
                 tok = f.read()
             if len(tok) == 128:
+                with open("%s.ack%d" % (path, rank), "wb") as f:
+                    f.write(b"1")
                 return tok
         time.sleep(0.01)
     raise RuntimeError("rendezvous token %s never appeared" % path)
@@ -76,7 +96,7 @@ def exchange_token(make_token, rank, world, group=None, path=None):
 def init_comm(decoder, rank=None, world=None, group=None, path=None, seed=1234):
     """Bind `decoder` to an RCCL communicator over all ranks, broadcast rank 0's parameters so the replicas start
     identical, and give every rank its own dropout stream (the reference draws one mask per global batch; ranks
-    that shared a seed would repeat the same mask on every shard)."""
+    that shared a seed would repeat the same mask on every shard).  seed=None leaves a single process's seed alone."""
     if rank is None or world is None:
         try:
             import torch.distributed as dist
@@ -87,7 +107,8 @@ def init_comm(decoder, rank=None, world=None, group=None, path=None, seed=1234):
     if world > 1:
         decoder.comm_init(rank, world, exchange_token(decoder.comm_unique_id, rank, world, group, path))
         decoder.broadcast_params(0)
-    decoder.set_seed(seed + rank)
+    if world > 1 or seed is not None:
+        decoder.set_seed((1234 if seed is None else seed) + rank)
     return rank, world
 
 
@@ -98,7 +119,7 @@ class GradReducer(object):
         self.dec = decoder
         _, n = decoder.comm_info()
         if n == 0:
-            init_comm(decoder, rank, world, group, path)
+            init_comm(decoder, rank, world, group, path, seed=None)      # a seed the caller set on one process stays
 
     def allreduce(self):
         self.dec.allreduce_grads()

@@ -262,7 +262,7 @@ class Attention(object):
     def train(self, batches, options, valid_batches=None, max_epochs=1, decay_c=0., alpha_c=0., clip_c=0.,
               patience=10, validFreq=-1, dispFreq=0, save_model_dir=None, reload_=False, from_dir=None, params=None):
         """Minimal counterpart of the optimisation loop of Attention.train (model_attention.py:1239-1517): epochs over
-        `batches` (an iterable of prepare_data() 8-tuples), f_grad_shared + f_update per minibatch with use_noise = 1,
+        `batches` (a re-iterable of prepare_data() 8-tuples, or a callable returning a fresh iterator per epoch), f_grad_shared + f_update per minibatch with use_noise = 1,
         validation NLL with use_noise = 0 (pred_probs), early stopping on it with `patience` (:1494-1503), and the
         reference's checkpoint files: model_best_so_far.npz = numpy.savez(path, history_errs=..., **params)
         (:1488-1490), reloaded with load_params when reload_ (:1109-1113).  Returns (tparams, history_errs)."""
@@ -281,12 +281,20 @@ class Attention(object):
         f_log_probs = self.function(inps, -cost, tparams=tparams)
         f_grad_shared, f_update = self.build_train_functions(tparams, options, decay_c, alpha_c, clip_c)
         best_p, bad_counter, uidx, estop = None, 0, 0, False
-        if iter(batches) is batches:              # a generator would be exhausted after the first epoch
-            batches = list(batches)
-        if valid_batches is not None and iter(valid_batches) is valid_batches:
-            valid_batches = list(valid_batches)
+        # `batches` / `valid_batches`: a re-iterable (list, dataset object) or a callable returning a fresh iterator -- the
+        # way to stream minibatches like the reference does (one prepare_data() 8-tuple alive at a time, :1250-1251).  A
+        # one-shot generator cannot be replayed and holding all of it would keep every batch's features in host memory.
+        def replayable(src, what, uses):
+            if callable(src):
+                return src
+            if iter(src) is src and uses > 1:
+                raise ValueError("%s is a one-shot generator but is needed %s: pass a list / re-iterable, or a callable "
+                                 "that returns a fresh iterator" % (what, "once per epoch" if what == 'batches' else "at every validation"))
+            return lambda: src
+        epoch_batches = replayable(batches, 'batches', max_epochs)
+        valid_iter = replayable(valid_batches, 'valid_batches', 2) if valid_batches is not None else None
         for eidx in range(max_epochs):
-            for batch in batches:
+            for batch in epoch_batches():
                 if batch[0] is None:              # "Minibatch with zero sample under length" (:1252-1254)
                     continue
                 uidx += 1
@@ -299,7 +307,7 @@ class Attention(object):
                     print('Epoch', eidx, 'Update', uidx, 'Train cost', c)
                 if valid_batches is not None and validFreq > 0 and uidx % validFreq == 0:
                     use_noise.set_value(0.)
-                    valid_err = self.pred_probs(valid_batches, f_log_probs)[0]
+                    valid_err = self.pred_probs(valid_iter(), f_log_probs)[0]
                     history_errs.append([eidx, uidx, float(c), float(valid_err)])
                     if best_p is None or valid_err <= numpy.array(history_errs)[:, 3].min():
                         best_p = common.unzip(tparams)

@@ -487,6 +487,8 @@ def main():
     nslab = 3 if dec.lt_mode == 1 else 2              # PL, L (and LW in lt_mode 1)
     slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
     sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
+    if not bf16 and D % 1024 == 0 and B <= 64 and B >= 17 and not os.environ.get("STATTN_NO_RIDER"):
+        sp_bytes += 4.0 * D * 4 * D                   # the riding h.U GEMM streams decoder_U once per launch
     sp_name = "spatial_bf16_kernel" if bf16 else ("spatial2_kernel<128>" if D % 1024 == 0 else "spatial_kernel")
 
     def hbm(name, nbytes, ms, key):
@@ -543,11 +545,13 @@ def main():
                                                            kind, " + ".join("%dx%dx%d" % x_ for x_ in shapes)),
                                              sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in shapes), ms)
         # the reverse-scan chain (one launch of each per decoder step) and the deferred context-gradient kernel
-        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel", B * T * D * (4.0 * 3 * K + 4.0 * 3), bkms["spatial_bwd"][0], "spatial_bwd")
+        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel (+ temporal backward, + riding dhU GEMM)", B * T * D * (4.0 * 3 * K + 4.0 * 9) + 4.0 * 4 * D * D,
+                                     bkms["spatial_bwd"][0], "spatial_bwd")
         kernels["bwd_panel_dctx_dhU"] = mfma("dpre.[Wc^T|U^T] (panel_kernel, K-split)", 2.0 * B * 4 * D * 2 * D, bkms["panel_dctx_dhU"][0], 8.0 * D * D * 4)
         kernels["bwd_panel_dhW"] = mfma("dsproj.[Wd*]^T (panel_kernel, K-split)", 2.0 * B * 4 * D * D, bkms["panel_dhW"][0], 4.0 * D * D * 4)
         for nm in ("lstm_bwd", "temporal_bwd", "reduce_T"):
-            kernels["bwd_" + nm] = dict(kernel=nm, bound="latency", ms_per_launch=bkms[nm][0])
+            if bkms[nm][1]:                           # (temporal_bwd: fused into spatial_bwd, no launches of its own)
+                kernels["bwd_" + nm] = dict(kernel=nm, bound="latency", ms_per_launch=bkms[nm][0])
         kernels["bwd_ctxgrad"] = hbm("ctxgrad_kernel", 4.0 * (B * T * K * D * 5.0 + c["t"] * B * T * D * 2.0), bkms["ctxgrad"][0], "ctxgrad")
         bwd_step_ms = sum(bkms[k_][0] for k_ in ("lstm_bwd", "panel_dctx_dhU", "temporal_bwd", "spatial_bwd", "reduce_T", "panel_dhW"))
     if args.kernel_breakdown and rank == 0:

@@ -258,7 +258,7 @@ int stattn_allreduce_scalars(stattn_handle* h, float* vals, int n);
  * LDS-tiled GEMM in the forward pass; 8 + i = the i-th of those launches alone (i < 16, in launch order: ff_local,
  * ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits);
  * over the last stattn_backward: 24 + i = the i-th LDS-tiled GEMM launch of the pass (i < 24, launch order: da, readout weight
- * gradients, readout input gradients, ... ), 48 .. 54 = lstm_bwd, panel dctx|dhU, temporal_bwd, spatial_bwd, reduce_T, panel dhW
+ * gradients, readout input gradients, ... ), 48 .. 54 = lstm_bwd, panel dctx (|dhU), [temporal_bwd: part of spatial_bwd since round 3, no launches], spatial_bwd, reduce_T, panel dhW
  * (one launch per reverse-scan step each) and the deferred ctxgrad kernel. */
 int stattn_set_profiling(stattn_handle* h, int enable);
 int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches);

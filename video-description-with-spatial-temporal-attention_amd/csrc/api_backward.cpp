@@ -21,7 +21,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
           *L = findbuf(h, "L"), *Mo = findbuf(h, "Mo"), *PG = findbuf(h, "PG"), *PL = findbuf(h, "PL"), *PM = findbuf(h, "PM"),
           *LW = findbuf(h, "LW"), *mean = findbuf(h, "mean"), *emb = findbuf(h, "emb"), *hs = findbuf(h, "hs"),
           *cs = findbuf(h, "cs"), *hd = findbuf(h, "hd"), *ctx = findbuf(h, "ctx"), *csum = findbuf(h, "csum"),
-          *sel = findbuf(h, "sel"), *al = findbuf(h, "alphal"), *ag = findbuf(h, "alphag"), *am = findbuf(h, "alpham"),
+          *sel = findbuf(h, "sel"), *cparts = findbuf(h, "cparts"), *al = findbuf(h, "alphal"), *ag = findbuf(h, "alphag"), *am = findbuf(h, "alpham"),
           *alt = findbuf(h, "alphalt"), *CL = findbuf(h, "CL"), *gates = findbuf(h, "gates"), *sproj = findbuf(h, "sproj"),
           *a1 = findbuf(h, "a1"), *tz = findbuf(h, "tz"), *lg = findbuf(h, "logits"), *pr = findbuf(h, "probs"),
           *dp = findbuf(h, "dp"), *d1 = findbuf(h, "d1"), *d2 = findbuf(h, "d2");
@@ -29,7 +29,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // backward workspaces
     float *da, *dhd, *dctx_r, *demb, *rg, *rm, *rlt, *rl, *sqg, *sqm, *sqlt, *sql, *UT, *WcT, *WdT, *dpre, *dsproj, *dcsum,
           *dselpre, *deg, *dem, *delt, *del, *dplt, *dslp, *dc, *dhp0, *dhp1, *dctxP, *dhUP, *dhWP, *dPL, *dL, *dLW, *dPG,
-          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg, *da_raw, *dsgp, *dsmp;
+          *dPM, *dMo, *pUl, *pUlt, *pUg, *pUm, *cpart, *ws, *dph0, *dpc0, *lossreg, *dsgp, *dsmp;
     const int KZ1 = 8, KZ2 = 16;
     const size_t WS = (size_t)16 << 20;
     CHK(getbuf_t(h, "b_da", R * E, &da));
@@ -53,7 +53,6 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CHK(getbuf_t(h, "b_dslp", MT * D, &dslp));
     CHK(getbuf_t(h, "b_dsgp", MT * D, &dsgp));
     CHK(getbuf_t(h, "b_dsmp", MT * D, &dsmp));
-    CHK(getbuf_t(h, "b_da_raw", 3 * MT, &da_raw));
     CHK(getbuf_t(h, "b_dc", (size_t)m * D, &dc));
     CHK(getbuf_t(h, "b_dhp0", (size_t)m * D, &dhp0)); CHK(getbuf_t(h, "b_dhp1", (size_t)m * D, &dhp1));
     CHK(getbuf_t(h, "b_dctxP", (size_t)KZ1 * m * D, &dctxP));
@@ -61,7 +60,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CHK(getbuf_t(h, "b_dhWP", (size_t)KZ2 * m * D, &dhWP));
     CHK(getbuf_t(h, "b_dPL", MTK * D, &dPL)); CHK(getbuf_t(h, "b_dL", MTK * D, &dL)); CHK(getbuf_t(h, "b_dLW", MTK * D, &dLW));
     CHK(getbuf_t(h, "b_dPG", MT * D, &dPG)); CHK(getbuf_t(h, "b_dPM", MT * D, &dPM)); CHK(getbuf_t(h, "b_dMo", MT * D, &dMo));
-    CHK(getbuf_t(h, "b_pUl", MT * D, &pUl)); CHK(getbuf_t(h, "b_pUlt", MT * D, &pUlt));
+    CHK(getbuf_t(h, "b_pUl", (size_t)ctxgrad_groups(K) * MT * D, &pUl)); CHK(getbuf_t(h, "b_pUlt", MT * D, &pUlt));
     CHK(getbuf_t(h, "b_pUg", MT * D, &pUg)); CHK(getbuf_t(h, "b_pUm", MT * D, &pUm));
     CHK(getbuf_t(h, "b_cpart", (size_t)256 * (size_t)(Vp > 4 * D ? Vp : 4 * D), &cpart));
     CHK(getbuf_t(h, "b_ws", WS, &ws));
@@ -189,8 +188,15 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // copies (skinny kernels)
     BwdPanels bp{};
     const bool panels = use_panels(h, m);
+    // dhU = dpre.U^T feeds only the NEXT reverse step: it rides in the attention launch of this step as extra workgroups
+    // (idle matrix cores of an HBM-bound kernel) instead of lengthening the K-split launch that dctx -- which IS needed
+    // at once -- waits for
+    static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
+    const bool rider = panels && m <= 64 && !norider;
     int kz1 = KZ1, kz2 = KZ2;
     float *dpre_pk = nullptr, *dsproj_pk = nullptr;
+    int kzU = 256 / (D / 16); kzU = kzU < 1 ? 1 : (kzU > KZ1 ? KZ1 : kzU);          // K-slices of the riding dhU GEMM
+    while (kzU > 1 && (4 * D / 16) % kzU) --kzU;
     if (panels) {
         CHK(pack_bwd_panels(h, &bp));
         CHK(getbuf_t(h, "pk_dpre", packed_rows_floats(m, 4 * D), &dpre_pk));
@@ -199,8 +205,10 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, hipMemsetAsync(dpre_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
             HIPCHK(h, hipMemsetAsync(dsproj_pk, 0, packed_rows_floats(m, 4 * D) * sizeof(float), s));
         }
-        // K split so that the launch fills the chip: 2 D / 16 column tiles (dctx | dhU), D / 16 (dhW)
-        kz1 = 256 / (2 * D / 16); kz1 = kz1 < 1 ? 1 : (kz1 > KZ1 ? KZ1 : kz1);
+        // K split so that the launch fills the chip: 2 D / 16 column tiles (dctx | dhU), D / 16 (dhW); with the dhU
+        // half riding in the attention launch (below) the first launch has D / 16 tiles as well
+        kz1 = 256 / ((rider ? 1 : 2) * D / 16); kz1 = kz1 < 1 ? 1 : (kz1 > KZ1 ? KZ1 : kz1);
+        while (kz1 > 1 && (4 * D / 16) % kz1) --kz1;
         kz2 = 256 / (D / 16); kz2 = kz2 < 1 ? 1 : (kz2 > KZ2 ? KZ2 : kz2);
     } else {
         HIPCHK(h, launch_transpose(s, w.U, 4 * D, UT, D, D, 4 * D));
@@ -216,7 +224,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         const bool last = (st == t - 1);
         {
             LstmBwdArgs a{};
-            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = kz1; a.dhW = dhWP; a.nW = kz2;
+            a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = rider ? kzU : kz1; a.dhW = dhWP; a.nW = kz2;
             a.dselpre = dselpre + (r0 + m); a.W_sel = h->opt.selector ? w.W_sel : nullptr;
             a.dhd = dhd + r0 * D; a.d1 = d1 + r0 * D; a.gates = gates + r0 * 4 * D;
             a.c_prev = cs + r0 * D; a.c_new = cs + (r0 + m) * D; a.mask = dmask + r0; a.dp = dp + r0 * 3 * D;
@@ -226,8 +234,8 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         }
         if (panels) {   // dctx = dpre.Wc^T and dhU = dpre.U^T as K-split partials
             PnArgs a{};
-            a.M = m; a.nseg = 2; a.kz = kz1; a.part_stride = (size_t)m * D;
-            for (int i = 0; i < 2; ++i) {
+            a.M = m; a.nseg = rider ? 1 : 2; a.kz = kz1; a.part_stride = (size_t)m * D;
+            for (int i = 0; i < a.nseg; ++i) {
                 PnSeg& sg = a.seg[i];
                 pn_seg_defaults(sg);
                 sg.npairs = 1; sg.p[0] = PnPair{dpre_pk, 4 * D, i == 0 ? bp.WcT : bp.UT, 4 * D, 1};
@@ -247,24 +255,24 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, launch_skinny(s, a));
         }
         {
-            TemporalBwdArgs a{};
-            a.dctxP = dctxP; a.nP = kz1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
-            a.csum = csum + r0 * D; a.sel = sel + r0; a.G = Gc; a.Mo = Mo; a.CL = CL + r0 * T * D;
-            a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
-            a.has_sel = h->opt.selector ? 1 : 0;
-            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0; a.da_raw = da_raw; a.M = m; a.T = T; a.D = D;
-            Prof pr(h, KC_KB0 + KB_TBWD);
-            HIPCHK(h, launch_temporal_bwd(s, a));
-        }
-        {
             SpatialBwdArgs a{};
             a.PL = PL; a.L = L; a.LW = LW; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
-            a.dcsum = dcsum + r0 * D; a.alphal = al + r0 * T * K;
-            a.PG = PG; a.PM = PM; a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T; a.da_raw = da_raw;
+            a.dctxP = dctxP; a.nP = panels ? kz1 : KZ1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
+            a.csum = csum + r0 * D; a.sel = sel + r0; a.has_sel = h->opt.selector ? 1 : 0;
+            a.cparts = cparts + r0 * 3 * D;
+            a.G = Gc; a.Mo = Mo; a.CL = CL + r0 * T * D;
+            a.rg = reg ? rg : nullptr; a.rm = reg ? rm : nullptr; a.rlt = reg ? rlt : nullptr;
+            a.dcsum = dcsum + r0 * D; a.dselpre = dselpre + r0; a.alphal = al + r0 * T * K;
+            a.PG = PG; a.PM = PM; a.ag = ag + r0 * T; a.am = am + r0 * T; a.alt = alt + r0 * T;
             a.Ug = w.Ug; a.Um = w.Um;
             a.deg = deg + r0 * T; a.dem = dem + r0 * T; a.delt = delt + r0 * T; a.dsgp = dsgp; a.dsmp = dsmp;
             a.rl = reg ? rl : nullptr; a.Ul = w.Ul; a.Ult = w.Ult; a.blt = w.blt;
             a.dplt = dplt + r0 * T * D; a.del = del + r0 * T * K; a.dslp = dslp; a.M = m; a.T = T; a.K = K; a.D = D;
+            if (rider) {   // dhU partials [kzU][m][D]: D / 16 tiles x kzU K-slices of the 4D-long contraction
+                RiderArgs& r = a.rider;
+                r.A = dpre_pk; r.P = bp.UT; r.C = dhUP; r.ldc = D; r.add = nullptr; r.ldadd = 0;
+                r.M = m; r.N = D; r.K = 4 * D; r.kz = kzU; r.part_stride = (size_t)m * D; r.nblocks = (D / 16) * kzU;
+            }
             Prof pr(h, KC_KB0 + KB_SPATIAL);
             HIPCHK(h, launch_spatial_bwd(s, a));
         }
@@ -295,7 +303,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // ---- deferred gradients.  Ordered by region of the flat buffer (= dict order) so that a data-parallel rank can
     // hand each region to the overlapped all-reduce as soon as it is final: decoder_* first (its 76 MB travel while
     // the F->D projection gradients -- the largest GEMM of the pass -- are computed), then ff_*, then Wemb.
-    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, kz1, dhWP, kz2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
+    HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, rider ? kzU : kz1, dhWP, kz2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
                                 dph0, dpc0, m, D));
     {
         CtxGradArgs a{};
@@ -308,7 +316,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         HIPCHK(h, launch_ctxgrad(s, a));
     }
     // -- region decoder_*
-    CSADD(pUl, D, (int)MT, D, G_("decoder_Ul_att"), 0, nullptr);
+    CSADD(pUl, D, (int)MT * ctxgrad_groups(K), D, G_("decoder_Ul_att"), 0, nullptr);
     CSADD(pUlt, D, (int)MT, D, G_("decoder_Ult_att"), 0, nullptr);
     CSADD(pUg, D, (int)MT, D, G_("decoder_Ug_att"), 0, nullptr);
     CSADD(pUm, D, (int)MT, D, G_("decoder_Um_att"), 0, nullptr);

@@ -135,7 +135,7 @@ int stattn_forward_train(stattn_handle* h) {
     float* rawm = findbuf(h, bcur(h, "rawm").c_str());
     CtxPtrs c{};
     c.G = findbuf(h, bcur(h, "G").c_str());
-    float *mean, *emb, *xproj, *hs, *cs, *hd, *ctx, *csum, *sel, *al, *ag, *am, *alt, *CL, *gates, *sproj, *preh,
+    float *mean, *emb, *xproj, *hs, *cs, *hd, *ctx, *csum, *cparts, *sel, *al, *ag, *am, *alt, *CL, *gates, *sproj, *preh,
           *eg, *em, *elt, *plt, *z1, *a1, *tz, *lg, *pr, *nll, *cost, *dp, *d1, *d2;
     CHK(getbuf_t(h, "L", (size_t)m * T * K * D, &c.L));
     CHK(getbuf_t(h, "Mo", (size_t)m * T * D, &c.Mo));
@@ -151,6 +151,7 @@ int stattn_forward_train(stattn_handle* h) {
     CHK(getbuf_t(h, "hd", R * D, &hd));
     CHK(getbuf_t(h, "ctx", R * D, &ctx));
     CHK(getbuf_t(h, "csum", R * D, &csum));
+    CHK(getbuf_t(h, "cparts", R * 3 * D, &cparts));
     CHK(getbuf_t(h, "sel", R, &sel));
     CHK(getbuf_t(h, "alphal", R * T * K, &al));
     CHK(getbuf_t(h, "alphag", R * T, &ag));
@@ -229,7 +230,7 @@ int stattn_forward_train(stattn_handle* h) {
         io.alphal = al + r0 * T * K; io.CL = CL + r0 * T * D;
         io.eg = eg + r0 * T; io.em = em + r0 * T; io.elt = elt + r0 * T; io.plt = plt + (h->opt.lt_mode == 0 ? r0 * T * D : 0);
         io.alphag = ag + r0 * T; io.alpham = am + r0 * T; io.alphalt = alt + r0 * T;
-        io.csum = csum + r0 * D; io.sel = sel + r0; io.ctx = ctx + r0 * D;
+        io.csum = csum + r0 * D; io.cparts = cparts + r0 * 3 * D; io.sel = sel + r0; io.ctx = ctx + r0 * D;
         io.h_out = hs + (r0 + m) * D; io.c_out = cs + (r0 + m) * D; io.gates = gates + r0 * 4 * D; io.hd = hd + r0 * D;
         io.pn = panels ? &pn : nullptr;
         io.h_prev_pk = hpk[st & 1]; io.h_out_pk = hpk[(st & 1) ^ 1]; io.ctx_pk = ctxpk;

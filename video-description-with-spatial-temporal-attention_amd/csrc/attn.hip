@@ -16,6 +16,7 @@
 //     ctx[b,:] = sel_b * sum_t (ag_t G[v,t,:] + am_t M[v,t,:] + alt_t CL[b,t,:])
 #include "kernels.h"
 #include "devmath.h"
+#include "panel_inl.h"
 
 #include <cstdlib>
 
@@ -164,8 +165,14 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
     constexpr int NW = NT / 64;
     __shared__ float s_red[NW * 10];
     __shared__ float s_e[KMAX];
+    // the first rider.nblocks workgroups compute the rider GEMM (h.U of this step) instead of an attention item
+    if ((int)blockIdx.x < a.rider.nblocks) {
+        __shared__ __attribute__((aligned(16))) float s_rider[NW * 64 * 16];
+        rider_tile<NW>(a.rider, (int)blockIdx.x, s_rider);
+        return;
+    }
     const int T = a.T, K = a.K, D = a.D;
-    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int bt = (int)blockIdx.x - a.rider.nblocks, b = bt / T, t = bt % T;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
     const size_t slab = ((size_t)v * T + t) * K * D;
@@ -475,7 +482,7 @@ constexpr int TPF = 8;    // frames per wave held in registers (T <= 32); longer
 __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     __shared__ float s_al[3][TMAX];
     __shared__ float s_sel;
-    __shared__ __attribute__((aligned(16))) float s_part[4][256];
+    __shared__ __attribute__((aligned(16))) float s_part[3][4][256];
     const int T = a.T, D = a.D;
     const int b = blockIdx.x, chunk = blockIdx.y;
     const int v = a.vid ? a.vid[b] : b;
@@ -525,35 +532,39 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     }
     __syncthreads();
 
-    // weighted sums over frames: wave w takes t = w, w+4, ...; lane owns 4 consecutive d
-    float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+    // weighted sums over frames: wave w takes t = w, w+4, ...; lane owns 4 consecutive d.  cg, cm, clt are kept apart
+    // (the backward pass needs each of them) and added at the end
+    float4 ac[3];
+#pragma unroll
+    for (int x = 0; x < 3; ++x) ac[x] = make_float4(0.f, 0.f, 0.f, 0.f);
+    auto fma3 = [&](int t, const float4& g, const float4& m, const float4& c) {
+        const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
+        ac[0].x += ag * g.x; ac[0].y += ag * g.y; ac[0].z += ag * g.z; ac[0].w += ag * g.w;
+        ac[1].x += am * m.x; ac[1].y += am * m.y; ac[1].z += am * m.z; ac[1].w += am * m.w;
+        ac[2].x += alt * c.x; ac[2].y += alt * c.y; ac[2].z += alt * c.z; ac[2].w += alt * c.w;
+    };
 #pragma unroll
     for (int i = 0; i < TPF; ++i) {
         const int t = w + 4 * i;
-        if (t < T) {
-            const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
-            acc.x += ag * g4[i].x + am * m4[i].x + alt * c4[i].x;
-            acc.y += ag * g4[i].y + am * m4[i].y + alt * c4[i].y;
-            acc.z += ag * g4[i].z + am * m4[i].z + alt * c4[i].z;
-            acc.w += ag * g4[i].w + am * m4[i].w + alt * c4[i].w;
-        }
+        if (t < T) fma3(t, g4[i], m4[i], c4[i]);
     }
-    for (int t = w + 4 * TPF; t < T; t += 4) {          // frames past the register-held ones (T > 32)
-        const float ag = s_al[0][t], am = s_al[1][t], alt = s_al[2][t];
-        const float4 g = ld4(G + (size_t)t * D), m = ld4(Mo + (size_t)t * D), c = ld4(CL + (size_t)t * D);
-        acc.x += ag * g.x + am * m.x + alt * c.x;
-        acc.y += ag * g.y + am * m.y + alt * c.y;
-        acc.z += ag * g.z + am * m.z + alt * c.z;
-        acc.w += ag * g.w + am * m.w + alt * c.w;
-    }
-    st4(&s_part[w][4 * lane], acc);
+    for (int t = w + 4 * TPF; t < T; t += 4)            // frames past the register-held ones (T > 32)
+        fma3(t, ld4(G + (size_t)t * D), ld4(Mo + (size_t)t * D), ld4(CL + (size_t)t * D));
+#pragma unroll
+    for (int x = 0; x < 3; ++x) st4(&s_part[x][w][4 * lane], ac[x]);
     __syncthreads();
     if (w == 0 && on) {
-        float4 r = ld4(&s_part[0][4 * lane]);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int i = 1; i < 4; ++i) {
-            const float4 q = ld4(&s_part[i][4 * lane]);
-            r.x += q.x; r.y += q.y; r.z += q.z; r.w += q.w;
+        for (int x = 0; x < 3; ++x) {
+            float4 px = ld4(&s_part[x][0][4 * lane]);
+#pragma unroll
+            for (int i = 1; i < 4; ++i) {
+                const float4 q = ld4(&s_part[x][i][4 * lane]);
+                px.x += q.x; px.y += q.y; px.z += q.z; px.w += q.w;
+            }
+            if (a.cparts) st4(a.cparts + ((size_t)x * a.M + b) * D + d, px);
+            r.x += px.x; r.y += px.y; r.z += px.z; r.w += px.w;
         }
         if (a.csum) st4(a.csum + (size_t)b * D + d, r);
         const float sel = s_sel;
@@ -565,9 +576,22 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
 
 }  // namespace
 
+// only spatial2_kernel carries a rider (its 120-VGPR budget covers the rider's 95; spatial_kernel would drop from six to
+// four workgroups per CU, the bf16 and shared-slab kernels are not per-row)
+static bool spatial_shared_path(const SpatialArgs& a) {
+    static const char* noshare = getenv("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
+    return a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= 2048;
+}
+bool spatial_rider_supported(const SpatialArgs& a) {
+    static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
+    static const char* v1 = getenv("STATTN_SPATIAL1");
+    return !norider && !a.bf16 && !spatial_shared_path(a) && a.D % 1024 == 0 && !v1;
+}
+
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
     if (a.M <= 0) return hipSuccess;
     if (a.K > KMAX || a.K < 1 || a.D % 4 != 0) return hipErrorInvalidValue;
+    if (a.rider.nblocks && (!spatial_rider_supported(a) || !rider_shape_ok(a.rider))) return hipErrorInvalidValue;
     if (a.bf16) {
         if (a.D % 8 != 0 || !a.LW) return hipErrorInvalidValue;
         if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
@@ -575,9 +599,8 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
         return hipGetLastError();
     }
     // beam search: the `group` consecutive rows of a video share its region tensors -> one pass over each slab
-    static const char* noshare = getenv("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
     // (worth it once the (video, frame) grid alone fills the chip several times: 104 workgroups at configs[0] do not)
-    if (a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= 2048) {
+    if (spatial_shared_path(a)) {
         const dim3 grid(a.M / a.group * a.T), block(256);
         switch (a.group) {
             case 2: hipLaunchKernelGGL(spatial_shared_kernel<2>, grid, block, 0, s, a); break;
@@ -593,7 +616,7 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
     // D a multiple of 1024: 128-thread workgroups with two columns per thread (all items of configs[1] resident at
     // once: 36 us instead of 41 us per launch there); otherwise the 256-thread kernel, one column per thread
     static const char* v1 = getenv("STATTN_SPATIAL1");          // A/B switch for tools
-    if (a.D % 1024 == 0 && !v1) hipLaunchKernelGGL(spatial2_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
+    if (a.D % 1024 == 0 && !v1) hipLaunchKernelGGL(spatial2_kernel<128>, dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
     else hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();
 }

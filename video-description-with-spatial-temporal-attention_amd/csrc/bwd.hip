@@ -5,8 +5,8 @@
 // Structure.  Inside the reverse time loop only what the recurrence needs is computed:
 //   lstm_bwd  -> dpre (gate pre-activation grads), carried dc, pass-through dh
 //   [skinny GEMM: dctx = dpre.Wc^T, dhU = dpre.U^T]
-//   temporal_bwd -> dcsum, selector grad, d alpha of the three temporal attentions
-//   spatial_bwd  -> dplt, spatial softmax backward (del), per-frame dsl
+//   spatial_bwd  -> dcsum, selector grad, temporal softmax backwards; dplt, spatial softmax backward (del), per-frame dsl
+//                   (+ the riding GEMM dhU = dpre.U^T in extra workgroups)
 //   reduce_T     -> dsl, dslt summed over frames
 //   [skinny GEMM: dhW = dsproj.[Wdl|Wdg|Wdm|Wdlt]^T]
 // Every gradient that accumulates over time WITHOUT feeding the recurrence (dPL, dL, dLW, dPG, dPM,
@@ -15,6 +15,7 @@
 // consume them once after the loop, instead of a read-modify-write of 54 MB tensors in every step.
 #include "kernels.h"
 #include "devmath.h"
+#include "panel_inl.h"
 
 namespace stattn {
 
@@ -134,46 +135,31 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
 
 // ---------------------------------------------------------------------------------------------
 
-// temporal backward, one workgroup per (row b, frame t):
-//   dctx = sum of the GEMM K-slice partials + readout term; selector backward (ctx = sel * csum, :433-435) -> dcsum, dselpre
-//   d alpha = <dcsum, X_t> + regulariser for the three temporal attentions (cg = sum_t ag_t G_t :399, cm :412,
-//   clt = sum_t alt_t CL_t :426)
-// Every frame's workgroup re-forms dcsum of its row from the partials (three 4 KB vectors from L2: cheaper than a
-// separate per-row launch in front, which was 4.8 us + a kernel boundary per step); frame 0 stores it.
-__global__ __launch_bounds__(256) void tbwd_kernel(const TemporalBwdArgs a) {
-    __shared__ float s_red[4 * 4];
-    const int T = a.T, D = a.D, bt = blockIdx.x, b = bt / T, t = bt - b * T, tid = threadIdx.x;
-    const int nd4 = D >> 2;
-    const size_t MD = (size_t)a.M * D;
-    const float sel = a.has_sel ? a.sel[b] : 1.f;
-    float p[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int d4 = tid; d4 < nd4; d4 += 256) {
-        const size_t ob = (size_t)b * D + 4 * d4, o = (size_t)bt * D + 4 * d4;
-        const float4 g4 = ld4(a.G + o), m4 = ld4(a.Mo + o), c4 = ld4(a.CL + o);
-        float4 dc = a.dctx_r ? ld4(a.dctx_r + ob) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 0; q < a.nP; ++q) add4(dc, ld4(a.dctxP + (size_t)q * MD + ob));
-        p[3] += dot4(dc, ld4(a.csum + ob));
-        const float4 dcs = scale4(dc, sel);
-        if (t == 0) st4(a.dcsum + ob, dcs);
-        p[0] += dot4(dcs, g4);
-        p[1] += dot4(dcs, m4);
-        p[2] += dot4(dcs, c4);
-    }
-    block_sum<4>(p, s_red, tid, 4);
-    if (tid < 3) {
-        const float* r = tid == 0 ? a.rg : (tid == 1 ? a.rm : a.rlt);
-        a.da_raw[(size_t)tid * a.M * T + bt] = p[tid] + (r ? r[bt] : 0.f);
-    }
-    if (tid == 3 && t == 0) a.dselpre[b] = a.has_sel ? p[3] * sel * (1.f - sel) : 0.f;
-}
-
-// ---------------------------------------------------------------------------------------------
-
-__global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a) {
+// Attention backward of one step, one workgroup per (row b, frame t).
+//
+// Temporal part (a launch of its own until round 3):
+//   dctx = readout term + the K-slice partials of dpre.Wc^T;  selector backward (ctx = sel * csum, :433-435) -> dcsum, dselpre
+//   d alpha_x[t] = <dcsum, X_t> + regulariser  for the three temporal attentions (cg = sum_t ag_t G_t :399, cm :412,
+//   clt = sum_t alt_t CL_t :426), then the softmax backward  de_x[t] = alpha_x[t] (d alpha_x[t] - <alpha_x, d alpha_x>).
+// The softmax backward looked like a dependency on every frame of the row, but
+//   <alpha_x, d alpha_x> = <dcsum, sum_t alpha_x[t] X_t> + <alpha_x, r_x> = <dcsum, c_x> + <alpha_x, r_x>
+// with c_x the context vector the forward pass formed (TemporalArgs::cparts): one more dot product over D per
+// workgroup and a T-long one over the regulariser terms.  Every frame's workgroup re-forms dcsum of its row from the
+// partials (a few 4 KB vectors from L2); frame 0 stores it for the deferred context gradients.
+//
+// Spatial part: dplt, spatial softmax backward (del), per-frame dsl / dsg / dsm.
+__global__ __launch_bounds__(256, 4) void spatial_bwd_kernel(const SpatialBwdArgs a) {     // 4 waves per SIMD: at most 128 VGPRs
     __shared__ float s_red[4 * 8];
     __shared__ float s_al[KMAX], s_da[KMAX];
+    // the first rider.nblocks workgroups compute the rider GEMM (dhU = dpre.U^T, needed only by the NEXT reverse step's
+    // lstm_bwd) on the matrix cores this HBM-bound kernel leaves idle
+    if ((int)blockIdx.x < a.rider.nblocks) {
+        __shared__ __attribute__((aligned(16))) float s_rider[4 * 64 * 16];
+        rider_tile<4>(a.rider, (int)blockIdx.x, s_rider);
+        return;
+    }
     const int T = a.T, K = a.K, D = a.D;
-    const int bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
+    const int bt = (int)blockIdx.x - a.rider.nblocks, b = bt / T, tid = threadIdx.x;
     const size_t slab = (size_t)bt * K * D;
     const float* __restrict__ PL = a.PL + slab;
     const float* __restrict__ L = a.L + slab;
@@ -182,20 +168,67 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
     const int nd4 = D >> 2;
     __shared__ float s_de[3];
     if (tid < K) s_al[tid] = a.alphal[(size_t)bt * K + tid];
-    // softmax backward of the three temporal attentions for this frame: de_t = alpha_t (dalpha_t - <alpha, dalpha>)
-    // (every (b,t) workgroup redoes the T-long dot product of its row: 3 T floats, wave 0..2)
-    if (tid < 192) {
-        const int w = tid >> 6, lane = tid & 63;
-        const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
-        const float* da = a.da_raw + (size_t)w * a.M * T + (size_t)b * T;
-        float dotp = 0.f;
-        for (int t = lane; t < T; t += 64) dotp += al[t] * da[t];
-        dotp = wave_sum(dotp);
-        if (lane == 0) {
-            const int t = bt - b * T;
-            const float de = al[t] * (da[t] - dotp);
-            s_de[w] = de;
-            (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt))[bt] = de;
+    // The LW rows of this lane's first column group are requested before anything else: they do not depend on the
+    // temporal part below, whose loads / reduction / barrier would otherwise be an exposed latency stage in front of them.
+    // (half of them: all eight would not fit the 128-VGPR budget next to the temporal part's own loads)
+    constexpr int NPF = 4;
+    float4 lw0[NPF];
+    if (K <= 8) {
+#pragma unroll
+        for (int kk = 0; kk < NPF; ++kk) lw0[kk] = ld4(LW + (size_t)min(kk, K - 1) * D + 4 * min(tid, nd4 - 1));
+    }
+    // ---- temporal part
+    const int tf = bt - b * T;
+    const size_t MD = (size_t)a.M * D;
+    const float sel = a.has_sel ? a.sel[b] : 1.f;
+    auto form_dcs = [&](int d4) {          // dcsum[b, 4 d4 ..] = sel * (readout term + partials of dpre.Wc^T)
+        const size_t ob = (size_t)b * D + 4 * d4;
+        float4 dc = a.dctx_r ? ld4(a.dctx_r + ob) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < a.nP; ++q) add4(dc, ld4(a.dctxP + (size_t)q * MD + ob));
+        return dc;
+    };
+    // dcsum of the row is needed again by the spatial part: parked in LDS (D <= 2048), else re-formed from the partials
+    constexpr int DCS_LDS = 2048;
+    __shared__ __attribute__((aligned(16))) float s_dcs[DCS_LDS];
+    const bool dcs_lds = D <= DCS_LDS;
+    {
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = 0.f;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const size_t ob = (size_t)b * D + 4 * d4, o = (size_t)bt * D + 4 * d4;
+            const float4 dc = form_dcs(d4);
+            q[6] += dot4(dc, ld4(a.csum + ob));
+            const float4 dcs = scale4(dc, sel);
+            if (dcs_lds) st4(&s_dcs[4 * d4], dcs);
+            if (tf == 0) st4(a.dcsum + ob, dcs);
+            q[0] += dot4(dcs, ld4(a.G + o));
+            q[1] += dot4(dcs, ld4(a.Mo + o));
+            q[2] += dot4(dcs, ld4(a.CL + o));
+            q[3] += dot4(dcs, ld4(a.cparts + ob));
+            q[4] += dot4(dcs, ld4(a.cparts + MD + ob));
+            q[5] += dot4(dcs, ld4(a.cparts + 2 * MD + ob));
+        }
+        block_sum<8>(q, s_red, tid, 4);
+        // softmax backward of the three temporal attentions for this frame (wave 0..2; the T-long <alpha, r> only with
+        // the regulariser on)
+        if (tid < 192) {
+            const int w = tid >> 6, lane = tid & 63;
+            const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
+            const float* r = w == 0 ? a.rg : (w == 1 ? a.rm : a.rlt);
+            float dotr = 0.f;
+            if (r) {
+                for (int t = lane; t < T; t += 64) dotr += al[t] * r[(size_t)b * T + t];
+                dotr = wave_sum(dotr);
+            }
+            if (lane == 0) {
+                const float da = q[w] + (r ? r[bt] : 0.f);
+                const float de = al[tf] * (da - (q[3 + w] + dotr));
+                s_de[w] = de;
+                (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt))[bt] = de;
+            }
+        } else if (tid == 192 && tf == 0) {
+            a.dselpre[b] = a.has_sel ? q[6] * sel * (1.f - sel) : 0.f;
         }
     }
     __syncthreads();
@@ -219,14 +252,15 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
         for (int d4 = tid; d4 < nd4; d4 += 256) {
             float4 lw[8];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) lw[kk] = ld4(LW + (size_t)min(kk, K - 1) * D + 4 * d4);
+            for (int kk = 0; kk < 8; ++kk)
+                lw[kk] = (kk < NPF && d4 == tid) ? lw0[kk < NPF ? kk : 0] : ld4(LW + (size_t)min(kk, K - 1) * D + 4 * d4);
             float4 pl = ld4(a.blt + 4 * d4);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
             const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
             const float4 dpl = scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt);
             st4(a.dplt + (size_t)bt * D + 4 * d4, dpl);
-            const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
+            const float4 dcl = scale4(dcs_lds ? ld4(&s_dcs[4 * d4]) : scale4(form_dcs(d4), sel), alt);
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk)
                 p[kk] += dot4(dcl, ld4(L + (size_t)min(kk, K - 1) * D + 4 * d4)) + dot4(dpl, lw[kk]);
@@ -248,7 +282,7 @@ __global__ __launch_bounds__(256) void spatial_bwd_kernel(const SpatialBwdArgs a
 #pragma unroll
             for (int i = 0; i < 8; ++i) p[i] = 0.f;
             for (int d4 = tid; d4 < nd4; d4 += 256) {
-                const float4 dcl = scale4(ld4(a.dcsum + (size_t)b * D + 4 * d4), alt);
+                const float4 dcl = scale4(dcs_lds ? ld4(&s_dcs[4 * d4]) : scale4(form_dcs(d4), sel), alt);
                 const float4 dpl = ld4(a.dplt + (size_t)bt * D + 4 * d4);
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
@@ -303,15 +337,25 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 //   dMo      = sum_s am_s dcsum_s
 // and the per-(b,t) partials of dUl, dUlt, dUg, dUm (summed over rows by colsum afterwards).
 
-__global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a) {
+// Work split: NG = ceil(K / 4) workgroups per (b,t) item, each owning four regions over ALL steps; the last group also
+// does the frame-level tensors, group 0 the dUlt partial.  The groups of an item read the same per-step operands
+// (sproj, dcsum, dplt rows: 120 KB per item over the 30 steps).  When one workgroup walked the region groups one after
+// the other, the second walk came 30 steps after the first and found nothing of it in the 4 MB L2 of its XCD (measured:
+// 1.39 GB through the fabric for 0.6 GB of distinct bytes).  Now the groups of an item are separate workgroups placed
+// on the SAME XCD and dispatched together (block n: XCD n % 8 by the round-robin dispatch; item = (n / (8 NG)) * 8 +
+// n % 8, group = (n / 8) % NG), so they run side by side and the second reader hits L2.
+__global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, const int NG) {
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
-    const int bt = blockIdx.x, b = bt / T, tid = threadIdx.x;
+    const int n = blockIdx.x;
+    const int bt = (n / (8 * NG)) * 8 + (n & 7), grp = (n >> 3) % NG;
+    if (bt >= M * T) return;                       // (grid rounded up to whole groups of 8 items)
+    const int b = bt / T, tid = threadIdx.x;
     const int nd4 = D >> 2;
     const size_t slab = (size_t)bt * K * D, MT = (size_t)M * T;
     for (int d4 = tid; d4 < nd4; d4 += 256) {
         const float4 ul = ld4(a.Ul + 4 * d4), blt = ld4(a.blt + 4 * d4);
         // frame-level tensors
-        {
+        if (grp == NG - 1) {
             const size_t fo = (size_t)bt * D + 4 * d4;
             const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
             float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg;
@@ -341,7 +385,8 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a) {
         // kernel whose floor is VALU issue -- 0.4 G tanh -- not bandwidth; 4 at a time re-reads the per-step operands
         // K / 4 times (L2 hits) and runs three waves per SIMD.)
         float4 pul = make_float4(0.f, 0.f, 0.f, 0.f), pult = pul;
-        for (int k0 = 0; k0 < K; k0 += 4) {
+        {
+            const int k0 = 4 * grp;
             float4 pl[4], lw[4], lwx[4], dpl[4], dl[4], dlw[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
@@ -406,8 +451,8 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a) {
                 }
             }
         }
-        st4(a.pUl + (size_t)bt * D + 4 * d4, pul);
-        st4(a.pUlt + (size_t)bt * D + 4 * d4, pult);
+        st4(a.pUl + ((size_t)grp * MT + bt) * D + 4 * d4, pul);        // one partial per region group (summed by the column sums)
+        if (grp == 0) st4(a.pUlt + (size_t)bt * D + 4 * d4, pult);
     }
 }
 
@@ -660,13 +705,11 @@ hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {
     hipLaunchKernelGGL(lstm_bwd_kernel, dim3((unsigned)((n + bs - 1) / bs)), dim3(bs), 0, s, a);
     return hipGetLastError();
 }
-hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a) {
-    hipLaunchKernelGGL(tbwd_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
-    return hipGetLastError();
-}
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     if (a.K > KMAX) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(spatial_bwd_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    if (a.rider.nblocks && !rider_shape_ok(a.rider)) return hipErrorInvalidValue;
+    if (!a.cparts || !a.csum || !a.dctxP || !a.dcsum || !a.dselpre) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(spatial_bwd_kernel, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
@@ -675,8 +718,11 @@ hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, 
     hipLaunchKernelGGL(reduce_T_kernel, dim3(M, 4, (nd4 + 255) / 256), dim3(bx), 0, s, dslp, dsgp, dsmp, dplt, dsproj, lddsp, T, D, dsproj_pk);
     return hipGetLastError();
 }
+int ctxgrad_groups(int K) { return (K + 3) / 4; }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
-    hipLaunchKernelGGL(ctxgrad_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
+    const int NG = ctxgrad_groups(a.K);
+    const int items8 = (a.M * a.T + 7) / 8;
+    hipLaunchKernelGGL(ctxgrad_kernel, dim3(items8 * 8 * NG), dim3(256), 0, s, a, NG);
     return hipGetLastError();
 }
 // dst[n] (+)= sum_r X[r, n]; `part` must hold colsum_parts(rows, N) * N floats

@@ -183,6 +183,21 @@ hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a);
 hipError_t launch_pack_rows(hipStream_t s, const float* src, int ld, int M, int K, float* dst);
 size_t packed_rows_floats(int M, int K);
 
+// "Rider": an independent row-panel GEMM  C[M x N] = A[M x K] . P (+ add)  computed by `nblocks` EXTRA workgroups at
+// the front of the grid of an HBM-bound attention launch, on matrix cores that the attention workgroups leave idle
+// (panel_inl.h rider_tile).  A in the packed activation layout (pn_pack_offset), P = 16-column packed panels
+// (PN_COLS_PLAIN), M <= 64.  nblocks = (N / 16) * kz; kz > 1: raw K-slice partials at C + z * part_stride.
+struct RiderArgs {
+    const float* A; const float* P; float* C; int ldc;
+    const float* add; int ldadd;       // [M,N] added in the epilogue (kz == 1 only), or null
+    int M, N, K, kz; size_t part_stride;
+    int nblocks;                       // 0: no rider
+};
+inline bool rider_shape_ok(const RiderArgs& r) {
+    return r.nblocks > 0 && r.M >= 1 && r.M <= 64 && r.N % 16 == 0 && r.K % 16 == 0 && r.kz >= 1 && r.nblocks == (r.N / 16) * r.kz &&
+           (r.K / 16) % r.kz == 0;
+}
+
 // ----------------------------------------------------------------------------
 // attention kernels (attn.hip)
 // ----------------------------------------------------------------------------
@@ -204,8 +219,10 @@ struct SpatialArgs {
     float* CL;         // [M,T,D]
     float* eg; float* em; float* elt;   // [M,T] raw scores (elt only in lt_mode 1)
     int M, T, K, D;
+    RiderArgs rider;   // optional GEMM computed by extra workgroups of this launch (fp32 per-row kernels only)
 };
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a);
+bool spatial_rider_supported(const SpatialArgs& a);   // would launch_spatial pick a kernel that can carry a rider?
 
 // elt[r] = dot(P[r,:], U) + c   (lt_mode 0, after the CL.Wclt GEMM with fused tanh)
 hipError_t launch_rowdot(hipStream_t s, const float* P, int ldp, const float* U, const float* c,
@@ -219,6 +236,7 @@ struct TemporalArgs {
     const float* h_prev; const float* W_sel; const float* b_sel;  // selector (null W_sel => none)
     float* alphag; float* alpham; float* alphalt;         // [M,T]
     float* csum;       // [M,D] cg+cm+clt before the gate (for backward), or null
+    float* cparts;     // [3][M,D] cg, cm, clt on their own (training: the backward pass needs <dcsum, c_x>), or null
     float* sel;        // [M] or null
     float* ctx;        // [M,D]
     float* ctx_pk;     // optional: ctx once more in the packed A layout of the row-panel LSTM kernel (pn_pack_offset)
@@ -264,28 +282,22 @@ struct LstmBwdArgs {
     int M, D, last;
 };
 
-struct TemporalBwdArgs {
-    const float* dctxP; int nP;           // partials of dpre.Wc^T  [nP][M,D]
-    const float* dctx_r;                  // [M,D] readout gradient wrt ctx (null if !ctx2out)
-    const float* csum; const float* sel;  // forward: [M,D], [M]
-    const float* G; const float* Mo;      // [M,T,D]
-    const float* CL;                      // [M,T,D] of this step
-    const float* rg; const float* rm; const float* rlt;   // [M,T] regulariser terms
-    int has_sel;
-    float* dcsum;                         // [M,D]
-    float* dselpre;                       // [M]
-    float* da_raw;                        // [3][M,T] d alpha (g, m, lt) before the softmax backward
-    int M, T, D;
-};
-
 struct SpatialBwdArgs {
     const float* PL; const float* L; const float* LW;     // [M,T,K,D]
     const float* sproj; int ldsp;
-    const float* dcsum;                                   // [M,D]
+    // temporal part (was a launch of its own): dctx = readout term + K-slice partials of dpre.Wc^T, selector backward,
+    // d alpha of the three temporal attentions and their softmax backward
+    const float* dctxP; int nP;                           // partials of dpre.Wc^T  [nP][M,D]
+    const float* dctx_r;                                  // [M,D] readout gradient wrt ctx (null if !ctx2out)
+    const float* csum; const float* sel; int has_sel;     // forward: [M,D] cg+cm+clt, [M] selector gate
+    const float* cparts;                                  // forward: [3][M,D] cg, cm, clt
+    const float* G; const float* Mo; const float* CL;     // [M,T,D] (CL of this step)
+    const float* rg; const float* rm; const float* rlt;   // [M,T] regulariser terms d/d alpha, or null
+    float* dcsum;                                         // [M,D] out (kept for the deferred context gradients)
+    float* dselpre;                                       // [M] out
     const float* alphal;                                  // [M,T,K]
     const float* PG; const float* PM;                     // [M,T,D]
     const float* ag; const float* am; const float* alt;   // [M,T] forward temporal attention weights
-    const float* da_raw;                                  // [3][M,T] from tbwd1
     const float* Ug; const float* Um;
     float* deg; float* dem; float* delt;                  // [M,T] out: temporal softmax backward
     float* dsgp; float* dsmp;                             // [M,T,D] out: per-frame dsg / dsm
@@ -295,6 +307,7 @@ struct SpatialBwdArgs {
     float* del;                                           // [M,T,K]
     float* dslp;                                          // [M,T,D] per-frame dsl
     int M, T, K, D;
+    RiderArgs rider;   // optional GEMM computed by extra workgroups of this launch
 };
 
 struct CtxGradArgs {
@@ -307,7 +320,8 @@ struct CtxGradArgs {
     const float* Ul; const float* Ult; const float* Ug; const float* Um; const float* blt;
     float* dPL; float* dL; float* dLW;         // [M,T,K,D]
     float* dPG; float* dPM; float* dMo;        // [M,T,D]
-    float* pUl; float* pUlt; float* pUg; float* pUm;   // [M*T, D] partials
+    float* pUl;                                // [ctxgrad_groups(K)][M*T, D] partials, one block per region group
+    float* pUlt; float* pUg; float* pUm;       // [M*T, D] partials
     int S, M, T, K, D;
 };
 
@@ -315,11 +329,11 @@ hipError_t launch_dlogit(hipStream_t s, const float* probs, int ldp, const int64
                          float* dl, int ldd, int rows, int V, int Vp);
 hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* sq, int steps, size_t n, float coef);
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a);
-hipError_t launch_temporal_bwd(hipStream_t s, const TemporalBwdArgs& a);
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a);
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
                            float* dsproj, int lddsp, int M, int T, int D, float* dsproj_pk = nullptr);
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a);
+int ctxgrad_groups(int K);    // region groups (= workgroups per (row, frame) item, = blocks of pUl)
 int colsum_parts(int rows, int N);
 hipError_t launch_colsum(hipStream_t s, const float* X, int ldx, int rows, int N, float* part, float* dst, int accumulate,
                          const float* row_weights = nullptr);

@@ -25,17 +25,11 @@
 // Block = MG row groups x KS K-slices waves; a wave holds MT m-tiles x NT n-tiles of accumulators and walks every
 // KS-th k-step with a three-deep register ring (two steps of loads in flight behind the MFMAs).  K-slices are
 // reduced through LDS in a fixed order (deterministic), then the epilogue runs once.
-#include "kernels.h"
-#include "devmath.h"
+#include "panel_inl.h"
 
 namespace stattn {
 
-// Timeline probe (tools/panel_probe.hip builds this file with -DSTATTN_PROBES): wave 0 of every workgroup stamps the
-// 100 MHz wall clock at the phase boundaries.  Compiled out of the product.
 #ifdef STATTN_PROBES
-#ifndef PN_VARIANT
-#define PN_VARIANT 0                // compile-time ablations: 1 A read as a packed stream, 2 no MFMAs, 3 no A loads, 4 no B loads
-#endif
 __device__ long long* pn_probe = nullptr;
 #define PN_STAMP(i) do { if (pn_probe && threadIdx.x == 0) pn_probe[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memrealtime(); } while (0)
 #else
@@ -43,114 +37,6 @@ __device__ long long* pn_probe = nullptr;
 #endif
 
 namespace {
-
-template <int MT, int NT>
-struct PnOps { float4 a[MT]; float4 b[NT]; };
-
-// s = logical k-step; the physical one is rotated by `rot` (see pn_rotation)
-template <int MT, int NT>
-__device__ __forceinline__ void pn_load(PnOps<MT, NT>& o, const float* const (&Ap)[MT], int astep, const float* __restrict__ Bp,
-                                        size_t tile_floats, int s, int rot, int nsteps) {
-    s += rot;
-    s = s >= nsteps ? s - nsteps : s;
-#if !(defined(STATTN_PROBES) && (PN_VARIANT == 4 || PN_VARIANT == 5))
-#pragma unroll
-    for (int i = 0; i < NT; ++i) o.b[i] = ld4(Bp + (size_t)i * tile_floats + (size_t)s * 256);
-#endif
-#if defined(STATTN_PROBES) && (PN_VARIANT == 3 || PN_VARIANT == 5)
-    return;
-#endif
-#pragma unroll
-    for (int i = 0; i < MT; ++i) o.a[i] = ld4(Ap[i] + (size_t)astep * s);
-}
-
-template <int MT, int NT>
-__device__ __forceinline__ void pn_mfma(f32x4 (&acc)[MT][NT], const PnOps<MT, NT>& o) {
-#if defined(STATTN_PROBES) && PN_VARIANT == 2
-    asm volatile("" :: "v"(o.a[0].x), "v"(o.b[0].x), "v"(o.a[MT - 1].w), "v"(o.b[NT - 1].w)); return;
-#endif
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-        for (int i = 0; i < MT; ++i)
-#pragma unroll
-            for (int n = 0; n < NT; ++n)
-                acc[i][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(o.a[i][q], o.b[n][q], acc[i][n], 0, 0, 0);
-}
-
-// acc += A[rows of this wave, K-steps s0, s0 + stride, ...] . panel
-// Ap[i]: row pointer of m-tile i (+ 4 g), Bp: packed panel of the first column tile (+ 4 lane), nsteps = K / 16.
-//
-// What bounds these kernels is memory-level parallelism, not bandwidth (tools/panel_probe.hip): the weight panel of a
-// workgroup comes from HBM / Infinity Cache with ~2 us of loaded latency, so a wave that keeps two or three k-steps in
-// flight moves ~8 KB/us per CU and the loop takes three times its MFMA time.  Hence a ring of R k-steps of operands in
-// registers: every load of the first R steps is issued before the first MFMA (for K = 1024 and eight K-slice waves
-// that is the wave's whole share: the launch is one burst of loads followed by MFMAs), and a slot is refilled R steps
-// ahead as soon as its MFMAs have been issued.
-// The refills are unconditional: past the last step they re-request it (an L1 hit) -- a branch around the loads
-// would make the compiler merge wait counts over both paths and drain the queue.  ONESHOT (the wave has at most R
-// steps) compiles the refills out.
-template <int MT, int NT, int R, bool ONESHOT>
-__device__ __forceinline__ void pn_accumulate(f32x4 (&acc)[MT][NT], const float* const (&Ap)[MT], int astep,
-                                              const float* __restrict__ Bp, size_t tile_floats, int nsteps, int s0, int stride, int rot) {
-    if (s0 >= nsteps) return;
-    const int n = (nsteps - s0 + stride - 1) / stride;         // steps of this wave
-    const int last = s0 + (n - 1) * stride;
-    PnOps<MT, NT> ring[R];
-#pragma unroll
-    for (int u = 0; u < R; ++u) pn_load(ring[u], Ap, astep, Bp, tile_floats, min(s0 + u * stride, last), rot, nsteps);
-    int base = 0;
-    if (!ONESHOT) {
-        for (; base + 2 * R <= n; base += R) {   // groups whose refills are all real; no branch between loads and MFMAs
-            const int sb = s0 + base * stride;
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                __builtin_amdgcn_sched_barrier(0);
-                pn_mfma(acc, ring[u]);
-                __builtin_amdgcn_sched_barrier(0);
-                pn_load(ring[u], Ap, astep, Bp, tile_floats, sb + (u + R) * stride, rot, nsteps);
-            }
-        }
-        if (base + R < n) {                      // one more refilling group when a partial group follows (clamped refills)
-            const int sb = s0 + base * stride;
-#pragma unroll
-            for (int u = 0; u < R; ++u) {
-                __builtin_amdgcn_sched_barrier(0);
-                pn_mfma(acc, ring[u]);
-                __builtin_amdgcn_sched_barrier(0);
-                pn_load(ring[u], Ap, astep, Bp, tile_floats, min(sb + (u + R) * stride, last), rot, nsteps);
-            }
-            base += R;
-        }
-    }
-    const int rem = n - base;                     // last group: its operands are in the ring, nothing is refilled
-#pragma unroll
-    for (int u = 0; u < R; ++u) {
-        if (u >= rem) break;
-        __builtin_amdgcn_sched_barrier(0);
-        pn_mfma(acc, ring[u]);
-        __builtin_amdgcn_sched_barrier(0);
-    }
-}
-
-// Every workgroup walks its panel in the same k order at the same time.  Unrotated, the 256 CUs would request the same
-// offset of 256 panels that lie a power of two apart (one HBM / L2 channel at a time: the weight stream ran at 2 TB/s)
-// and the same lines of A (32 CUs of an XCD on one L2 channel).  Rotating the k order per workgroup -- by its index
-// within the XCD plus 8 per XCD -- spreads both over the channels; it only permutes the summation order.
-__device__ __forceinline__ int pn_rotation(int block, int nsteps) { return ((block >> 3) + ((block & 7) << 3)) % nsteps; }
-
-// 16x16 C/D map: col = lane & 15, row = 4 (lane >> 4) + r.  red[ks][row][col], row pitch CB.
-template <int MT, int NT>
-__device__ __forceinline__ void pn_spill(float* red, int RB, int ks, int mg, const f32x4 (&acc)[MT][NT], int j, int g) {
-    constexpr int CB = 16 * NT;
-#pragma unroll
-    for (int i = 0; i < MT; ++i)
-#pragma unroll
-        for (int n = 0; n < NT; ++n)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-                red[((size_t)ks * RB + (mg * MT + i) * 16 + 4 * g + r) * CB + n * 16 + j] = acc[i][n][r];
-}
 
 // ---- general grouped GEMM with fused epilogue ------------------------------------------------------------
 template <int MT, int NT, int MAXT, int R, bool ONESHOT>

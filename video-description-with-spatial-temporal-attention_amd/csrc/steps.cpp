@@ -253,10 +253,17 @@ int pack_bwd_panels(stattn_handle* h, BwdPanels* p) {
 int run_step(stattn_handle* h, const StepIO& io) {
     const int D = h->D, E = h->E;
     const Weights& w = h->w;
+    // h.U (+ x_) is not needed before the LSTM kernel: when the attention launch can carry it as a rider (extra
+    // workgroups on the idle matrix cores of the HBM-bound kernel), the state-projection launch -- which IS on the
+    // critical path -- shrinks to h.[Wdl|Wdg|Wdm|Wdlt]
+    SpatialArgs sa{};
+    sa.bf16 = h->opt.precision == 1; sa.group = h->opt.precision != 1 ? io.group : 0;
+    sa.M = io.M; sa.T = io.T; sa.K = io.K; sa.D = D;
+    const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && spatial_rider_supported(sa);
     if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
         Prof pr(h, KC_HPROJ);
         PnArgs a{};
-        a.M = io.M; a.nseg = 2;
+        a.M = io.M; a.nseg = rider ? 1 : 2;
         PnSeg& s0 = a.seg[0];
         pn_seg_defaults(s0);
         const PnPair hA = io.h_prev_pk ? PnPair{io.h_prev_pk, D, nullptr, D, 1} : PnPair{io.h_prev, D, nullptr, D, 0};
@@ -294,6 +301,12 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.PG = io.c.PG; a.PM = io.c.PM; a.vid = io.vid;
         a.group = h->opt.precision != 1 ? io.group : 0;
         a.sproj = io.sproj; a.ldsp = 4 * D;
+        if (rider) {   // preh = h.U (+ x_): 4D / 16 tiles, one K-slice
+            RiderArgs& r = a.rider;
+            r.A = io.h_prev_pk; r.P = io.pn->U; r.C = io.preh; r.ldc = 4 * D;
+            r.add = io.xproj; r.ldadd = 4 * D;
+            r.M = io.M; r.N = 4 * D; r.K = D; r.kz = 1; r.part_stride = 0; r.nblocks = 4 * D / 16;
+        }
         a.Ul = w.Ul; a.cl = w.cl; a.Ug = w.Ug; a.cg = w.cg; a.Um = w.Um; a.cm = w.cm;
         a.Ult = w.Ult; a.clt = w.clt; a.blt = w.blt;
         a.alphal = io.alphal; a.CL = io.CL; a.eg = io.eg; a.em = io.em; a.elt = io.elt;
@@ -316,7 +329,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.eg = io.eg; a.em = io.em; a.elt = io.elt; a.G = io.c.G; a.Mo = io.c.Mo; a.vid = io.vid; a.CL = io.CL;
         a.h_prev = io.h_prev; a.W_sel = h->opt.selector ? w.W_sel : nullptr; a.b_sel = w.b_sel;
         a.alphag = io.alphag; a.alpham = io.alpham; a.alphalt = io.alphalt;
-        a.csum = io.csum; a.sel = io.sel; a.ctx = io.ctx; a.ctx_pk = io.pn ? io.ctx_pk : nullptr;
+        a.csum = io.csum; a.cparts = io.cparts; a.sel = io.sel; a.ctx = io.ctx; a.ctx_pk = io.pn ? io.ctx_pk : nullptr;
         a.M = io.M; a.T = io.T; a.D = D;
         HIPCHK(h, launch_temporal(h->stream, a));
     }

@@ -58,6 +58,7 @@ struct StepIO {
     const float* emb;                // [M,E]  (sampling: third LSTM pair) or null
     const float* dp; const float* mask; const float* d1;
     float *alphal, *CL, *eg, *em, *elt, *plt, *alphag, *alpham, *alphalt, *csum, *sel, *ctx;
+    float* cparts;                   // training: [3][M][D] cg, cm, clt of this step (or null)
     float *h_out, *c_out, *gates, *hd;
     const FwdPanels* pn;             // packed weight panels, or null -> the 64-column skinny kernels
     const float* h_prev_pk;          // with pn: h_prev in the packed A layout (or null: plain rows are gathered)

@@ -160,6 +160,7 @@ void stattn_destroy(stattn_handle* h) {
     if (h->comm_stream) (void)hipStreamSynchronize(h->comm_stream);
     comm_release(h);
     if (h->beam_gexec) (void)hipGraphExecDestroy(h->beam_gexec);
+    if (h->beam_gexec8) (void)hipGraphExecDestroy(h->beam_gexec8);
     if (h->pin_io) (void)hipHostFree(h->pin_io);
     if (h->pin_plan[0]) (void)hipHostFree(h->pin_plan[0]);
     if (h->pin_plan[1]) (void)hipHostFree(h->pin_plan[1]);

@@ -339,6 +339,42 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         for (float* q : {emb_pk, a1_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, E) * sizeof(float), s));
         HIPCHK(h, launch_pack_rows(s, hp, D, M, D, hp_pk));          // initial states; later words: beam_update's gather
     }
+    // Small batches (<= 16 rows: the reference's own evaluation decodes ONE video at a time, metrics.py:121-135) are
+    // launch-latency bound -- each of the ten launches of a word costs 5-11 us however little it computes.  Their word is
+    // six launches: attention, temporal fuse, LSTM, [readout layer 1 | state projections of the NEXT word] in one
+    // row-panel launch (both only need the new h; the projections are linear in h, so beam_update gathers their rows
+    // with the hypotheses instead of recomputing them), logits with the vocabulary statistics in the epilogue (tile
+    // max / sum-exp / best candidates: no logits or probabilities are stored, no softmax or top-k launch), update.
+    static const char* nosmall = getenv("STATTN_BEAM_NOSMALL");       // A/B switch for tools
+    const bool small = panels && M <= 16 && h->opt.precision != 1 && !nosmall;
+    float *proj = nullptr, *proj_step = nullptr, *ho_pk = nullptr, *vstats = nullptr;
+    int vtile = 0;
+    PnArgs lgargs{};
+    if (small) {
+        CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
+        CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
+        HIPCHK(h, hipMemsetAsync(ho_pk, 0, packed_rows_floats(M, D) * sizeof(float), s));
+        // the logits launch (same arguments for every word)
+        lgargs.M = M; lgargs.nseg = 1;
+        PnSeg& so = lgargs.seg[0];
+        pn_seg_defaults(so);
+        so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
+        so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+        so.stats_V = V; so.stats_kb = k; so.stats_skip0 = suppress_eos ? 1 : 0;
+        vtile = Vp / panel_tile_cols(lgargs);
+        CHK(getbuf_t(h, "bs_vstats", (size_t)M * vtile * PN_STATS_REC, &vstats));
+        so.stats = vstats;
+        // state projections of the first word from the initial states
+        PnArgs a{};
+        a.M = M; a.nseg = 2;
+        for (int i = 0; i < 2; ++i) {
+            PnSeg& sg = a.seg[i];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{hp_pk, D, i == 0 ? pn.Wd : pn.U, D, 1};
+            sg.C = proj + (size_t)i * 4 * D; sg.ldc = 8 * D; sg.N = 4 * D;
+        }
+        HIPCHK(h, launch_panel(s, a));
+    }
     // first word: no previous word, zero embedding (:803-804); afterwards beam_update writes the embedding of the
     // word it selects (no lookup launch inside the loop)
     HIPCHK(h, hipMemsetAsync(emb, 0, (size_t)M * E * sizeof(float), s));
@@ -355,8 +391,30 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
         io.pn = panels ? &pn : nullptr;
         io.h_prev_pk = hp_pk; io.h_out_pk = nullptr; io.ctx_pk = ctx_pk; io.emb_pk = emb_pk; io.hd_pk = hd_pk;
+        if (small) {       // projections of this word are in `proj` ([sproj | preh] per row); the LSTM also packs the new h
+            io.skip_hproj = true; io.sproj = proj; io.preh = proj + (size_t)4 * D; io.ldproj = 8 * D; io.h_out_pk = ho_pk;
+        }
         CHK(run_step(h, io));
-        if (panels) {      // readout (:817-838) on the row-panel kernel
+        if (small) {       // readout layer 1 + the next word's state projections (before the beam is re-ordered), then logits -> statistics
+            PnArgs a{};
+            a.M = M; a.nseg = 3;
+            PnSeg& sg = a.seg[0];
+            pn_seg_defaults(sg);
+            sg.npairs = 1; sg.p[0] = PnPair{hd_pk, D, pn.Wl1, D, 1};
+            if (h->opt.ctx2out) { sg.p[1] = PnPair{ctx_pk, D, pn.Wl2, D, 1}; sg.npairs = 2; sg.bias2 = w.bl2; }
+            sg.Cpk = a1_pk;
+            sg.bias = w.bl1;
+            if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
+            sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
+            for (int i = 0; i < 2; ++i) {
+                PnSeg& sp = a.seg[1 + i];
+                pn_seg_defaults(sp);
+                sp.npairs = 1; sp.p[0] = PnPair{ho_pk, D, i == 0 ? pn.Wd : pn.U, D, 1};
+                sp.C = proj_step + (size_t)i * 4 * D; sp.ldc = 8 * D; sp.N = 4 * D;
+            }
+            HIPCHK(h, launch_panel(s, a));
+            HIPCHK(h, launch_panel(s, lgargs));
+        } else if (panels) {      // readout (:817-838) on the row-panel kernel
             PnArgs a{};
             a.M = M; a.nseg = 1;
             PnSeg& sg = a.seg[0];
@@ -405,14 +463,20 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
-        HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
+        if (small) {
+            ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile;
+            ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D;
+        } else {
+            HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
+        }
         HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
     HIPCHK(h, hipMemsetAsync(d_step, 0, sizeof(int), s));
 
-    // The launch-bound inner loop is captured once as a hipGraph of TWO words (even + odd parity) and replayed; the
-    // host only comes back every 8 words to see whether every video has finished.  Falls back to eager launches if
+    // The launch-bound inner loop is captured once as hipGraphs of EIGHT and of TWO words (even + odd parity alternate)
+    // and replayed -- a replay costs 10-16 us of host / front-end time whatever it holds, so the long graph carries the
+    // bulk and the short one the remainder; the host only comes back every 8 words to see whether every video has finished.  Falls back to eager launches if
     // the capture is refused (or STATTN_BEAM_NOGRAPH is set, for A/B runs).
     hipGraphExec_t gexec = nullptr;
     static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
@@ -431,28 +495,42 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                           (const void*)pr, (const void*)d_step, (const void*)tk_cost, (const void*)tk_idx, (const void*)pn.Wd,
                           (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
                           (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows, (const void*)hp_pk,
-                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket})
+                          (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket,
+                          (const void*)proj, (const void*)proj_step, (const void*)ho_pk, (const void*)vstats})
         sig.push_back((uintptr_t)q);
-    if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
-        gexec = h->beam_gexec;                                   // same buffers and shapes as last time: replay as is
-    } else if (!nograph && !h->profiling && L0 >= 2) {
-        if (h->beam_gexec) { (void)hipGraphExecDestroy(h->beam_gexec); h->beam_gexec = nullptr; }
+    hipGraphExec_t gexec8 = nullptr;
+    auto capture = [&](int nwords) -> hipGraphExec_t {
         hipGraph_t graph = nullptr;
+        hipGraphExec_t ge = nullptr;
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
-            const int r0 = enqueue_word(0), r1 = r0 == STATTN_OK ? enqueue_word(1) : r0;
+            int r = STATTN_OK;
+            for (int i = 0; i < nwords && r == STATTN_OK; ++i) r = enqueue_word(i & 1);
             const hipError_t e = hipStreamEndCapture(s, &graph);
-            ok = r0 == STATTN_OK && r1 == STATTN_OK && e == hipSuccess && graph != nullptr;
+            ok = r == STATTN_OK && e == hipSuccess && graph != nullptr;
         }
-        if (ok) ok = hipGraphInstantiate(&gexec, graph, nullptr, nullptr, 0) == hipSuccess;
+        if (ok) ok = hipGraphInstantiate(&ge, graph, nullptr, nullptr, 0) == hipSuccess;
         if (graph) (void)hipGraphDestroy(graph);
-        if (!ok) { gexec = nullptr; (void)hipGetLastError(); }
-        else { h->beam_gexec = gexec; h->beam_gsig = sig; }
+        if (!ok) { ge = nullptr; (void)hipGetLastError(); }
+        return ge;
+    };
+    if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
+        gexec = h->beam_gexec; gexec8 = h->beam_gexec8;          // same buffers and shapes as last time: replay as is
+    } else if (!nograph && !h->profiling && L0 >= 2) {
+        if (h->beam_gexec) { (void)hipGraphExecDestroy(h->beam_gexec); h->beam_gexec = nullptr; }
+        if (h->beam_gexec8) { (void)hipGraphExecDestroy(h->beam_gexec8); h->beam_gexec8 = nullptr; }
+        gexec = capture(2);
+        if (gexec && L0 >= 8) gexec8 = capture(8);
+        if (gexec) { h->beam_gexec = gexec; h->beam_gexec8 = gexec8; h->beam_gsig = sig; }
     }
     int steps_run = 0;
     int rc_loop = STATTN_OK;
     for (int st = 0; st < L0;) {
-        if (gexec && st + 2 <= L0) {
+        if (gexec8 && (st & 1) == 0 && st + 8 <= L0) {
+            if (hipGraphLaunch(gexec8, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
+            st += 8;
+            ++h->beam_graph_replays;
+        } else if (gexec && (st & 1) == 0 && st + 2 <= L0) {
             if (hipGraphLaunch(gexec, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
             st += 2;
             ++h->beam_graph_replays;

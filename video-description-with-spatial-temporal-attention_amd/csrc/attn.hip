@@ -253,6 +253,76 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
     }
 }
 
+// Small grids (decode: a handful of rows; M T workgroups do not even fill the chip): latency is all that counts, so
+// a lane requests EVERYTHING it will ever need -- its column of PL, L and LW for all K <= 8 regions, 24 float4 -- in one
+// burst and the kernel is a single memory round trip (the kernels above wait for the softmax before they ask for L / LW).
+// One float4 column per lane: D <= 4 * blockDim.
+__global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a) {
+    __shared__ float s_red[4 * 10];
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int v = a.vid ? a.vid[b] : b;
+    const int tid = threadIdx.x, nw = blockDim.x >> 6;
+    const int d4 = min(tid, (D >> 2) - 1);
+    const float on = tid < (D >> 2) ? 1.f : 0.f;
+    const size_t slab = ((size_t)v * T + t) * K * D, fo = ((size_t)v * T + t) * D + 4 * d4;
+    const float* __restrict__ sl = a.sproj + (size_t)b * a.ldsp;
+    float4 pl[8], l[8], lw[8];
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const size_t o = slab + (size_t)min(kk, K - 1) * D + 4 * d4;
+        pl[kk] = ld4(a.PL + o); l[kk] = ld4(a.L + o);
+        lw[kk] = a.LW ? ld4(a.LW + o) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
+    const float4 s0 = ld4(sl + 4 * d4), s1 = ld4(sl + D + 4 * d4), s2 = ld4(sl + 2 * D + 4 * d4), s3 = ld4(sl + 3 * D + 4 * d4);
+    float p[10];
+    {
+        const float4 u4 = ld4(a.Ul + 4 * d4);
+#pragma unroll
+        for (int kk = 0; kk < 8; ++kk) p[kk] = on * dot4_tanh(pl[kk], s0, u4);
+        p[8] = on * dot4_tanh(pg, s1, ld4(a.Ug + 4 * d4));
+        p[9] = on * dot4_tanh(pm, s2, ld4(a.Um + 4 * d4));
+    }
+    {   // block_sum over nw waves
+        const int lane = tid & 63, w = tid >> 6;
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { const float r = wave_sum(p[i]); if (lane == 0) s_red[w * 10 + i] = r; }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 10; ++i) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q * 10 + i]; p[i] = r; }
+    }
+    if (tid == 0) { a.eg[bt] = p[8] + a.cg[0]; a.em[bt] = p[9] + a.cm[0]; }
+    // softmax over the K regions (every lane redundantly, from registers)
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { p[kk] += a.cl[0]; if (kk < K) mx = fmaxf(mx, p[kk]); }
+    float sum = 0.f;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) { p[kk] = kk < K ? __expf(p[kk] - mx) : 0.f; sum += p[kk]; }
+    const float inv = 1.0f / sum;
+    float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = c4;
+#pragma unroll
+    for (int kk = 0; kk < 8; ++kk) {
+        const float al = p[kk] * inv;
+        if (tid == kk && kk < K) a.alphal[(size_t)bt * K + kk] = al;
+        c4.x += al * l[kk].x; c4.y += al * l[kk].y; c4.z += al * l[kk].z; c4.w += al * l[kk].w;
+        w4.x += al * lw[kk].x; w4.y += al * lw[kk].y; w4.z += al * lw[kk].z; w4.w += al * lw[kk].w;
+    }
+    if (on != 0.f) st4(a.CL + (size_t)bt * D + 4 * d4, c4);
+    if (a.LW) {
+        const float4 bl = ld4(a.blt + 4 * d4);
+        w4.x += bl.x; w4.y += bl.y; w4.z += bl.z; w4.w += bl.w;
+        float pe = on * dot4_tanh(w4, s3, ld4(a.Ult + 4 * d4));
+        const int lane = tid & 63, w = tid >> 6;
+        pe = wave_sum(pe);
+        __syncthreads();                       // (s_red is being re-used)
+        if (lane == 0) s_red[w] = pe;
+        __syncthreads();
+        if (tid == 0) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q]; a.elt[bt] = r + a.clt[0]; }
+    }
+}
+
 template <int NT>
 __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
     constexpr int NW = NT / 64;
@@ -611,6 +681,13 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
             case 7: hipLaunchKernelGGL(spatial_shared_kernel<7>, grid, block, 0, s, a); break;
             default: hipLaunchKernelGGL(spatial_shared_kernel<8>, grid, block, 0, s, a); break;
         }
+        return hipGetLastError();
+    }
+    // a grid that does not fill the chip (decode with a handful of rows): the single-round-trip kernel
+    static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
+    if (!nosm && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024) {
+        const int nt = ((a.D / 4 + 63) / 64) * 64;
+        hipLaunchKernelGGL(spatial_small_kernel, dim3(a.M * a.T), dim3(nt), 0, s, a);
         return hipGetLastError();
     }
     // D a multiple of 1024: 128-thread workgroups with two columns per thread (all items of configs[1] resident at

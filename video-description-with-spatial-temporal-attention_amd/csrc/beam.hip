@@ -115,7 +115,53 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
     const int v = blockIdx.x, tid = threadIdx.x;
     const int k = a.k, D = a.D, L = a.maxlen, V = a.V, step = *a.step;
     const int nsel = a.live_k[v] > 0 ? k - a.dead_k[v] : 0;    // how many candidates survive (:923)
-    if (nsel > 0) {                                            // (uniform over the workgroup)
+    if (nsel > 0 && a.stats) {
+        // Small-batch decode: no probabilities were materialised.  The logits launch left, per (row, vocabulary tile),
+        // the tile max, sum exp(v - max) and its best values; here: log-sum-exp per live row, then
+        // cost = hyp_score - log p = hyp_score + lse - v for the tiles' candidates, merged like the slice winners above.
+        __shared__ float s_lse[KB];
+        __shared__ float s_m[4][KB], s_s[4][KB];
+        const int live = a.live_k[v], nt = a.ntile, lane = tid & 63, w = tid >> 6;
+        for (int j = 0; j < live; ++j) {   // per-thread running (max, sum) over its tiles, wave merge; ONE barrier for all rows
+            const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
+            float rm = -INFINITY, rs = 0.f;
+            for (int t = tid; t < nt; t += 256) {
+                const float tm = rec[(size_t)t * PN_STATS_REC], ts = rec[(size_t)t * PN_STATS_REC + 1];
+                if (tm > -INFINITY) {
+                    const float nm = fmaxf(rm, tm);
+                    rs = rs * __expf(rm - nm) + ts * __expf(tm - nm);      // (exp(-inf) = 0 on the first tile)
+                    rm = nm;
+                }
+            }
+            const float wm = wave_max(rm);
+            const float ws = wave_sum(rm > -INFINITY ? rs * __expf(rm - wm) : 0.f);
+            if (lane == 0) { s_m[w][j] = wm; s_s[w][j] = ws; }
+        }
+        __syncthreads();
+        if (tid < live) {
+            const float m = fmaxf(fmaxf(s_m[0][tid], s_m[1][tid]), fmaxf(s_m[2][tid], s_m[3][tid]));
+            float ssum = 0.f;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) if (s_m[q][tid] > -INFINITY) ssum += s_s[q][tid] * __expf(s_m[q][tid] - m);
+            s_lse[tid] = m + logf(ssum);
+        }
+        __syncthreads();
+        float lc[KB]; int li[KB];
+#pragma unroll
+        for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+        const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
+        for (int j = 0; j < live; ++j) {
+            const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
+            const float base = a.hyp_score[v * k + j] + s_lse[j];
+            for (int e = tid; e < per; e += 256) {
+                const int t = e / nsel, i = e - t * nsel;
+                const float val = rec[(size_t)t * PN_STATS_REC + 2 + i];
+                if (val > -INFINITY)
+                    list_insert(lc, li, base - val, j * V + reinterpret_cast<const int*>(rec)[(size_t)t * PN_STATS_REC + 2 + PN_STATS_KB + i]);
+            }
+        }
+        block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
+    } else if (nsel > 0) {                                     // (uniform over the workgroup)
         float lc[KB]; int li[KB];
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
@@ -166,6 +212,11 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
             float* __restrict__ hd = a.h_next + (size_t)(v * k + slot) * D;
             float* __restrict__ cd = a.c_next + (size_t)(v * k + slot) * D;
             for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
+            if (a.proj_next) {   // the next step's state projections travel with the hypothesis (linear in h: gathered, not recomputed)
+                const float* __restrict__ ps = a.proj_step + (size_t)(v * k + ti) * a.nproj;
+                float* __restrict__ pd = a.proj_next + (size_t)(v * k + slot) * a.nproj;
+                for (int d = tid * 4; d < a.nproj; d += 1024) *reinterpret_cast<float4*>(pd + d) = *reinterpret_cast<const float4*>(ps + d);
+            }
             if (a.h_next_pk)
                 for (int d = tid; d < D; d += 256) a.h_next_pk[pn_pack_offset(v * k + slot, d, D >> 4)] = hs[d];
             // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here,
@@ -211,6 +262,8 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
 }
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx) {
     if (!a.ticket) return hipErrorInvalidValue;
+    if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB)) return hipErrorInvalidValue;
+    if (a.proj_next && (!a.proj_step || a.nproj % 4)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
     return hipGetLastError();
 }

@@ -111,7 +111,8 @@ struct stattn_handle {
     int ck_T = 0, ck_K = 0;
     bool ck_proj = false;
     // beam search: the captured two-word graph is kept while every pointer and shape it baked in is unchanged
-    hipGraphExec_t beam_gexec = nullptr;
+    hipGraphExec_t beam_gexec = nullptr;    // two words (even + odd ping-pong parity)
+    hipGraphExec_t beam_gexec8 = nullptr;   // eight words: a replay costs 10-16 us of launch overhead whatever it holds
     std::vector<uintptr_t> beam_gsig;
     long beam_graph_replays = 0;        // replays in the last stattn_beam_search (0 = eager launches)
     bool ck_valid = false;

@@ -160,7 +160,14 @@ struct PnSeg {
     const float* mul; int ldmul;
     float scale; int act;
     float* Cpk;                        // optional: the result once more in the packed A layout (it feeds another panel GEMM)
+    // Vocabulary statistics instead of (not: besides) the plain store -- the small-batch decode step (panel.hip):
+    // per (row, column tile) one PnTileStats record of the biased values v[n], n < stats_V (column 0 excluded when
+    // stats_skip0): tile max, sum exp(v - max), and the stats_kb largest values with their columns.
+    float* stats; int stats_V, stats_kb, stats_skip0;
 };
+// record layout (floats): [0] max, [1] sum of exp(v - max), [2 .. 2+8) values descending, [10 .. 18) their columns (int bits)
+constexpr int PN_STATS_KB = 8;
+constexpr int PN_STATS_REC = 2 + 2 * PN_STATS_KB;
 struct PnArgs {
     PnSeg seg[6]; int nseg; int M;
     int kz; size_t part_stride;        // K split over gridDim.y: raw partial tiles to C + z * part_stride, no epilogue
@@ -168,6 +175,7 @@ struct PnArgs {
 void pn_seg_defaults(PnSeg& s);
 bool panel_supported(int M);
 hipError_t launch_panel(hipStream_t s, const PnArgs& a);
+int panel_tile_cols(const PnArgs& a);   // 16 or 32: column-tile width launch_panel picks (unit of PnSeg::stats records)
 struct LstmPnArgs {
     PnPair p[3]; int npairs;           // panels packed with PN_COLS_LSTM
     const float* pre_add; int ldpre; const float* bias;
@@ -393,6 +401,11 @@ struct BeamArgs {
     const float* Wemb; int E;           // embedding table: the update writes the next step's input embedding ...
     float* emb_next; float* emb_next_pk;   // ... [nvid*k, E] (and optionally its packed copy); null = not written
     int* ticket;                        // device int, zero: last workgroup of the update advances *step
+    // small-batch decode step: instead of `probs`, per (row, vocabulary tile) statistics written by the logits launch
+    // (PnSeg::stats): the update forms log-sum-exp per row and selects among the tiles' best candidates
+    const float* stats; int ntile;
+    // ... and gathers the NEXT step's state projections (computed from h of this step before the beam was re-ordered)
+    const float* proj_step; float* proj_next; int nproj;   // [nvid*k, nproj] rows (sproj | preh), or null
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
 };
 int beam_topk_splits(int nvid);

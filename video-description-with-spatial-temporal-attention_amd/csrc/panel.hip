@@ -83,6 +83,38 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     PN_STAMP(2);
 
     const int n0 = tg * CB;
+    if (sg.stats) {   // vocabulary statistics of this column tile (small-batch decode: the logits are never stored)
+        // final biased values -> the extra RB x CB block behind the K-slice partials (launch_panel sizes it in)
+        float* fin = red + (size_t)KS * RB * CB;
+        for (int idx = tid; idx < RB * CB; idx += blockDim.x) {
+            const int row = idx / CB, col = idx % CB;
+            float v = 0.f;
+            for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + col];
+            const int n = n0 + col;
+            if (sg.bias) v += sg.bias[n];
+            if (n >= sg.stats_V || (sg.stats_skip0 && n == 0)) v = -INFINITY;
+            fin[idx] = v;
+        }
+        __syncthreads();
+        const int nw = blockDim.x >> 6;
+        const int ntile = sg.N / CB;
+        for (int row = w; row < a.M; row += nw) {        // one wave per row: lane = column of the tile
+            float v = lane < CB ? fin[row * CB + lane] : -INFINITY;
+            const float mx = wave_max(v);
+            const float se = wave_sum(v > -INFINITY ? __expf(v - mx) : 0.f);
+            float* rec = sg.stats + ((size_t)row * ntile + tg) * PN_STATS_REC;
+            if (lane == 0) { rec[0] = mx; rec[1] = se; }
+            for (int i = 0; i < sg.stats_kb; ++i) {       // the kb largest, ties to the lower column
+                const float m = wave_max(v);
+                const unsigned long long hit = __ballot(v == m);
+                const int src = __ffsll((long long)hit) - 1;
+                if (lane == 0) { rec[2 + i] = m; reinterpret_cast<int*>(rec)[2 + PN_STATS_KB + i] = n0 + src; }
+                if (lane == src) v = -INFINITY;
+            }
+        }
+        PN_STAMP(3);
+        return;
+    }
     for (int idx = tid; idx < RB * CB; idx += blockDim.x) {
         const int row = idx / CB, col = idx % CB;
         if (row >= a.M) continue;
@@ -289,6 +321,24 @@ void pn_seg_defaults(PnSeg& s) {
     s.scale = 1.f;
 }
 
+// column-tile width launch_panel uses for `a` (16, or 32 when that still fills the chip): what PnSeg::stats records are
+// counted in (N / width per row)
+int panel_tile_cols(const PnArgs& a) {
+    int tiles = 0, min_steps = 1 << 30;
+    const int kz = a.kz > 1 ? a.kz : 1;
+    for (int i = 0; i < a.nseg; ++i) {
+        tiles += a.seg[i].N / 16;
+        for (int p = 0; p < a.seg[i].npairs; ++p) {
+            const int st = (a.seg[i].p[p].K / 16 + kz - 1) / kz;
+            min_steps = st < min_steps ? st : min_steps;
+        }
+    }
+    const PnGeom q = pn_geom(a.M, 16, min_steps);
+    bool nt2 = tiles * kz >= 512 && q.MG == 1;
+    for (int i = 0; i < a.nseg; ++i) nt2 = nt2 && (a.seg[i].N % 32 == 0);
+    return nt2 ? 32 : 16;
+}
+
 hipError_t launch_panel(hipStream_t s, const PnArgs& a) {
     if (a.M <= 0 || a.nseg <= 0) return hipSuccess;
     if (!panel_supported(a.M)) return hipErrorInvalidValue;
@@ -315,7 +365,12 @@ hipError_t launch_panel(hipStream_t s, const PnArgs& a) {
     for (int i = 0; i < a.nseg; ++i) nt2 = nt2 && (a.seg[i].N % 32 == 0);
     const int CB = nt2 ? 32 : 16;
     dim3 grid(tiles / (nt2 ? 2 : 1), kz), block(64 * q.MG * q.KS);
-    const size_t lds = (size_t)q.KS * q.MG * q.MT * 16 * CB * sizeof(float);
+    bool stats = false;
+    for (int i = 0; i < a.nseg; ++i) stats = stats || a.seg[i].stats;
+    if (stats && (q.MG != 1 || kz != 1)) return hipErrorInvalidValue;      // every row in one row group, no K split over blocks
+    for (int i = 0; i < a.nseg; ++i)
+        if (a.seg[i].stats && (a.seg[i].stats_kb < 1 || a.seg[i].stats_kb > PN_STATS_KB)) return hipErrorInvalidValue;
+    const size_t lds = ((size_t)q.KS + (stats ? 1 : 0)) * q.MG * q.MT * 16 * CB * sizeof(float);
 #define STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, R_, OS_)                                                         \
     do {                                                                                                    \
         hipError_t e_ = pn_allow_lds(panel_kernel<MT_, NT_, MAXT_, R_, OS_>, lds);                          \

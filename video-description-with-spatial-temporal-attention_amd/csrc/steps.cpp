@@ -259,8 +259,10 @@ int run_step(stattn_handle* h, const StepIO& io) {
     SpatialArgs sa{};
     sa.bf16 = h->opt.precision == 1; sa.group = h->opt.precision != 1 ? io.group : 0;
     sa.M = io.M; sa.T = io.T; sa.K = io.K; sa.D = D;
-    const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && spatial_rider_supported(sa);
-    if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
+    const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && !io.skip_hproj && spatial_rider_supported(sa);
+    const int ldp = io.ldproj ? io.ldproj : 4 * D;
+    if (io.skip_hproj) {
+    } else if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
         Prof pr(h, KC_HPROJ);
         PnArgs a{};
         a.M = io.M; a.nseg = rider ? 1 : 2;
@@ -268,11 +270,11 @@ int run_step(stattn_handle* h, const StepIO& io) {
         pn_seg_defaults(s0);
         const PnPair hA = io.h_prev_pk ? PnPair{io.h_prev_pk, D, nullptr, D, 1} : PnPair{io.h_prev, D, nullptr, D, 0};
         s0.npairs = 1; s0.p[0] = hA; s0.p[0].P = io.pn->Wd;
-        s0.C = io.sproj; s0.ldc = 4 * D; s0.N = 4 * D;         // [Wdl | Wdg | Wdm | Wdlt]: 4 x D/16 consecutive tiles
+        s0.C = io.sproj; s0.ldc = ldp; s0.N = 4 * D;           // [Wdl | Wdg | Wdm | Wdlt]: 4 x D/16 consecutive tiles
         PnSeg& s1 = a.seg[1];
         pn_seg_defaults(s1);
         s1.npairs = 1; s1.p[0] = hA; s1.p[0].P = io.pn->U;
-        s1.C = io.preh; s1.ldc = 4 * D; s1.N = 4 * D;
+        s1.C = io.preh; s1.ldc = ldp; s1.N = 4 * D;
         if (io.xproj) { s1.add = io.xproj; s1.ldadd = 4 * D; }
         HIPCHK(h, launch_panel(h->stream, a));
     } else {   // state projections: h.[Wdl | Wdg | Wdm | Wdlt] -> sproj, h.U (+ x_) -> preh   (:371, 389, 402, 415, 437-438)
@@ -284,12 +286,12 @@ int run_step(stattn_handle* h, const StepIO& io) {
             SkSeg& s = a.seg[i];
             skinny_seg_defaults(s);
             s.npairs = 1; s.p[0] = SkPair{io.h_prev, Wd[i], D, D, D, 0};
-            s.C = io.sproj + (size_t)i * D; s.ldc = 4 * D; s.N = D;
+            s.C = io.sproj + (size_t)i * D; s.ldc = ldp; s.N = D;
         }
         SkSeg& s = a.seg[4];
         skinny_seg_defaults(s);
         s.npairs = 1; s.p[0] = SkPair{io.h_prev, w.U, D, 4 * D, D, 0};
-        s.C = io.preh; s.ldc = 4 * D; s.N = 4 * D;
+        s.C = io.preh; s.ldc = ldp; s.N = 4 * D;
         if (io.xproj) { s.add = io.xproj; s.ldadd = 4 * D; }
         HIPCHK(h, launch_skinny(h->stream, a));
     }
@@ -300,10 +302,10 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.bf16 = h->opt.precision == 1;
         a.PG = io.c.PG; a.PM = io.c.PM; a.vid = io.vid;
         a.group = h->opt.precision != 1 ? io.group : 0;
-        a.sproj = io.sproj; a.ldsp = 4 * D;
+        a.sproj = io.sproj; a.ldsp = ldp;
         if (rider) {   // preh = h.U (+ x_): 4D / 16 tiles, one K-slice
             RiderArgs& r = a.rider;
-            r.A = io.h_prev_pk; r.P = io.pn->U; r.C = io.preh; r.ldc = 4 * D;
+            r.A = io.h_prev_pk; r.P = io.pn->U; r.C = io.preh; r.ldc = ldp;
             r.add = io.xproj; r.ldadd = 4 * D;
             r.M = io.M; r.N = 4 * D; r.K = D; r.kz = 1; r.part_stride = 0; r.nblocks = 4 * D / 16;
         }
@@ -319,7 +321,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = io.CL; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = io.plt; g.ldc = D;
         g.M = io.M * io.T; g.N = D; g.K = D; g.bias = w.blt;
-        g.rowadd = io.sproj + 3 * (size_t)D; g.ldrow = 4 * D; g.rowgroup = io.T; g.act = 1;
+        g.rowadd = io.sproj + 3 * (size_t)D; g.ldrow = ldp; g.rowgroup = io.T; g.act = 1;
         HIPCHK(h, launch_gemm(h->stream, g, false, false));
         HIPCHK(h, launch_rowdot(h->stream, io.plt, D, w.Ult, w.clt, io.elt, io.M * io.T, D));
     }
@@ -339,7 +341,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.npairs = 1; a.p[0] = io.ctx_pk ? PnPair{io.ctx_pk, D, io.pn->Wc, D, 1} : PnPair{io.ctx, D, io.pn->Wc, D, 0};
         if (io.emb) { a.p[1] = io.emb_pk ? PnPair{io.emb_pk, E, io.pn->W, E, 1} : PnPair{io.emb, E, io.pn->W, E, 0}; a.npairs = 2; a.bias = w.b; }
         a.h_pk = io.h_out_pk; a.hd_pk = io.hd_pk;
-        a.pre_add = io.preh; a.ldpre = 4 * D;
+        a.pre_add = io.preh; a.ldpre = ldp;
         a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
         a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
         a.d1 = io.d1; a.ldd1 = D; a.d1_scalar = 0.5f; a.hd_out = io.hd;
@@ -350,7 +352,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         LstmArgs a{};
         a.npairs = 1; a.p[0] = SkPair{io.ctx, w.Wc, D, 4 * D, D, 0};
         if (io.emb) { a.p[1] = SkPair{io.emb, w.W, E, 4 * D, E, 0}; a.npairs = 2; a.bias = w.b; }
-        a.pre_add = io.preh; a.ldpre = 4 * D;
+        a.pre_add = io.preh; a.ldpre = ldp;
         a.dp = io.dp; a.lddp = 3 * D; a.mask = io.mask;
         a.h_prev = io.h_prev; a.c_prev = io.c_prev; a.h_out = io.h_out; a.c_out = io.c_out; a.gates = io.gates;
         a.d1 = io.d1; a.ldd1 = D; a.d1_scalar = 0.5f; a.hd_out = io.hd;

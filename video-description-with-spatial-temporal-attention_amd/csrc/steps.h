@@ -53,7 +53,10 @@ struct StepIO {
     CtxPtrs c; const int* vid;
     int group;                       // beam search: rows v * group + h share video v (0 / 1: every row has its own video index)
     const float* h_prev; const float* c_prev;
-    float *sproj, *preh;             // [M,4D] each
+    float *sproj, *preh;             // [M,4D] each (row stride ldproj, 0 = 4D)
+    int ldproj;
+    bool skip_hproj;                 // sproj / preh of this step are already in place (small-batch decode: they were computed
+                                     // from h right after the previous step's LSTM and gathered with the beam)
     const float* xproj;              // [M,4D] (training: emb.W + b) or null
     const float* emb;                // [M,E]  (sampling: third LSTM pair) or null
     const float* dp; const float* mask; const float* d1;

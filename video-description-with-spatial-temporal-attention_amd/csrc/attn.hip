@@ -27,6 +27,12 @@ namespace {
 constexpr int KMAX = 64;     // regions per frame supported by the LDS softmax
 constexpr int TMAX = 256;    // frames supported by the temporal kernel
 
+// e^{2x} per component, exponent clamped to +-80 (see spatial_shared_kernel)
+__device__ __forceinline__ float4 exp2x4(float4 x) {
+    return make_float4(__expf(__builtin_amdgcn_fmed3f(2.f * x.x, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.y, -80.f, 80.f)),
+                       __expf(__builtin_amdgcn_fmed3f(2.f * x.z, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.w, -80.f, 80.f)));
+}
+
 __device__ __forceinline__ float dot4_tanh(float4 x, float4 s, float4 u) {
     return fast_tanh(x.x + s.x) * u.x + fast_tanh(x.y + s.y) * u.y +
            fast_tanh(x.z + s.z) * u.z + fast_tanh(x.w + s.w) * u.w;
@@ -431,7 +437,16 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
     // slab is 64 lanes x 16 B x D/256 fully coalesced loads), so a wave_sum finishes its scores: no cross-wave reduction
     const int lane = tid & 63, w = tid >> 6;
     for (int k0 = 8 * w; k0 < K; k0 += 32) {
-        float p[8 * H];          // p[h * 8 + kk]
+        // This phase is VALU-bound at configs[4] (H K D = 164 k tanh per workgroup, 419 M per word: as long as the
+        // 1 GB of slabs takes to stream), so the tanh is split along its sum:
+        //     tanh(x + s) = 1 - 2 / (1 + e^{2x} e^{2s})
+        // e^{2x} is formed ONCE per slab element and shared by the H hypotheses, e^{2s} once per (hypothesis, column) and
+        // shared by the 8 regions in flight: per (hypothesis, region, column) one multiply, one add, one v_rcp and one
+        // FMA remain -- ONE transcendental instead of two.  U . 1 is added once at the end (the "1 -" of every term).
+        // Exponents are clamped to +-80 (|x|, |s| <= 40: e^{80} e^{80} = inf -> tanh = 1, e^{-80} e^{-80} = 0 -> -1, never
+        // 0 x inf); inside that domain the result equals the direct form to 1e-7.
+        float p[8 * H];          // p[h * 8 + kk] = sum_d (-2 U_d) / (1 + e^{2x} e^{2s})
+        float usum = 0.f;
 #pragma unroll
         for (int i = 0; i < 8 * H; ++i) p[i] = 0.f;
         for (int d4 = lane; d4 < nd4; d4 += 64) {
@@ -439,18 +454,26 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) x[kk] = ld4(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
             const float4 u4 = ld4(a.Ul + 4 * d4);
+            usum += (u4.x + u4.y) + (u4.z + u4.w);
+            const float4 m2u = make_float4(-2.f * u4.x, -2.f * u4.y, -2.f * u4.z, -2.f * u4.w);
+#pragma unroll
+            for (int kk = 0; kk < 8; ++kk) x[kk] = exp2x4(x[kk]);
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const float4 s4 = ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4);
+                const float4 es = exp2x4(ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4));
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) p[h * 8 + kk] += dot4_tanh(x[kk], s4, u4);
-                __builtin_amdgcn_sched_barrier(0);     // one hypothesis at a time: interleaving all 8 H tanh chains spills
+                for (int kk = 0; kk < 8; ++kk) {
+                    p[h * 8 + kk] += m2u.x * fast_rcp(1.f + x[kk].x * es.x) + m2u.y * fast_rcp(1.f + x[kk].y * es.y) +
+                                     m2u.z * fast_rcp(1.f + x[kk].z * es.z) + m2u.w * fast_rcp(1.f + x[kk].w * es.w);
+                }
+                __builtin_amdgcn_sched_barrier(0);     // one hypothesis at a time: interleaving all 8 H chains spills
             }
         }
+        usum = wave_sum(usum);
 #pragma unroll
         for (int i = 0; i < 8 * H; ++i) {
             const float r = wave_sum(p[i]);
-            if (lane == 0 && k0 + (i & 7) < K) s_e[i >> 3][k0 + (i & 7)] = r + a.cl[0];
+            if (lane == 0 && k0 + (i & 7) < K) s_e[i >> 3][k0 + (i & 7)] = r + usum + a.cl[0];
         }
     }
     // ---- the two frame scores per hypothesis (PG / PM rows are shared by the hypotheses as well)
@@ -491,16 +514,17 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         float4 c4[H], w4[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
-        for (int k0 = 0; k0 < K; k0 += 4) {            // four regions' loads (8 x 16 B per lane) in flight together
-            float4 l4[4], q4[4];
+        constexpr int RG = 4;                          // regions per round: 2 RG x 16 B per lane in flight together
+        for (int k0 = 0; k0 < K; k0 += RG) {
+            float4 l4[RG], q4[RG];
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < RG; ++kk) {
                 const int k = min(k0 + kk, K - 1);
                 l4[kk] = ld4(L + (size_t)k * D + 4 * d4);
                 q4[kk] = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
 #pragma unroll
-            for (int kk = 0; kk < 4; ++kk) {
+            for (int kk = 0; kk < RG; ++kk) {
 #pragma unroll
                 for (int h = 0; h < H; ++h) {
                     const float al = k0 + kk < K ? s_e[h][k0 + kk] : 0.f;
@@ -528,6 +552,8 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
             if (tid == h) a.elt[(size_t)(b0 + h) * T + t] = pe[h] + a.clt[0];
     }
 }
+
+
 
 // one wave per row: out[r] = dot(P[r,:], U) + c
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P, int ldp,

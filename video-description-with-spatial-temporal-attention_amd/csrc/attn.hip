@@ -27,12 +27,6 @@ namespace {
 constexpr int KMAX = 64;     // regions per frame supported by the LDS softmax
 constexpr int TMAX = 256;    // frames supported by the temporal kernel
 
-// e^{2x} per component, exponent clamped to +-80 (see spatial_shared_kernel)
-__device__ __forceinline__ float4 exp2x4(float4 x) {
-    return make_float4(__expf(__builtin_amdgcn_fmed3f(2.f * x.x, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.y, -80.f, 80.f)),
-                       __expf(__builtin_amdgcn_fmed3f(2.f * x.z, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.w, -80.f, 80.f)));
-}
-
 __device__ __forceinline__ float dot4_tanh(float4 x, float4 s, float4 u) {
     return fast_tanh(x.x + s.x) * u.x + fast_tanh(x.y + s.y) * u.y +
            fast_tanh(x.z + s.z) * u.z + fast_tanh(x.w + s.w) * u.w;
@@ -178,7 +172,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
         return;
     }
     const int T = a.T, K = a.K, D = a.D;
-    const int bt = (int)blockIdx.x - a.rider.nblocks, b = bt / T, t = bt % T;
+    const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, t = bt % T;   // a row's frames on one XCD (shared sproj row)
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
     const size_t slab = ((size_t)v * T + t) * K * D;

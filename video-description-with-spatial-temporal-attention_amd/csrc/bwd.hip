@@ -48,6 +48,9 @@ __device__ __forceinline__ float4 tanh4s(float4 x, float4 s) {
 __device__ __forceinline__ float4 one_minus_sq(float4 t) {
     return make_float4(1.f - t.x * t.x, 1.f - t.y * t.y, 1.f - t.z * t.z, 1.f - t.w * t.w);
 }
+__device__ __forceinline__ float4 r_minus_sq(float4 r) {     // r - r^2 = (1 - tanh^2) / 4 for r = 1 / (1 + e^{2z})
+    return make_float4(r.x - r.x * r.x, r.y - r.y * r.y, r.z - r.z * r.z, r.w - r.w * r.w);
+}
 __device__ __forceinline__ float4 mul4(float4 a, float4 b) { return make_float4(a.x * b.x, a.y * b.y, a.z * b.z, a.w * b.w); }
 __device__ __forceinline__ float4 scale4(float4 a, float s) { return make_float4(a.x * s, a.y * s, a.z * s, a.w * s); }
 __device__ __forceinline__ void fma4(float4& acc, float s, float4 v) { acc.x += s * v.x; acc.y += s * v.y; acc.z += s * v.z; acc.w += s * v.w; }
@@ -159,7 +162,8 @@ __global__ __launch_bounds__(256, 4) void spatial_bwd_kernel(const SpatialBwdArg
         return;
     }
     const int T = a.T, K = a.K, D = a.D;
-    const int bt = (int)blockIdx.x - a.rider.nblocks, b = bt / T, tid = threadIdx.x;
+    // all frames of a batch row on one XCD: they share the row's sproj, dcsum partials, csum / cparts
+    const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, tid = threadIdx.x;
     const size_t slab = (size_t)bt * K * D;
     const float* __restrict__ PL = a.PL + slab;
     const float* __restrict__ L = a.L + slab;
@@ -347,7 +351,13 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, const int NG) {
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
     const int n = blockIdx.x;
-    const int bt = (n / (8 * NG)) * 8 + (n & 7), grp = (n >> 3) % NG;
+    int bt, grp;
+    if (M & 7) { bt = (n / (8 * NG)) * 8 + (n & 7); grp = (n >> 3) % NG; }
+    else {      // whole batch rows per XCD as well: the 30 steps' sproj / dcsum rows of a row are shared by its T frames
+        const int x = n & 7, i = n >> 3, it = i / NG;
+        grp = i - it * NG;
+        bt = (x + 8 * (it / T)) * T + it % T;
+    }
     if (bt >= M * T) return;                       // (grid rounded up to whole groups of 8 items)
     const int b = bt / T, tid = threadIdx.x;
     const int nd4 = D >> 2;
@@ -357,8 +367,11 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
         // frame-level tensors
         if (grp == NG - 1) {
             const size_t fo = (size_t)bt * D + 4 * d4;
-            const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
+            // e^{2 PG}, e^{2 PM} once: tanh(P + s_step) = 1 - 2 r with r = 1 / (1 + e^{2P} e^{2s}) (devmath.h exp2x4); the sums
+            // below carry r and r - r^2 and are turned into tanh / 1 - tanh^2 after the loop
+            const float4 pg = exp2x4(ld4(a.PG + fo)), pm = exp2x4(ld4(a.PM + fo));
             float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg;
+            float sdeg = 0.f, sdem = 0.f;
             struct FrameIn { float4 sg, sm, dcs; float deg, dem, am; };
             auto fetch_f = [&](int s_) {
                 FrameIn r;
@@ -370,28 +383,29 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             };
             for (int s = 0; s < S; ++s) {
                 const FrameIn cf = fetch_f(s);
-                const float4 tg = tanh4s(pg, cf.sg), tm = tanh4s(pm, cf.sm);
-                fma4(dpg, cf.deg, one_minus_sq(tg)); fma4(ug, cf.deg, tg);
-                fma4(dpm, cf.dem, one_minus_sq(tm)); fma4(um, cf.dem, tm);
+                const float4 rg = rcp1p4(pg, exp2x4(cf.sg)), rm = rcp1p4(pm, exp2x4(cf.sm));
+                fma4(dpg, cf.deg, r_minus_sq(rg)); fma4(ug, cf.deg, rg); sdeg += cf.deg;
+                fma4(dpm, cf.dem, r_minus_sq(rm)); fma4(um, cf.dem, rm); sdem += cf.dem;
                 fma4(dmo, cf.am, cf.dcs);
             }
-            st4(a.dPG + fo, mul4(dpg, ld4(a.Ug + 4 * d4)));
-            st4(a.dPM + fo, mul4(dpm, ld4(a.Um + 4 * d4)));
+            st4(a.dPG + fo, mul4(scale4(dpg, 4.f), ld4(a.Ug + 4 * d4)));        // sum deg (1 - tanh^2) = 4 sum deg (r - r^2)
+            st4(a.dPM + fo, mul4(scale4(dpm, 4.f), ld4(a.Um + 4 * d4)));
             st4(a.dMo + fo, dmo);
-            st4(a.pUg + fo, ug);
-            st4(a.pUm + fo, um);
+            st4(a.pUg + fo, make_float4(sdeg - 2.f * ug.x, sdeg - 2.f * ug.y, sdeg - 2.f * ug.z, sdeg - 2.f * ug.w));   // sum deg tanh = sum deg (1 - 2 r)
+            st4(a.pUm + fo, make_float4(sdem - 2.f * um.x, sdem - 2.f * um.y, sdem - 2.f * um.z, sdem - 2.f * um.w));
         }
         // region-level tensors, 4 regions at a time.  (8 at a time meant 40 float4 accumulators = one wave per SIMD for a
         // kernel whose floor is VALU issue -- 0.4 G tanh -- not bandwidth; 4 at a time re-reads the per-step operands
         // K / 4 times (L2 hits) and runs three waves per SIMD.)
         float4 pul = make_float4(0.f, 0.f, 0.f, 0.f), pult = pul;
+        float sde_all = 0.f;
         {
             const int k0 = 4 * grp;
             float4 pl[4], lw[4], lwx[4], dpl[4], dl[4], dlw[4];
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
                 const size_t o = slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
-                pl[kk] = ld4(a.PL + o); lw[kk] = ld4(a.LW + o);
+                pl[kk] = exp2x4(ld4(a.PL + o)); lw[kk] = ld4(a.LW + o);       // pl holds e^{2 PL} (see the frame-level part)
                 // first pass, K <= 8: regions 4..7 of LW as well -- plt below needs every region of the frame
                 lwx[kk] = (k0 == 0 && K > 4 && K <= 8) ? ld4(a.LW + slab + (size_t)min(4 + kk, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
@@ -415,14 +429,16 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
                 }
                 return r;
             };
+            float sde = 0.f;
             for (int s = 0; s < S; ++s) {
                 const StepIn cur = fetch(s);
                 const float4 dcl = scale4(cur.dcs, cur.alt);
+                const float4 esl = exp2x4(cur.sl);
 #pragma unroll
                 for (int kk = 0; kk < 4; ++kk) {
-                    const float4 th = tanh4s(pl[kk], cur.sl);
-                    fma4(dpl[kk], cur.de[kk], one_minus_sq(th));
-                    if (k0 + kk < K) fma4(pul, cur.de[kk], th);
+                    const float4 r = rcp1p4(pl[kk], esl);
+                    fma4(dpl[kk], cur.de[kk], r_minus_sq(r));
+                    if (k0 + kk < K) { fma4(pul, cur.de[kk], r); sde += cur.de[kk]; }
                     fma4(dl[kk], cur.al[kk], dcl);
                     fma4(dlw[kk], cur.al[kk], cur.dp);
                 }
@@ -445,12 +461,14 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             for (int kk = 0; kk < 4; ++kk) {
                 if (k0 + kk < K) {
                     const size_t o = slab + (size_t)(k0 + kk) * D + 4 * d4;
-                    st4(a.dPL + o, mul4(dpl[kk], ul));
+                    st4(a.dPL + o, mul4(scale4(dpl[kk], 4.f), ul));
                     st4(a.dL + o, dl[kk]);
                     st4(a.dLW + o, dlw[kk]);
                 }
             }
+            sde_all = sde;
         }
+        pul = make_float4(sde_all - 2.f * pul.x, sde_all - 2.f * pul.y, sde_all - 2.f * pul.z, sde_all - 2.f * pul.w);   // sum de tanh = sum de (1 - 2 r)
         st4(a.pUl + ((size_t)grp * MT + bt) * D + 4 * d4, pul);        // one partial per region group (summed by the column sums)
         if (grp == 0) st4(a.pUlt + (size_t)bt * D + 4 * d4, pult);
     }

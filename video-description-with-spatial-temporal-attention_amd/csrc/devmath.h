@@ -29,7 +29,37 @@ __device__ __forceinline__ float wave_max(float v) {
     return v;
 }
 
+// Workgroup -> XCD placement.  Block n of a launch runs on XCD n % 8 (observed dispatch order; each XCD has its own 4 MiB
+// L2).  Work items that read the same rows / lines should therefore sit on the same XCD, or every XCD fetches its own
+// copy through the fabric.  Both maps are bijections of [0, nblocks) for any nblocks: only performance depends on them.
+//   xcd_contiguous: XCD x gets a CONTIGUOUS range of items (neighbouring column tiles share cache lines)
+__device__ __forceinline__ int xcd_contiguous(int n, int nblocks) {
+    const int x = n & 7, i = n >> 3, q = nblocks >> 3, r = nblocks & 7;
+    return x * q + (x < r ? x : r) + i;
+}
+//   xcd_rows: items are (row, sub) pairs with `per_row` sub-items per row (frames of a batch row): XCD x gets whole
+//   rows x, x + 8, ... (valid when rows % 8 == 0, else the identity)
+__device__ __forceinline__ int xcd_rows(int n, int rows, int per_row) {
+    if (rows & 7) return n;
+    const int x = n & 7, i = n >> 3;
+    return (x + 8 * (i / per_row)) * per_row + i % per_row;
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+
+// e^{2x} per component, exponent clamped to +-80.  tanh(x + s) = 1 - 2 / (1 + e^{2x} e^{2s}) lets kernels that evaluate
+// tanh(x + s_i) for MANY shifts s_i of the same x (the H hypotheses of a video in beam search, the 30 time steps of the
+// deferred context gradients) pay one v_exp per x and per shift and only a v_rcp per pair -- one transcendental instead
+// of two.  With the clamp e^{80} e^{80} = inf gives tanh = 1 and e^{-80} e^{-80} = 0 gives -1, never 0 x inf; for
+// |x|, |s| <= 40 the result equals the direct form to 1e-7.
+__device__ __forceinline__ float4 exp2x4(float4 x) {
+    return make_float4(__expf(__builtin_amdgcn_fmed3f(2.f * x.x, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.y, -80.f, 80.f)),
+                       __expf(__builtin_amdgcn_fmed3f(2.f * x.z, -80.f, 80.f)), __expf(__builtin_amdgcn_fmed3f(2.f * x.w, -80.f, 80.f)));
+}
+// r = 1 / (1 + ex es) per component:  tanh = 1 - 2 r,  1 - tanh^2 = 4 (r - r^2)
+__device__ __forceinline__ float4 rcp1p4(float4 ex, float4 es) {
+    return make_float4(fast_rcp(1.f + ex.x * es.x), fast_rcp(1.f + ex.y * es.y), fast_rcp(1.f + ex.z * es.z), fast_rcp(1.f + ex.w * es.w));
+}
 
 }  // namespace stattn

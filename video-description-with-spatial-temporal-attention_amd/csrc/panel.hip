@@ -43,8 +43,9 @@ template <int MT, int NT, int MAXT, int R, bool ONESHOT>
 __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int MG, const int KS) {
     extern __shared__ __attribute__((aligned(16))) float red[];
     constexpr int CB = 16 * NT;
-    // locate the segment of this group of NT column tiles
-    int tg = blockIdx.x, si = 0;
+    // locate the segment of this group of NT column tiles.  Neighbouring tiles share the cache lines of the row-major
+    // epilogue operands and of C (a tile's 64 / 128 bytes per row are a fraction of a line): XCD-contiguous tile ranges
+    int tg = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), si = 0;
     while (si + 1 < a.nseg && tg >= a.seg[si].N / CB) { tg -= a.seg[si].N / CB; ++si; }
     const PnSeg& sg = a.seg[si];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
@@ -141,7 +142,10 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
     extern __shared__ __attribute__((aligned(16))) float red[];
     constexpr int CB = 16;
     const int D = a.D;
-    const int c = blockIdx.x;
+    // XCD-contiguous tile ranges: the epilogue reads 16-byte pieces (four units) of row-major [M, 4D] / [M, D] operands --
+    // with tile c on XCD c % 8 the four to eight tiles that share a line sat on as many XCDs and every one of them
+    // fetched the line for itself (measured: 40 MB through the fabric per launch for 20 MB of distinct bytes)
+    const int c = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
     const int j = lane & 15, g = lane >> 4;
     const int mg = w % MG, ks = w / MG;

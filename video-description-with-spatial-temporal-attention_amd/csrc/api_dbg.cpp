@@ -56,6 +56,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         float* P;
         CHK(getbuf_t(h, "dbg_P", (size_t)K * N, &P));
         CHK(pack(h, dB, transB ? K : N, transB ? 1 : 0, K, N / 16, PN_COLS_PLAIN, P));
+        CHK(pack_flush(h));
         PnArgs a{};
         a.M = M; a.nseg = 1;
         PnSeg& sg = a.seg[0];

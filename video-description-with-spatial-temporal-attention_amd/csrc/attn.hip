@@ -705,6 +705,8 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
     }
     // a grid that does not fill the chip (decode with a handful of rows): the single-round-trip kernel
     static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
+    // (on a grid that fills the chip it loses: 38 us against 33 at configs[1] -- three resident workgroups per CU with one
+    // round trip each move fewer bytes than eight with three)
     if (!nosm && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024) {
         const int nt = ((a.D / 4 + 63) / 64) * 64;
         hipLaunchKernelGGL(spatial_small_kernel, dim3(a.M * a.T), dim3(nt), 0, s, a);

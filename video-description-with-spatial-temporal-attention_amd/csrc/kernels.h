@@ -149,6 +149,11 @@ struct PackJob {
     float* dst; int S_total; int s_off;   // destination panel set: k-steps per tile, first k-step filled by this job
 };
 hipError_t launch_pack_panels(hipStream_t s, const PackJob& jb);
+// several repacking jobs in ONE launch (a pass repacks six to ten weight matrices: one launch instead of as many)
+constexpr int PACK_BATCH_MAX = 12;
+struct PackBatch { PackJob j[PACK_BATCH_MAX]; unsigned blk0[PACK_BATCH_MAX + 1]; int n; };
+bool pack_batch_add(PackBatch& b, const PackJob& jb);
+hipError_t launch_pack_batch(hipStream_t s, const PackBatch& b);
 // A: activations [M][lda], or with apk = 1 the packed layout written by the producing kernel (ceil(M / 16) * 16 rows
 // allocated); P: packed weight panels of the segment's first tile
 struct PnPair { const float* A; int lda; const float* P; int K; int apk; };

@@ -237,8 +237,14 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
 // src_t = 0: W is [K][ldw] (k-major rows): the four k of a float4 are four strided reads;
 // src_t = 1: the operand is W^T with W stored [N][ldw]: the four k are contiguous in one row of W (the reverse-scan
 //            recurrences use the transposed weights without ever materialising a transpose).
-__global__ __launch_bounds__(256) void pack_panels_kernel(const PackJob jb) {
-    const size_t idx = (size_t)blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void pack_one(const PackJob& jb, size_t idx);
+__global__ __launch_bounds__(256) void pack_panels_kernel(const PackJob jb) { pack_one(jb, (size_t)blockIdx.x * 256 + threadIdx.x); }
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatch b) {
+    int q = 0;
+    while (q + 1 < b.n && blockIdx.x >= b.blk0[q + 1]) ++q;
+    pack_one(b.j[q], (size_t)(blockIdx.x - b.blk0[q]) * 256 + threadIdx.x);
+}
+__device__ __forceinline__ void pack_one(const PackJob& jb, size_t idx) {
     const int S = jb.K >> 4;
     const size_t total = (size_t)jb.ntiles * S * 64;
     if (idx >= total) return;
@@ -317,6 +323,21 @@ hipError_t launch_pack_panels(hipStream_t s, const PackJob& jb) {
     if (jb.src_t && (jb.ldw % 4 != 0)) return hipErrorInvalidValue;
     const size_t total = (size_t)jb.ntiles * (jb.K >> 4) * 64;
     hipLaunchKernelGGL(pack_panels_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, jb);
+    return hipGetLastError();
+}
+
+bool pack_batch_add(PackBatch& b, const PackJob& jb) {
+    if (b.n >= PACK_BATCH_MAX || jb.K % 16 != 0 || jb.ntiles <= 0 || !jb.W || !jb.dst || (jb.src_t && (jb.ldw % 4 != 0))) return false;
+    const size_t total = (size_t)jb.ntiles * (jb.K >> 4) * 64;
+    if (b.n == 0) b.blk0[0] = 0;
+    b.j[b.n] = jb;
+    b.blk0[b.n + 1] = b.blk0[b.n] + (unsigned)((total + 255) / 256);
+    ++b.n;
+    return true;
+}
+hipError_t launch_pack_batch(hipStream_t s, const PackBatch& b) {
+    if (b.n <= 0) return hipSuccess;
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(b.blk0[b.n]), dim3(256), 0, s, b);
     return hipGetLastError();
 }
 

@@ -202,11 +202,20 @@ bool use_panels(const stattn_handle* h, int M, int min_rows) {
     return !off && M >= min_rows && M <= 256 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
 }
 
+// repacking jobs are collected per pass and run as one launch (pack_flush)
+static thread_local PackBatch g_packs{};
 int pack(stattn_handle* h, const float* W, int ldw, int src_t, int K, int ntiles, int cols, float* dst, int S_total, int s_off) {
     PackJob jb{};
     jb.W = W; jb.ldw = ldw; jb.src_t = src_t; jb.K = K; jb.ntiles = ntiles; jb.cols = cols; jb.D = h->D;
     jb.dst = dst; jb.S_total = S_total ? S_total : K / 16; jb.s_off = s_off;
-    HIPCHK(h, launch_pack_panels(h->stream, jb));
+    if (g_packs.n == PACK_BATCH_MAX) CHK(pack_flush(h));
+    if (!pack_batch_add(g_packs, jb)) { g_packs = PackBatch{}; return fail(h, STATTN_EINVAL, "pack: bad repacking job"); }
+    return STATTN_OK;
+}
+int pack_flush(stattn_handle* h) {
+    const PackBatch b = g_packs;
+    g_packs = PackBatch{};
+    HIPCHK(h, launch_pack_batch(h->stream, b));
     return STATTN_OK;
 }
 
@@ -231,7 +240,7 @@ int pack_fwd_panels(stattn_handle* h, FwdPanels* p, bool readout) {
         if (h->opt.ctx2out) CHK(pack(h, w.Wl2, E, 0, D, E / 16, PN_COLS_PLAIN, p->Wl2));
         CHK(pack(h, w.Wo, Vp, 0, E, Vp / 16, PN_COLS_PLAIN, p->Wo));
     }
-    return STATTN_OK;
+    return pack_flush(h);
 }
 
 // transposed recurrent weights of the reverse scan, packed straight from the untransposed parameters
@@ -245,7 +254,7 @@ int pack_bwd_panels(stattn_handle* h, BwdPanels* p) {
     CHK(pack(h, w.U, 4 * D, 1, 4 * D, D / 16, PN_COLS_PLAIN, p->UT));
     const float* Wd[4] = {w.Wdl, w.Wdg, w.Wdm, w.Wdlt};
     for (int i = 0; i < 4; ++i) CHK(pack(h, Wd[i], D, 1, D, D / 16, PN_COLS_PLAIN, p->WdT, 4 * D / 16, i * D / 16));
-    return STATTN_OK;
+    return pack_flush(h);
 }
 
 

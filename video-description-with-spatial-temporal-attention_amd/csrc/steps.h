@@ -44,6 +44,7 @@ struct BwdPanels { float *WcT, *UT, *WdT; };
 
 bool use_panels(const stattn_handle* h, int M, int min_rows = 17);
 int pack(stattn_handle* h, const float* W, int ldw, int src_t, int K, int ntiles, int cols, float* dst, int S_total = 0, int s_off = 0);
+int pack_flush(stattn_handle* h);      // run the repacking jobs collected by pack() as one launch
 int pack_fwd_panels(stattn_handle* h, FwdPanels* p, bool readout);
 int pack_bwd_panels(stattn_handle* h, BwdPanels* p);
 

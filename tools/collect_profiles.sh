@@ -1,0 +1,26 @@
+#!/bin/bash
+# usage (on the GPU box, through gpurun): tools/collect_profiles.sh <round tag, e.g. r03>
+# Everything profiles/ holds for a round: bench lines of every configuration, kernel-trace stats, the PMC passes
+# (FETCH_SIZE / WRITE_SIZE / MfmaUtil, each its own rocprofv3 run) and the FETCH_SIZE calibration.  Output: gpurun_out/<tag>_*
+r=$1
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+o=gpurun_out
+python bench.py > $o/${r}_bench_c2_train.json 2> $o/${r}_bench_c2_train.err
+python bench.py --mode forward > $o/${r}_bench_c2_forward.json 2>> $o/${r}_bench.err
+python bench.py --config c2v20k --no-cpu-baseline > $o/${r}_bench_c2v20k_train.json 2>> $o/${r}_bench.err
+python bench.py --config c4 --precision bf16 --no-cpu-baseline > $o/${r}_bench_c4_train_bf16.json 2>> $o/${r}_bench.err
+python bench.py --config c4 --no-cpu-baseline --no-split > $o/${r}_bench_c4_train_fp32.json 2>> $o/${r}_bench.err
+python bench.py --mode beam --config c5 --steps 5 --warmup 1 > $o/${r}_bench_c5_beam.json 2>> $o/${r}_bench.err
+python bench.py --mode beam --config c1 --beam 1 --steps 50 --warmup 3 > $o/${r}_bench_c1_greedy_beam1.json 2>> $o/${r}_bench.err
+python bench.py --mode beam --config c1 --beam 5 --steps 50 --warmup 3 > $o/${r}_bench_c1_beam5.json 2>> $o/${r}_bench.err
+python bench.py --mode decode --config c1 --steps 5 --warmup 1 > $o/${r}_bench_c1_decode.json 2>> $o/${r}_bench.err
+python bench.py --mode decode --config c1 --beam 5 --steps 5 --warmup 1 --no-cpu-baseline > $o/${r}_bench_c1_decode_beam5.json 2>> $o/${r}_bench.err
+tools/prof_trace.sh ${r}_trace_c2_train --steps 5 --warmup 1 --no-cpu-baseline --no-split
+tools/prof_trace.sh ${r}_trace_c5_beam --mode beam --config c5 --steps 3 --warmup 1
+tools/prof_trace.sh ${r}_trace_c1_beam1 --mode beam --config c1 --beam 1 --steps 20 --warmup 2
+for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
+    tools/prof_pmc.sh ${r}_pmc_train $c python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split
+done
+tools/prof_pmc.sh ${r}_fetch_calibration FETCH_SIZE tools/bin/fetch_calib
+ls -la $o | grep ${r}_

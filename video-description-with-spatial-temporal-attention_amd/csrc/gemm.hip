@@ -336,6 +336,40 @@ hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, float* C, int ld
     return hipGetLastError();
 }
 
+template <int TM, int TN>
+hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
+    constexpr int BM = 64 * TM, BN = 64 * TN;
+    GemmGroup G{};
+    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    bool edge = false;
+    int tiles = 0;
+    for (int i = 0; i < n; ++i) {
+        GemmArgs g = gs[i];
+        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % BN != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;   // (tB: K % 4 == 0 as well, covered)
+        g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
+        edge = edge || g.K % BK != 0 || (tA && g.M % BM != 0);
+        G.g[i] = g;
+        G.tile_start[i] = tiles;
+        tiles += ((g.M + BM - 1) / BM) * (g.N / BN);
+    }
+    G.tile_start[n] = tiles; G.n = n;
+    int per_xcd = 0;                                            // blocks an XCD may have to walk: sum of its largest shares
+    for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
+    const dim3 grid(per_xcd * NXCD);
+    if (tA) {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, false>), grid, dim3(256), 0, s, G);
+    } else if (tB) {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, false>), grid, dim3(256), 0, s, G);
+    } else {
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, false>), grid, dim3(256), 0, s, G);
+    }
+    return hipGetLastError();
+}
+
+
 hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
     if (n < 1 || n > GEMM_GROUP_MAX || (tA && tB)) return hipErrorInvalidValue;
     if (n == 1) return launch_gemm(s, gs[0], tA, tB);
@@ -344,34 +378,20 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, 
         for (int i = 0; i < n; ++i) split = split && gs[i].split && gemm_split_supported(gs[i], tA, tB);
         if (split) return launch_gemm_split_group(s, gs, n, tA, tB);
     }
-    GemmGroup G{};
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
-    bool edge = false;
-    int tiles = 0;
-    for (int i = 0; i < n; ++i) {
-        GemmArgs g = gs[i];
-        if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % 64 != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;   // (tB: K % 4 == 0 as well, covered)
-        g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
-        edge = edge || g.K % BK != 0 || (tA && g.M % 64 != 0);
-        G.g[i] = g;
-        G.tile_start[i] = tiles;
-        tiles += ((g.M + 63) / 64) * (g.N / 64);
+    // Tile of a grouped launch.  64 x 64 is the default (13 tiles per CU on the biggest projection: no tail).  When every
+    // problem has N % 128 == 0 the 128 x 128 tile halves the L2 -> LDS traffic per flop; it is taken when the GROUP's
+    // tile count fills whole rounds of the resident workgroups (the small problems are what fills the big one's tail).
+    static const char* gt = getenv("STATTN_GROUP_TILE");          // "22" / "11": force (tools)
+    bool n128 = true;
+    long t22 = 0;
+    for (int i = 0; i < n; ++i) { n128 = n128 && gs[i].N % 128 == 0 && gs[i].M >= 128; t22 += (long)((gs[i].M + 127) / 128) * (gs[i].N / 128); }
+    bool big = false;
+    if (n128 && !(gt && gt[0] == '1')) {
+        const double rounds = t22 / 512.0;                          // two resident 128 x 128 workgroups per CU
+        const double q = rounds / (double)(long)(rounds + 0.999999);
+        big = (gt && gt[0] == '2') || (rounds >= 2.0 && q >= 0.93);
     }
-    G.tile_start[n] = tiles; G.n = n;
-    int per_xcd = 0;                                            // blocks an XCD may have to walk: sum of its largest shares
-    for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
-    const dim3 grid(per_xcd * NXCD);
-    if (tA) {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, true, false, false>), grid, dim3(256), 0, s, G);
-    } else if (tB) {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, true, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, true, false>), grid, dim3(256), 0, s, G);
-    } else {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<1, 1, false, false, false>), grid, dim3(256), 0, s, G);
-    }
-    return hipGetLastError();
+    return big ? launch_group_cfg<2, 2>(s, gs, n, tA, tB) : launch_group_cfg<1, 1>(s, gs, n, tA, tB);
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {

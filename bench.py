@@ -261,16 +261,68 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
         dist.destroy_process_group()
 
 
-def measured_traffic(args, dec):
-    """HBM-side bytes per launch of the kernels named in the bench line, from the rocprofv3 PMC passes committed under
-    profiles/ (separate --pmc FETCH_SIZE / WRITE_SIZE runs of this very command, FETCH_SIZE doubled per the gfx950
-    correction: profiles/README.md, tools/pmc_summary.py --json).  Counters cannot be read from inside the timed run, so a
-    configuration that has no committed PMC summary reports null."""
+TRAFFIC_KERNELS = {"gemm_nn": ("gemm2_group_kernel<1, 1, false, false, false>", "gemm2_group_kernel<2, 2, false, false, false>",
+                               "gemm2_kernel<1, 1, false, false, false>", "gemm2_kernel<2, 2, false, false, false>",
+                               "gemm3_group_kernel", "gemm3_kernel"),
+                   "spatial": ("spatial2_kernel<128>", "spatial_kernel", "spatial_bf16_kernel"),
+                   "spatial_bwd": ("spatial_bwd_kernel",), "temporal": ("temporal_kernel",), "ctxgrad": ("ctxgrad_kernel",)}
+
+
+def live_traffic(args):
+    """HBM-side bytes per launch measured NOW: two short child runs of this very command under
+    `rocprofv3 --pmc FETCH_SIZE` / `--pmc WRITE_SIZE` (separate passes, kernel trace only), mean per launch per kernel
+    class; FETCH_SIZE (KiB) is doubled -- the gfx950 correction, calibrated on the access patterns of these kernels by
+    tools/fetch_calib.hip (profiles/r03_fetch_calibration.csv).  Returns {} when rocprofv3 is not there or a pass fails."""
+    import csv
+    import shutil
+    import subprocess
+    import tempfile
+    if not shutil.which("rocprofv3") or os.environ.get("STATTN_BENCH_CHILD"):
+        return {}
+    tot = {}
+    try:
+        for ctr, mult in (("FETCH_SIZE", 2.0), ("WRITE_SIZE", 1.0)):
+            with tempfile.TemporaryDirectory(dir="/tmp") as d:
+                cmd = ["rocprofv3", "--pmc", ctr, "--kernel-trace", "--output-format", "csv", "-d", d, "-o", "t", "--",
+                       sys.executable, os.path.abspath(__file__), "--steps", "1", "--warmup", "1", "--no-cpu-baseline", "--no-split",
+                       "--no-live-pmc", "--mode", args.mode, "--config", args.config, "--precision", args.precision]
+                if args.lt_mode is not None:
+                    cmd += ["--lt-mode", str(args.lt_mode)]
+                env = dict(os.environ, STATTN_BENCH_CHILD="1", TMPDIR="/tmp")
+                r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240)
+                files = [os.path.join(dp, f) for dp, _, fs in os.walk(d) for f in fs if f.endswith("counter_collection.csv")]
+                if r.returncode != 0 or not files:
+                    return {}
+                for row in csv.DictReader(open(files[0])):
+                    if row["Counter_Name"] != ctr:
+                        continue
+                    for cls, pats in TRAFFIC_KERNELS.items():
+                        if any(p_ in row["Kernel_Name"] for p_ in pats):
+                            t_ = tot.setdefault(cls, {"FETCH_SIZE": [0.0, 0], "WRITE_SIZE": [0.0, 0]})[ctr]
+                            t_[0] += float(row["Counter_Value"]) * 1024.0 * mult
+                            t_[1] += 1
+    except Exception:
+        return {}
+    out = {}
+    for cls, v in tot.items():
+        if v["FETCH_SIZE"][1] and v["WRITE_SIZE"][1]:
+            out[cls] = v["FETCH_SIZE"][0] / v["FETCH_SIZE"][1] + v["WRITE_SIZE"][0] / v["WRITE_SIZE"][1]
+    return out
+
+
+def measured_traffic(args, dec, rank=0, world=1):
+    """HBM-side bytes per launch of the kernels named in the bench line (FETCH_SIZE x 2 + WRITE_SIZE): measured live by
+    two rocprofv3 PMC child passes when possible (one GPU, rocprofv3 on the box; `traffic_source` says which), else from
+    the passes committed under profiles/ (profiles/pmc_traffic.json), else null."""
+    if world == 1 and not args.no_live_pmc:
+        live = live_traffic(args)
+        if live:
+            return live, "live: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE child passes of this command (FETCH_SIZE x 2, gfx950)"
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if not os.path.exists(path):
-        return {}
+        return {}, None
     key = "%s/%s/lt%d/%s" % (args.config, args.mode, dec.lt_mode, args.precision)
-    return json.load(open(path)).get(key, {})
+    return json.load(open(path)).get(key, {}), "profiles/pmc_traffic.json (committed rocprofv3 PMC passes)"
 
 
 def spawn_ranks(n):
@@ -319,6 +371,8 @@ def main():
                     help="bf16: the bf16-MFMA path of BASELINE configs[3]; split: fp32 results with the large GEMMs on the bf16 matrix "
                          "cores through exactly split operands (neither is the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure "
+                                                               "the `traffic` fields live (falls back to profiles/pmc_traffic.json)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra precision='split' measurement reported beside the fp32 headline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
     args = ap.parse_args()
@@ -457,7 +511,7 @@ def main():
     split = args.precision == "split"
     # split: fp32 work done as six bf16 MFMA products per multiply -> the roof is the dense bf16 peak / 6
     mfma_peak = MFMA_BF16_PEAK_TF if bf16 else (MFMA_BF16_PEAK_TF / 6.0 if split else MFMA_F32_PEAK_TF)
-    traffic = measured_traffic(args, dec)            # rocprofv3 PMC bytes per launch from profiles/, or {}
+    traffic, traffic_source = measured_traffic(args, dec, rank, world) if rank == 0 else ({}, None)
     # (1) dominant kernel class by time share: the LDS-tiled MFMA GEMM.  `roofline` = all plain (NN) launches of one
     #     forward pass (flops per launch / average launch duration); `kernels` below has every launch on its own.
     BTK, BT, R = B * T * K, B * T, B * t
@@ -570,6 +624,7 @@ def main():
                roofline=roofline, roofline_hbm=roofline_hbm, kernels=kernels,
                decoder_step_us=step_ms * 1e3,       # sum of the per-step kernel classes (HIP events, includes the record gaps)
                kernel_ms={k: v[0] for k, v in kms.items()})
+    out["traffic_source"] = traffic_source
     if bwd_step_ms is not None:
         out["reverse_step_us"] = bwd_step_ms * 1e3      # the six launches of one reverse-scan step
     if comm:

@@ -156,6 +156,17 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
                        const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
                        int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count);
 
+/* gen_sample(stochastic=True) (model_attention.py:863-918) for 1 .. 16 videos at once, on the device: every word is a draw
+ * from the next-word distribution (the reference draws with Theano's MRG stream at :841; here Gumbel-max on the logits with
+ * the library's counter-based generator, seeded by stattn_set_seed and a per-call counter), the caption ends with the first
+ * <eos> -- which is part of the sample -- or after maxlen words.  out_tokens (nvid, maxlen) padded with -1, out_lens
+ * (nvid,), out_scores (nvid,) = the SUM of the drawn words' probabilities, as the reference computes it (:916).
+ * Features as in stattn_beam_search (all NULL: the videos staged by stattn_beam_stage).  stattn_beam_final_state works
+ * after it as after a beam search. */
+int stattn_sample_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                         const float* ctxm, int T, int K, int maxlen,
+                         int64_t* out_tokens, float* out_scores, int32_t* out_lens);
+
 /* gen_sample's third and fourth return values (next_state, next_memory, :994) for the videos of the last
  * stattn_beam_search: out_h / out_c (nvid,k,D), the first out_rows[v] rows of video v are valid -- the state outputs of
  * the f_next call that ended the video's loop (every live hypothesis at that point), or the gathered states of the

@@ -670,3 +670,69 @@ def test_reference_executed_gen_sample_on_the_hip_path(stattn_mod, O, device_loo
             assert np.abs(hs[0] - fx[tag + '_state']).max() < TOL and np.abs(cs[0] - fx[tag + '_memory']).max() < TOL
             n_eos += sum(1 for x in want if x[-1] == 0)
     assert n_eos >= 60
+
+
+def test_device_side_stochastic_gen_sample(stattn_mod, O):
+    """gen_sample(stochastic=True) on the device (stattn_sample_search: Gumbel-max draws in the logits launch).  The draws
+    cannot equal Theano's MRG stream (nor the host loop's numpy one), so the checks are: (1) the score is the SUM of the
+    drawn words' probabilities (model_attention.py:916) -- verified by teacher-forcing the drawn words through the
+    oracle's f_next; (2) a caption ends with its first <eos>, which is part of the sample (:914-918); (3) same seed, same
+    call index -> same draws, other seed -> other draws; (4) the first word follows the oracle's next-word distribution
+    (2000 draws, total-variation distance)."""
+    opt = O.default_options(dim=64, dim_word=64, n_words=37, ctxg_dim=64, ctxl_dim=32, ctxm_dim=32, ctxglm_dim=64)
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden')
+    P = dict(np.load(os.path.join(gold, 'params.npz')))
+    P['ff_logit_W'] = P['ff_logit_W'] * np.float32(6.0)
+    P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += np.float32(1.0)
+    P64 = O.cast_params(P, np.float64)
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    dec = tparams.decoder
+    b = O.synthetic_batch(opt, B=4, T=5, K=3, t=3, seed=70)
+    fi, fn = O.sampler_closures(P64, opt, np.float64)
+
+    def teacher_forced_score(v, words):
+        args = (b['ctxg'][v].astype(np.float64), b['mask_ctxg'][v], b['ctxl'][v].astype(np.float64), None, b['ctxm'][v].astype(np.float64), None)
+        _, h, c = fi(args[0], args[1])
+        h, c, x, tot = h[None], c[None], np.array([-1], np.int64), 0.0
+        for w in words:
+            p, _, h, c = fn(x, *args, h, c)
+            tot += p[0, w]
+            x = np.array([w], np.int64)
+        return tot
+
+    dec.set_seed(99)
+    first = dec.sample_search(b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], maxlen=12)
+    n_eos = 0
+    for v, (words, score) in enumerate(first):
+        assert 1 <= len(words) <= 12 and all(0 <= w < 37 for w in words)
+        assert 0 not in words[:-1]                                   # the caption stops at its first <eos>
+        n_eos += words[-1] == 0
+        assert len(words) == 12 or words[-1] == 0
+        np.testing.assert_allclose(score, teacher_forced_score(v, words), rtol=0, atol=TOL * len(words))
+    dec.set_seed(99)
+    again = dec.sample_search(b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], maxlen=12)
+    assert [w for w, _ in again] == [w for w, _ in first]
+    nxt = dec.sample_search(b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], maxlen=12)      # next call index: new draws
+    dec.set_seed(7)
+    other = dec.sample_search(b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], maxlen=12)
+    assert [w for w, _ in nxt] != [w for w, _ in first] and [w for w, _ in other] != [w for w, _ in first]
+    # first-word distribution of video 0 against the oracle's probabilities
+    g, gm, l, m = b['ctxg'][:1], b['mask_ctxg'][:1], b['ctxl'][:1], b['ctxm'][:1]
+    dec.beam_stage(np.repeat(g, 16, 0), np.repeat(gm, 16, 0), np.repeat(l, 16, 0), np.repeat(m, 16, 0))
+    counts = np.zeros(37)
+    for _ in range(125):                                             # 125 calls x 16 copies of the video = 2000 draws
+        for words, _ in dec.sample_search(maxlen=1, resident=True):
+            counts[words[0]] += 1
+    _, h0, c0 = fi(g[0].astype(np.float64), gm[0])
+    p0 = fn(np.array([-1], np.int64), g[0].astype(np.float64), gm[0], l[0].astype(np.float64), None, m[0].astype(np.float64), None, h0[None], c0[None])[0][0]
+    tv = 0.5 * np.abs(counts / counts.sum() - p0).sum()
+    assert tv < 0.06, (tv, counts, p0)                               # expected ~0.03 for 2000 draws over this distribution
+    # the reference surface: Attention.gen_sample(stochastic=True) runs this path and keeps gen_sample's return shape
+    dec.set_seed(5)
+    sample, score, hs, cs = model.gen_sample(tparams, f_init, f_next, b['ctxg'][1], b['mask_ctxg'][1], b['ctxl'][1], b['mask_ctxl'][1],
+                                             b['ctxm'][1], b['mask_ctxm'][1], opt, None, 1, 9, True)
+    assert isinstance(sample, list) and 1 <= len(sample) <= 9 and isinstance(score, float)
+    assert isinstance(hs, list) and hs[0].shape == (1, 64) and cs[0].shape == (1, 64)
+    np.testing.assert_allclose(score, teacher_forced_score(1, sample), rtol=0, atol=TOL * len(sample))

@@ -58,6 +58,7 @@ _SIGNATURES = {
     "stattn_beam_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                      _I64, _F, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
     "stattn_beam_final_state": (C.c_int, [_H, _F, _F, C.POINTER(C.c_int32)]),
+    "stattn_sample_search": (C.c_int, [_H, C.c_int, _F, _F, _F, _F, C.c_int, C.c_int, C.c_int, _I64, _F, C.POINTER(C.c_int32)]),
     "stattn_set_batch": (C.c_int, [_H, _I64, _F, C.c_int, C.c_int, _F, _F, _F, _F, _F, _F, C.c_int, C.c_int]),
     "stattn_host_alloc": (C.c_int, [C.c_size_t, C.POINTER(C.c_void_p)]),
     "stattn_host_free": (C.c_int, [C.c_void_p]),
@@ -385,6 +386,25 @@ class Decoder(object):
             samples = [tok[v, j, :ln[v, j]].tolist() for j in range(cnt[v])]
             out.append((samples, sc[v, :cnt[v]].copy()))
         return out
+
+    def sample_search(self, ctxg=None, ctxg_mask=None, ctxl=None, ctxm=None, maxlen=30, resident=False):
+        """gen_sample(stochastic=True) for a batch of at most 16 videos, device-side (stattn_sample_search): one
+        (word list, score) pair per video -- the words include the closing <eos> when one was drawn, the score is the
+        sum of the drawn words' probabilities (model_attention.py:913-918)."""
+        if resident:
+            if getattr(self, "_staged", None) is None:
+                raise ValueError("sample_search(resident=True) needs beam_stage() first")
+            nvid, T, K = self._staged
+            pg = pk = pl = pm = None
+        else:
+            ctxg, ctxg_mask, ctxl, ctxm, nvid, T, K = self._beam_shapes(ctxg, ctxg_mask, ctxl, ctxm)
+            pg, pk, pl, pm = _fp(ctxg), _fp(ctxg_mask), _fp(ctxl), _fp(ctxm)
+            self._staged = (nvid, T, K)
+        tok = np.empty((nvid, maxlen), np.int64); sc = np.empty((nvid,), np.float32); ln = np.empty((nvid,), np.int32)
+        self._chk(self._lib.stattn_sample_search(self._h, nvid, pg, pk, pl, pm, T, K, int(maxlen), tok.ctypes.data_as(_I64),
+                                                 _fp(sc), ln.ctypes.data_as(C.POINTER(C.c_int32))))
+        self._beam_shape = (nvid, 1)
+        return [(tok[v, :ln[v]].tolist(), float(sc[v])) for v in range(nvid)]
 
     def beam_final_state(self):
         """(next_state, next_memory) of gen_sample for every video of the last beam_search: a list of

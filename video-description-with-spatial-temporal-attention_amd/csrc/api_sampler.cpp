@@ -243,9 +243,32 @@ int stattn_beam_stage(stattn_handle* h, int nvid, const float* ctxg, const float
     return beam_stage_impl(h, nvid, ctxg, ctxg_mask, ctxl, ctxm, T, K);
 }
 
+static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                            const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos, int stochastic,
+                            int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count);
+
 int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
                        const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos,
                        int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count) {
+    return beam_search_impl(h, nvid, ctxg, ctxg_mask, ctxl, ctxm, T, K, k, maxlen, suppress_eos, 0, out_tokens, out_scores, out_lens, out_count);
+}
+
+// gen_sample(stochastic=True) (model_attention.py:863-918) for up to 16 videos at once, on the device: every word is a
+// draw from the next-word distribution (Gumbel-max in the logits launch: no probabilities leave the chip), the caption
+// ends with the first <eos> (which is part of the sample, :914-918) or after maxlen words, and the score is the SUM of
+// the drawn words' probabilities, as the reference computes it (:916).  Draws follow the handle's seed (stattn_set_seed)
+// and a per-call counter: reproducible, different from call to call.
+int stattn_sample_search(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                         const float* ctxm, int T, int K, int maxlen, int64_t* out_tokens, float* out_scores, int32_t* out_lens) {
+    if (!h || nvid < 1 || nvid > 16) return fail(h, STATTN_EINVAL, "sample_search: 1 <= nvid <= 16");
+    if (h->opt.precision == 1) return fail(h, STATTN_EINVAL, "sample_search: not available on a bf16 handle");
+    std::vector<int32_t> cnt(nvid);
+    return beam_search_impl(h, nvid, ctxg, ctxg_mask, ctxl, ctxm, T, K, 1, maxlen, 0, 1, out_tokens, out_scores, out_lens, cnt.data());
+}
+
+static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const float* ctxg_mask, const float* ctxl,
+                            const float* ctxm, int T, int K, int k, int maxlen, int suppress_eos, int stochastic,
+                            int64_t* out_tokens, float* out_scores, int32_t* out_lens, int32_t* out_count) {
     const bool resident = !ctxg && !ctxg_mask && !ctxl && !ctxm;
     if (!h || nvid <= 0 || (!resident && (!ctxg || !ctxg_mask || !ctxl || !ctxm)) || T <= 0 || K <= 0 || k < 1 || k > 8 ||
         maxlen < 1 || !out_tokens || !out_scores || !out_lens || !out_count)
@@ -346,7 +369,14 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     // with the hypotheses instead of recomputing them), logits with the vocabulary statistics in the epilogue (tile
     // max / sum-exp / best candidates: no logits or probabilities are stored, no softmax or top-k launch), update.
     static const char* nosmall = getenv("STATTN_BEAM_NOSMALL");       // A/B switch for tools
-    const bool small = panels && M <= 16 && h->opt.precision != 1 && !nosmall;
+    const bool small = panels && M <= 16 && h->opt.precision != 1 && (!nosmall || stochastic);
+    if (stochastic && !small) return fail(h, STATTN_EINVAL, "sample_search: needs the row-panel path (at most 16 rows, dim / dim_word multiples of 16)");
+    unsigned long long* d_seed = nullptr;
+    if (stochastic) {      // seed of this call's draws, in device memory (the captured word graph is reused from call to call)
+        const unsigned long long draw_seed = (h->seed * 0x9E3779B97F4A7C15ull + 0x632BE59BD9B4E019ull * (++h->draw)) | 1ull;
+        CHK(getbuf_t(h, "bs_seed", (size_t)1, &d_seed));
+        HIPCHK(h, hipMemcpy(d_seed, &draw_seed, sizeof draw_seed, hipMemcpyHostToDevice));
+    }
     float *proj = nullptr, *proj_step = nullptr, *ho_pk = nullptr, *vstats = nullptr;
     int vtile = 0;
     PnArgs lgargs{};
@@ -361,6 +391,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
         so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
         so.stats_V = V; so.stats_kb = k; so.stats_skip0 = suppress_eos ? 1 : 0;
+        so.stats_seed = d_seed; so.stats_step = d_step;
         vtile = Vp / panel_tile_cols(lgargs);
         CHK(getbuf_t(h, "bs_vstats", (size_t)M * vtile * PN_STATS_REC, &vstats));
         so.stats = vstats;
@@ -464,7 +495,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
         if (small) {
-            ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile;
+            ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile; ba.tile_cols = Vp / vtile; ba.stochastic = stochastic;
             ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D;
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
@@ -482,7 +513,7 @@ int stattn_beam_search(stattn_handle* h, int nvid, const float* ctxg, const floa
     static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
     h->beam_graph_replays = 0;
     // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
-    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos,
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed,
                                   (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
     for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
                           (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,

@@ -152,15 +152,22 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
         const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
         for (int j = 0; j < live; ++j) {
             const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
-            const float base = a.hyp_score[v * k + j] + s_lse[j];
+            const float base = a.stochastic ? 0.f : a.hyp_score[v * k + j] + s_lse[j];
             for (int e = tid; e < per; e += 256) {
                 const int t = e / nsel, i = e - t * nsel;
-                const float val = rec[(size_t)t * PN_STATS_REC + 2 + i];
+                const float val = rec[(size_t)t * PN_STATS_REC + 2 + i];       // (stochastic: the tile's best PERTURBED value)
                 if (val > -INFINITY)
                     list_insert(lc, li, base - val, j * V + reinterpret_cast<const int*>(rec)[(size_t)t * PN_STATS_REC + 2 + PN_STATS_KB + i]);
             }
         }
         block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
+        if (a.stochastic && tid == 0 && res_i[0] != 0x7fffffff) {
+            // the draw is word res_i[0]; gen_sample's stochastic "score" is the running SUM of the drawn words'
+            // probabilities (model_attention.py:916): p = exp(v - lse) with v the unperturbed logit kept by the tile
+            const int col = res_i[0] % V;
+            const float* rec = a.stats + ((size_t)(v * k) * nt + col / a.tile_cols) * PN_STATS_REC;
+            res_c[0] = a.hyp_score[v * k] + __expf(rec[3] - s_lse[0]);
+        }
     } else if (nsel > 0) {                                     // (uniform over the workgroup)
         float lc[KB]; int li[KB];
 #pragma unroll
@@ -262,7 +269,7 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
 }
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx) {
     if (!a.ticket) return hipErrorInvalidValue;
-    if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB)) return hipErrorInvalidValue;
+    if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB || (a.stochastic && (a.k != 1 || a.tile_cols < 1)))) return hipErrorInvalidValue;
     if (a.proj_next && (!a.proj_step || a.nproj % 4)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
     return hipGetLastError();

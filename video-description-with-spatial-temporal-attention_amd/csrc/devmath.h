@@ -48,6 +48,18 @@ __device__ __forceinline__ int xcd_rows(int n, int rows, int per_row) {
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
 
+// counter-based generator (splitmix64 finaliser): u in (0, 1) from (seed, a, b), and the Gumbel(0, 1) variate -log(-log u)
+__device__ __forceinline__ unsigned long long mix64_dev(unsigned long long z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+__device__ __forceinline__ float gumbel01(unsigned long long seed, unsigned long long a, unsigned long long b) {
+    const unsigned long long hsh = mix64_dev(mix64_dev(seed ^ (a * 0x9E3779B97F4A7C15ull)) + b);
+    const float u = ((float)(hsh >> 40) + 0.5f) * (1.0f / 16777216.0f);      // (0, 1), never 0 or 1
+    return -__logf(-__logf(u));
+}
+
 // e^{2x} per component, exponent clamped to +-80.  tanh(x + s) = 1 - 2 / (1 + e^{2x} e^{2s}) lets kernels that evaluate
 // tanh(x + s_i) for MANY shifts s_i of the same x (the H hypotheses of a video in beam search, the 30 time steps of the
 // deferred context gradients) pay one v_exp per x and per shift and only a v_rcp per pair -- one transcendental instead

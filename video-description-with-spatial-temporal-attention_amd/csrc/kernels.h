@@ -169,6 +169,11 @@ struct PnSeg {
     // per (row, column tile) one PnTileStats record of the biased values v[n], n < stats_V (column 0 excluded when
     // stats_skip0): tile max, sum exp(v - max), and the stats_kb largest values with their columns.
     float* stats; int stats_V, stats_kb, stats_skip0;
+    // ancestral sampling (gen_sample(stochastic=True), model_attention.py:841, :913-918): with stats_seed given the ONE
+    // candidate of a tile is its arg-max of v[n] + Gumbel noise (Gumbel-max: the arg-max over the whole vocabulary is a
+    // draw from softmax(v)); record [2] = the perturbed value, [3] = v of that column.  Noise is keyed by
+    // (*stats_seed, *stats_step, row, n): reproducible, independent of the tiling.
+    const unsigned long long* stats_seed; const int* stats_step;     // device words (a captured graph replays with new draws)
 };
 // record layout (floats): [0] max, [1] sum of exp(v - max), [2 .. 2+8) values descending, [10 .. 18) their columns (int bits)
 constexpr int PN_STATS_KB = 8;
@@ -408,7 +413,9 @@ struct BeamArgs {
     int* ticket;                        // device int, zero: last workgroup of the update advances *step
     // small-batch decode step: instead of `probs`, per (row, vocabulary tile) statistics written by the logits launch
     // (PnSeg::stats): the update forms log-sum-exp per row and selects among the tiles' best candidates
-    const float* stats; int ntile;
+    const float* stats; int ntile, tile_cols;     // tiles per row and their width (16 / 32 columns)
+    int stochastic;                     // stats mode, k = 1: the candidate with the largest PERTURBED value is the draw; its
+                                        // "cost" is the running sum of p(word) (:916), word 0 ends the caption (:917)
     // ... and gathers the NEXT step's state projections (computed from h of this step before the beam was re-ordered)
     const float* proj_step; float* proj_next; int nproj;   // [nvid*k, nproj] rows (sproj | preh), or null
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop

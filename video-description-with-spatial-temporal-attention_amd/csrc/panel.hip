@@ -105,6 +105,15 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
             const float se = wave_sum(v > -INFINITY ? __expf(v - mx) : 0.f);
             float* rec = sg.stats + ((size_t)row * ntile + tg) * PN_STATS_REC;
             if (lane == 0) { rec[0] = mx; rec[1] = se; }
+            if (sg.stats_seed) {                          // ancestral sampling: arg-max of v + Gumbel noise within the tile
+                const float pv = v > -INFINITY ? v + gumbel01(*sg.stats_seed, (unsigned long long)(*sg.stats_step) * 65536ull + row, n0 + lane) : -INFINITY;
+                const float m = wave_max(pv);
+                const unsigned long long hit = __ballot(pv == m);
+                const int src = __ffsll((long long)hit) - 1;
+                const float vsrc = __shfl(v, src, 64);
+                if (lane == 0) { rec[2] = m; rec[3] = vsrc; reinterpret_cast<int*>(rec)[2 + PN_STATS_KB] = n0 + src; }
+                continue;
+            }
             for (int i = 0; i < sg.stats_kb; ++i) {       // the kb largest, ties to the lower column
                 const float m = wave_max(v);
                 const unsigned long long hit = __ballot(v == m);

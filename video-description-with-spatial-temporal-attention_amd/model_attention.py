@@ -345,6 +345,12 @@ class Attention(object):
         if restrict_voc:
             raise NotImplementedError()
         dec = getattr(f_next, 'decoder', None)
+        if dec is not None and stochastic and getattr(f_next, 'device_loop', False) and dec.precision != 'bf16':
+            # ancestral sampling on the device as well (stattn_sample_search: Gumbel-max in the logits launch, no m x V
+            # copy per word); `sample` is one flat word list and the score the summed probabilities, like :913-918
+            (sample, score), = dec.sample_search(ctxg_0[None], ctxg_mask[None], ctxl_0[None], ctxm_0[None], maxlen=maxlen)
+            (hh, cc), = dec.beam_final_state()
+            return sample, score, [hh], [cc]
         if dec is not None and not stochastic and k <= 8 and getattr(f_next, 'device_loop', False):
             # the whole loop on the device (stattn_beam_search: hipGraph-captured word sequence, no per-word host
             # round trip); k = 1 is the greedy decode of :896-918

@@ -541,7 +541,10 @@ def main():
     nslab = 3 if dec.lt_mode == 1 else 2              # PL, L (and LW in lt_mode 1)
     slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
     sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
-    if not bf16 and D % 1024 == 0 and B <= 64 and B >= 17 and not os.environ.get("STATTN_NO_RIDER"):
+    # the off-critical-path halves of the recurrent GEMMs ride in the attention launches
+    fwd_rider = not bf16 and D % 1024 == 0 and 17 <= B <= 64 and not os.environ.get("STATTN_NO_RIDER")
+    bwd_rider = 17 <= B <= 64 and not os.environ.get("STATTN_NO_RIDER") and not os.environ.get("STATTN_NO_PANELS")
+    if fwd_rider:
         sp_bytes += 4.0 * D * 4 * D                   # the riding h.U GEMM streams decoder_U once per launch
     sp_name = "spatial_bf16_kernel" if bf16 else ("spatial2_kernel<128>" if D % 1024 == 0 else "spatial_kernel")
 
@@ -565,7 +568,9 @@ def main():
     # (3) every kernel of the per-step chain and every GEMM launch of the pass on its own roof
     kernels = dict(
         spatial=roofline_hbm,
-        state_proj=mfma("h.[Wdl|Wdg|Wdm|Wdlt|U] (panel_kernel / skinny)", 2.0 * B * D * 8 * D, kms["hproj"][0], 8.0 * D * D * 4),
+        state_proj=(mfma("h.[Wdl|Wdg|Wdm|Wdlt] (panel_kernel; h.U rides in the attention launch)", 2.0 * B * D * 4 * D, kms["hproj"][0], 4.0 * D * D * 4)
+                    if fwd_rider else
+                    mfma("h.[Wdl|Wdg|Wdm|Wdlt|U] (panel_kernel / skinny)", 2.0 * B * D * 8 * D, kms["hproj"][0], 8.0 * D * D * 4)),
         lstm=mfma("ctx.Wc + gates (lstm_panel_kernel / lstm_kernel)", 2.0 * B * D * 4 * D, kms["lstm"][0], 4.0 * D * D * 4),
         temporal=hbm("temporal_kernel", B * T * D * 4.0 * 3, kms["temporal"][0], "temporal"))
     for l_, ms in zip(launches, gms):
@@ -599,9 +604,13 @@ def main():
                                                            kind, " + ".join("%dx%dx%d" % x_ for x_ in shapes)),
                                              sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in shapes), ms)
         # the reverse-scan chain (one launch of each per decoder step) and the deferred context-gradient kernel
-        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel (+ temporal backward, + riding dhU GEMM)", B * T * D * (4.0 * 3 * K + 4.0 * 9) + 4.0 * 4 * D * D,
+        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel (+ temporal backward%s)" % (", + riding dhU = dpre.U^T GEMM" if bwd_rider else ""),
+                                     B * T * D * (4.0 * 3 * K + 4.0 * 9) + (4.0 * 4 * D * D if bwd_rider else 0.0),
                                      bkms["spatial_bwd"][0], "spatial_bwd")
-        kernels["bwd_panel_dctx_dhU"] = mfma("dpre.[Wc^T|U^T] (panel_kernel, K-split)", 2.0 * B * 4 * D * 2 * D, bkms["panel_dctx_dhU"][0], 8.0 * D * D * 4)
+        if bwd_rider:
+            kernels["bwd_panel_dctx"] = mfma("dpre.Wc^T (panel_kernel, K-split; dpre.U^T rides in spatial_bwd)", 2.0 * B * 4 * D * D, bkms["panel_dctx_dhU"][0], 4.0 * D * D * 4)
+        else:
+            kernels["bwd_panel_dctx_dhU"] = mfma("dpre.[Wc^T|U^T] (panel_kernel, K-split)", 2.0 * B * 4 * D * 2 * D, bkms["panel_dctx_dhU"][0], 8.0 * D * D * 4)
         kernels["bwd_panel_dhW"] = mfma("dsproj.[Wd*]^T (panel_kernel, K-split)", 2.0 * B * 4 * D * D, bkms["panel_dhW"][0], 4.0 * D * D * 4)
         for nm in ("lstm_bwd", "temporal_bwd", "reduce_T"):
             if bkms[nm][1]:                           # (temporal_bwd: fused into spatial_bwd, no launches of its own)

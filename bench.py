@@ -353,6 +353,28 @@ def spawn_ranks(n):
         raise SystemExit("a rank failed (exit code %d)" % rc)
 
 
+class stdout_to_stderr(object):
+    """gloo ("[Gloo] Rank r is connected to ...") and RCCL (its version / library-path banner) print to STDOUT from
+    C / C++.  stdout carries the one JSON line of the contract and nothing else, so file descriptor 1 points at stderr
+    while they initialise; C stdio is flushed before it is switched back (RCCL's banner sits in libc's buffer)."""
+
+    def __enter__(self):
+        sys.stdout.flush()
+        self.keep = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        import ctypes
+        sys.stdout.flush()
+        try:
+            ctypes.CDLL(None).fflush(None)
+        except Exception:
+            pass
+        os.dup2(self.keep, 1)
+        os.close(self.keep)
+        return False
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -371,6 +393,9 @@ def main():
                     help="bf16: the bf16-MFMA path of BASELINE configs[3]; split: fp32 results with the large GEMMs on the bf16 matrix "
                          "cores through exactly split operands (neither is the headline)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--share-gpu", action="store_true", help="functional check of the N > 1 path on a 1-GPU box: all ranks run on "
+                    "cuda:0 and RCCL connects them over its socket transport (every rank poses as its own host); the line is "
+                    "marked shared_gpu and is NOT a scaling number")
     ap.add_argument("--no-live-pmc", action="store_true", help="do not spawn the two rocprofv3 --pmc child passes that measure "
                                                                "the `traffic` fields live (falls back to profiles/pmc_traffic.json)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra precision='split' measurement reported beside the fp32 headline")
@@ -394,14 +419,22 @@ def main():
                          % (args.gpus, world, args.gpus, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libstattn has no CPU path)")
-    if world > torch.cuda.device_count():
+    if args.share_gpu:
+        # RCCL refuses two ranks on one device of one host: every rank poses as a host of its own and RCCL connects
+        # them through its socket transport over loopback (functional check of the N > 1 path on a 1-GPU box)
+        local = 0
+        os.environ.update(NCCL_HOSTID="stattn-bench-rank-%d" % rank, NCCL_SOCKET_IFNAME="lo", NCCL_IB_DISABLE="1",
+                          NCCL_P2P_DISABLE="1", NCCL_SHM_DISABLE="1")
+    if world > torch.cuda.device_count() and not args.share_gpu:
         raise SystemExit("--gpus %d but this node shows %d GPU(s)" % (world, torch.cuda.device_count()))
     torch.cuda.set_device(local)
     if world > 1:
         # torch.distributed is the CONTROL plane only (rendezvous token, barrier, max-over-ranks of the clock): gloo
         # over 127.0.0.1.  The data path -- the gradient all-reduce -- is RCCL inside libstattn.so (csrc/comm.cpp).
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("gloo")
+        with stdout_to_stderr():
+            dist.init_process_group("gloo")
+            dist.barrier()
 
     import stattn
     from stattn import dp
@@ -419,7 +452,8 @@ def main():
     train = args.mode == "train"
     dec.set_use_noise(1.0 if train else 0.0)
     if train:
-        dp.init_comm(dec, rank, world)                # RCCL communicator (world > 1), rank 0's weights, seed + rank
+        with stdout_to_stderr():
+            dp.init_comm(dec, rank, world)            # RCCL communicator (world > 1), rank 0's weights, seed + rank
         ncomm = dec.comm_info()[1]
         if world > 1 and ncomm != world:
             raise SystemExit("RCCL communicator has %d ranks, expected %d" % (ncomm, world))
@@ -629,7 +663,7 @@ def main():
                                        "optimisation step = build_model forward + BPTT backward + gradient all-reduce + clip + Adadelta"
                                        if train else "build_model forward (teacher-forced decoder pass + readout + softmax/NLL)",
                                        B, T, K, c["F"], D, c["E"], c["V"], c["t"], dec.lt_mode),
-                           global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world, h2d=args.h2d),
+                           global_batch=B * world, caption_len=c["t"], parallelism="dp%d" % world + (" (ranks time-sharing ONE GPU, RCCL socket transport over loopback: functional run of the N > 1 path, not a scaling number)" if args.share_gpu else ""), h2d=args.h2d),
                roofline=roofline, roofline_hbm=roofline_hbm, kernels=kernels,
                decoder_step_us=step_ms * 1e3,       # sum of the per-step kernel classes (HIP events, includes the record gaps)
                kernel_ms={k: v[0] for k, v in kms.items()})
@@ -638,6 +672,8 @@ def main():
         out["reverse_step_us"] = bwd_step_ms * 1e3      # the six launches of one reverse-scan step
     if comm:
         out.update(comm)
+    if args.share_gpu:
+        out["shared_gpu"] = True
     if args.precision == "fp32" and world == 1 and not args.no_split and args.h2d == "none":
         # The same workload with precision='split' (fp32 results, the big GEMMs on the bf16 matrix cores with exactly
         # split operands: csrc/gemm_split.hip), reported beside the headline, never as it.
@@ -670,6 +706,8 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, options, params, 99, train)
         print(json.dumps(out))
+    sys.stdout.flush()
+    os.dup2(2, 1)                         # whatever C libraries still hold in their stdio buffers goes to stderr at exit
     if world > 1:
         dist.barrier()
         if train:

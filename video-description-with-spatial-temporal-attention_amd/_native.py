@@ -99,6 +99,34 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 DEBUG_SYMBOLS = tuple(_DBG_SIGNATURES)
 
 
+def _one_hip_runtime():
+    """One HIP runtime per process.  libstattn.so needs `libamdhip64.so.7`; torch ships its own copy under torch/lib
+    and asks for it as `libamdhip64.so`, so whichever of the two libraries is loaded SECOND brings a second HIP + HSA
+    runtime when libstattn came first (torch first is fine: its copy carries the soname libstattn asks for).  The
+    second runtime cannot open the GPU again, and whatever binds to it -- torch.cuda, torch's RCCL -- finds no device.
+    So when torch is installed (not necessarily imported) and no HIP runtime is loaded yet, torch's copy is loaded
+    first and libstattn binds to it."""
+    try:
+        with open("/proc/self/maps") as f:
+            if "libamdhip64" in f.read():
+                return
+    except OSError:
+        pass
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def load_library():
     """dlopen libstattn.so and declare every prototype.  Loading needs no GPU."""
     global _LIB
@@ -108,6 +136,7 @@ def load_library():
     if not os.path.exists(path):
         raise NativeError("%s is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "(or `make -C %s/csrc`).  stattn has no CPU fallback." % (path, _HERE))
+    _one_hip_runtime()
     lib = C.CDLL(path)
     for name, (res, args) in list(_SIGNATURES.items()) + list(_DBG_SIGNATURES.items()):
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol

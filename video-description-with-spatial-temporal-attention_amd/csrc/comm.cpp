@@ -31,7 +31,10 @@ struct Rccl {
 
 // Resolution order: (1) an RCCL this process ALREADY carries (RTLD_NOLOAD: torch ships its own librccl.so under
 // torch/lib and a second copy of the library in one process would mean two sets of IPC / topology state), (2) the
-// loader path, (3) the ROCm install.  The file that was taken is reported by stattn_comm_library_path() and printed
+// librccl that sits NEXT TO the HIP runtime this library is bound to (torch/lib or the ROCm install: RCCL opens
+// "libhsa-runtime64.so" by name, and an RCCL from another directory than the running HIP / HSA pair brings a second,
+// uninitialised HSA runtime into the process -- ncclCommInitRank then reports "no ROCm-capable device"), (3) the
+// loader path, (4) the ROCm install.  The file that was taken is reported by stattn_comm_library_path() and printed
 // once to stderr by the first stattn_comm_init, so a scaling log shows which RCCL ran.
 Rccl* rccl() {
     static Rccl r;
@@ -40,6 +43,20 @@ Rccl* rccl() {
     for (const char* n : names) {
         r.lib = dlopen(n, RTLD_NOW | RTLD_LOCAL | RTLD_NOLOAD);
         if (r.lib) break;
+    }
+    if (!r.lib) {
+        Dl_info hip{};
+        if (dladdr(reinterpret_cast<void*>(&hipGetDeviceCount), &hip) && hip.dli_fname) {
+            std::string dir(hip.dli_fname);
+            const size_t slash = dir.rfind('/');
+            if (slash != std::string::npos) {
+                dir.resize(slash + 1);
+                for (const char* n : {"librccl.so", "librccl.so.1"}) {
+                    r.lib = dlopen((dir + n).c_str(), RTLD_NOW | RTLD_LOCAL);
+                    if (r.lib) break;
+                }
+            }
+        }
     }
     for (const char* n : names) {
         if (r.lib) break;

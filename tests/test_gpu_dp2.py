@@ -1,4 +1,4 @@
-"""A data-parallel step with TWO RCCL ranks (BASELINE configs[2] is 8; the GPU boxes this repo is tested on have one
+"""A data-parallel step with TWO (and three) RCCL ranks (BASELINE configs[2] is 8; the GPU boxes this repo is tested on have one
 GPU).  Two processes share cuda:0.  RCCL refuses two ranks of one communicator on the same device *of the same host*, so
 each rank is given its own NCCL_HOSTID: RCCL then treats them as two single-GPU nodes and connects them through its
 socket transport over the loopback interface.  That is slow and says nothing about xGMI, but everything in csrc/comm.cpp
@@ -45,37 +45,39 @@ def _run_ranks(tmp, mode, world=2, timeout=420):
     return rcs, logs
 
 
-@pytest.mark.parametrize("mode", [1, 0])          # 1: regions overlapped with backward (the default), 0: one all-reduce after it
-def test_two_rccl_ranks_reproduce_the_single_process_step(tmp_path, mode):
+# mode 1: regions overlapped with backward (the default), 0: one all-reduce after it; three ranks: shards of 1 / 2 / 2 rows
+@pytest.mark.parametrize("world,mode", [(2, 1), (2, 0), (3, 1)])
+def test_rccl_ranks_reproduce_the_single_process_step(tmp_path, world, mode):
     import stattn
     from oracle import stattn_oracle_grad as OG
     sys.path.insert(0, HERE)
     import _dp2_worker as W
     tmp = str(tmp_path)
-    rcs, logs = _run_ranks(tmp, mode)
+    rcs, logs = _run_ranks(tmp, mode, world)
     if rcs is None:
         pytest.fail("two-rank RCCL run timed out\n" + logs)
     if any(rcs) and ("Duplicate GPU" in logs or "no socket interface" in logs.lower() or "Bootstrap : no" in logs):
         pytest.skip("this RCCL build / box cannot run two ranks on one GPU over loopback:\n" + logs[-800:])
-    assert rcs == [0, 0], logs
+    assert rcs == [0] * world, logs
     O, opt, P, batch = W.problem()
-    r = [np.load(os.path.join(tmp, "rank%d.npz" % i)) for i in range(2)]
-    meta = [json.load(open(os.path.join(tmp, "rank%d.json" % i))) for i in range(2)]
-    for i in range(2):
-        assert meta[i]["comm_info"] == [i, 2]
-        assert meta[i]["stats"]["ranks"] == 2                   # what RCCL itself reports (ncclCommCount)
+    r = [np.load(os.path.join(tmp, "rank%d.npz" % i)) for i in range(world)]
+    meta = [json.load(open(os.path.join(tmp, "rank%d.json" % i))) for i in range(world)]
+    for i in range(world):
+        assert meta[i]["comm_info"] == [i, world]
+        assert meta[i]["stats"]["ranks"] == world               # what RCCL itself reports (ncclCommCount)
         assert meta[i]["stats"]["overlap"] == mode
         assert meta[i]["stats"]["regions"] == (4 if mode else 0)
         assert "librccl" in meta[i]["library"]
     # the broadcast made rank 1 start from rank 0's parameters
     for k in P:
-        np.testing.assert_array_equal(r[1]["s_" + k], P[k])
-        np.testing.assert_array_equal(r[0]["s_" + k], P[k])
+        for i in range(world):
+            np.testing.assert_array_equal(r[i]["s_" + k], P[k])
     # summed gradient == the oracle's full-batch gradient; both ranks hold the same bits
     ref = OG.loss_and_grads(P, opt, batch, alpha_c=W.ALPHA_C, decay_c=W.DECAY_C)
     ref0 = OG.loss_and_grads(P, opt, batch, alpha_c=W.ALPHA_C, decay_c=0.0, want=('grads',))['grads']
     for k in P:
-        np.testing.assert_array_equal(r[0]["g_" + k], r[1]["g_" + k])
+        for i in range(1, world):
+            np.testing.assert_array_equal(r[0]["g_" + k], r[i]["g_" + k])
     bad = []
     for k in P:
         g, t = np.asarray(r[0]["g_" + k], np.float64), np.asarray(ref0[k], np.float64)
@@ -83,7 +85,8 @@ def test_two_rccl_ranks_reproduce_the_single_process_step(tmp_path, mode):
             bad.append((k, float(np.abs(g - t).max()), float(np.abs(t).max())))
     assert not bad, bad
     np.testing.assert_allclose(meta[0]["loss"], ref['loss'], rtol=2e-4)
-    np.testing.assert_allclose(meta[1]["loss"], meta[0]["loss"], rtol=1e-6)
+    for i in range(1, world):
+        np.testing.assert_allclose(meta[i]["loss"], meta[0]["loss"], rtol=1e-6)
     # two steps later the replicas are still bit-identical and equal to a single process that saw the whole batch
     plain = stattn.Decoder(opt, lt_mode=1)
     plain.set_params(P)
@@ -94,7 +97,8 @@ def test_two_rccl_ranks_reproduce_the_single_process_step(tmp_path, mode):
     p_ref = plain.get_params()
     moved = 0.0
     for k in P:
-        np.testing.assert_array_equal(r[0]["p_" + k], r[1]["p_" + k])
+        for i in range(1, world):
+            np.testing.assert_array_equal(r[0]["p_" + k], r[i]["p_" + k])
         np.testing.assert_allclose(r[0]["p_" + k], p_ref[k], rtol=2e-4, atol=2e-6)
         moved = max(moved, float(np.abs(p_ref[k] - P[k]).max()))
     assert moved > 1e-4                                         # the update did something

@@ -553,7 +553,10 @@ def main():
     # (csrc/gemm.hip launch_gemm_group): a launch = a list of (name, M, N, K)
     proj1 = [("ff_local", BTK, D, F), ("ff_motion", BT, D, F), ("pctxg", BT, D, D)]
     proj2 = [("pctxl", BTK, D, D)] + ([("L.Wclt", BTK, D, D)] if dec.lt_mode == 1 else []) + [("pctxm", BT, D, D)]
-    tail = [[("readout_h", R, E, D)]] + ([[("readout_ctx", R, E, D)]] if options["ctx2out"] else []) + [[("logits", R, Vp, E)]]
+    if options["ctx2out"] and args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR"):
+        tail = [[("readout_h+ctx", R, E, 2 * D)], [("logits", R, Vp, E)]]      # one K-concatenated launch (split-K + fused epilogue)
+    else:
+        tail = [[("readout_h", R, E, D)]] + ([[("readout_ctx", R, E, D)]] if options["ctx2out"] else []) + [[("logits", R, Vp, E)]]
     if bf16:
         launches = [[x_] for x_ in proj1 + [proj2[0]] + [proj2[-1]] + proj2[1:-1]] + [[("xproj", R, 4 * D, E)]] + tail
     elif os.environ.get("STATTN_GEMM_NOGROUP"):

@@ -61,6 +61,24 @@ def test_lds_tiled_gemm_matches_float64(stattn_mod, O, M, N, K):
         np.testing.assert_allclose(dec.gemm(np.ascontiguousarray(A.T), B, transA=True), ref, atol=tol, rtol=1e-5)
 
 
+@pytest.mark.parametrize("M,N,K", [(1920, 512, 2048), (200, 64, 128), (300, 128, 1024), (64, 1024, 4096), (37, 192, 64)])
+def test_paired_gemm_with_split_k_epilogue_matches_float64(stattn_mod, O, M, N, K):
+    """C = A1.B1 + A2.B2 in one launch (K-concatenated operand pairs: the readout's a = tanh(hd.Wl1 + ctx.Wl2 + ...),
+    model_attention.py:687-699) -- split-K with the epilogue applied by the reduction of the partial tiles when the shape
+    leaves most of the chip idle (first and third case), the plain tile loop otherwise."""
+    dec = _decoder(stattn_mod, O, SMALL, 1)[3]
+    rng = np.random.RandomState(M + N + K)
+    A = rng.uniform(-1, 1, (M, K)).astype(np.float32)
+    B = rng.uniform(-1, 1, (K, N)).astype(np.float32)
+    bias = rng.uniform(-1, 1, (N,)).astype(np.float32)
+    add = rng.uniform(-1, 1, (M, N)).astype(np.float32)
+    ref = A.astype(np.float64) @ B.astype(np.float64)
+    np.testing.assert_allclose(dec.gemm(A, B, kind=5), ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
+    out = dec.gemm(A, B, bias=bias, add=add, act=1, alpha=0.05, kind=5)
+    np.testing.assert_allclose(out, np.tanh(0.05 * ref + bias + add), atol=1e-5, rtol=1e-5)
+    np.testing.assert_array_equal(out, dec.gemm(A, B, bias=bias, add=add, act=1, alpha=0.05, kind=5))     # fixed summation order
+
+
 @pytest.mark.parametrize("M,N,K", [(1, 64, 16), (5, 128, 1024), (64, 8192, 1024), (64, 12032, 512), (160, 256, 256), (17, 192, 48)])
 def test_skinny_gemm_matches_float64(stattn_mod, O, M, N, K):
     dec = _decoder(stattn_mod, O, SMALL, 1)[3]

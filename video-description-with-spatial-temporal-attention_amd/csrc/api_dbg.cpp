@@ -21,7 +21,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
     HIPCHK(h, hipMemcpyAsync(dB, B, (size_t)K * N * 4, hipMemcpyHostToDevice, s));
     if (bias) HIPCHK(h, hipMemcpyAsync(dbias, bias, (size_t)N * 4, hipMemcpyHostToDevice, s));
     if (add) HIPCHK(h, hipMemcpyAsync(dadd, add, (size_t)M * N * 4, hipMemcpyHostToDevice, s));
-    if (kind == 0 || kind == 4) {
+    if (kind == 0 || kind == 4 || kind == 5) {
         GemmArgs g;
         gemm_defaults(g); g.split = h->opt.precision != 0;
         g.split = kind == 4;
@@ -29,6 +29,17 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         g.M = M; g.N = N; g.K = K; g.alpha = alpha; g.bias = bias ? dbias : nullptr;
         if (add) { g.add = dadd; g.ldadd = N; }
         g.act = act;
+        if (kind == 5) {
+            // the same product as TWO K-concatenated operand pairs (k < K / 2 from the first, the rest from the second: the
+            // readout's joint launch) with a split-K workspace, so that the epilogue-applying reduction runs when it qualifies
+            if (transA || transB || K % 64 != 0) return fail(h, STATTN_EINVAL, "paired GEMM: NN only, K % 64 == 0");
+            float* dws;
+            const size_t WSF = (size_t)8 * M * N;
+            CHK(getbuf_t(h, "dbg_ws", WSF, &dws));
+            g.K = K / 2;
+            g.A2 = dA + K / 2; g.lda2 = K; g.B2 = dB + (size_t)(K / 2) * N; g.ldb2 = N; g.K2 = K / 2;
+            g.ws = dws; g.ws_floats = WSF;
+        }
         if (g.split && !gemm_split_supported(g, transA != 0, transB != 0))
             return fail(h, STATTN_EINVAL, "split kernel: N % 128 == 0, k-contiguous operands 16-byte aligned");
         hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);

@@ -264,13 +264,32 @@ int stattn_forward_train(stattn_handle* h) {
     } else {
         Prof pr_(h, KC_READOUT);
         GemmArgs g;
+        static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools
+        const bool pair = h->opt.ctx2out && h->opt.precision == 0 && D % 32 == 0 && !nopair;
+        if (pair) {
+            // a = tanh((h*d1).Wl1 + ctx.Wl2 + bl1 + bl2 [+ emb]) * d2 as ONE K-concatenated GEMM (K = 2 D): the two 240-tile
+            // launches it replaces each left three quarters of the chip's workgroup slots empty; split-K over the joint K
+            // fills them, and the epilogue runs in the reduction of the partial tiles
+            float* fws;
+            const size_t FWS = (size_t)8 * R * E;
+            CHK(getbuf_t(h, "f_ws", FWS, &fws));
+            gemm_defaults(g);
+            g.A = hd; g.lda = D; g.B = w.Wl1; g.ldb = E; g.K = D;
+            g.A2 = ctx; g.lda2 = D; g.B2 = w.Wl2; g.ldb2 = E; g.K2 = D;
+            g.C = a1; g.ldc = E; g.M = (int)R; g.N = E; g.bias = w.bl1; g.bias2 = w.bl2;
+            if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
+            g.act = 1; g.mul = d2; g.ldmul = E; g.Cact = tz; g.ldcact = E;
+            g.ws = fws; g.ws_floats = FWS;
+            HIPCHK(h, gemm_nn(h, g));
+        } else {
         gemm_defaults(g); g.split = h->opt.precision != 0;      // z1 = (h*d1).Wl1 + bl1 [+ emb]
         g.A = hd; g.lda = D; g.B = w.Wl1; g.ldb = E; g.C = h->opt.ctx2out ? z1 : a1; g.ldc = E;
         g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
         if (!h->opt.ctx2out) { g.act = 1; g.mul = d2; g.ldmul = E; g.Cact = tz; g.ldcact = E; }
         HIPCHK(h, gemm_nn(h, g));
-        if (h->opt.ctx2out) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
+        }
+        if (h->opt.ctx2out && !pair) {  // a = tanh(ctx.Wl2 + bl2 + z1) * d2
             gemm_defaults(g); g.split = h->opt.precision != 0;
             g.A = ctx; g.lda = D; g.B = w.Wl2; g.ldb = E; g.C = a1; g.ldc = E;
             g.M = (int)R; g.N = E; g.K = D; g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E;

@@ -129,13 +129,14 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    int kb = 0, ke = g.K;
+    const int Kt = g.K + (g.A2 ? g.K2 : 0);          // K-concatenated second operand pair (NN only)
+    int kb = 0, ke = Kt;
     float* Cout = g.C;
     int ldc = g.ldc;
     if (g.kslices > 1) {
-        const int per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
+        const int per = ((Kt + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
         kb = ky * per;
-        ke = kb + per < g.K ? kb + per : g.K;
+        ke = kb + per < Kt ? kb + per : Kt;
         Cout = g.ws + (size_t)ky * g.M * g.N;
         ldc = g.N;
     }
@@ -146,12 +147,23 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     // counted vmcnt waits); the redundant tail loads hit L2
     auto ktile = [&](int t) { return kb + (t < nk ? t : (nk > 0 ? nk - 1 : 0)) * BK; };
 
-    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(0), ke, tid);
-    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(0), ke, tid);
+    // tile t of A / B into a register set; with a second operand pair the tiles at k >= K come from it (a uniform select)
+    auto loadA = [&](float4 (&r)[TA::NF4], int t) {
+        const int k = ktile(t);
+        const bool second = g.A2 && k >= g.K;
+        TA::template gload<EDGE>(r, second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M, second ? k - g.K : k, second ? ke - g.K : ke, tid);
+    };
+    auto loadB = [&](float4 (&r)[TB::NF4], int t) {
+        const int k = ktile(t);
+        const bool second = g.A2 && k >= g.K;
+        TB::template gload<EDGE>(r, second ? g.B2 : g.B, second ? g.ldb2 : g.ldb, n0, g.N, second ? k - g.K : k, second ? ke - g.K : ke, tid);
+    };
+    loadA(ra0, 0);
+    loadB(rb0, 0);
     TA::sstore(ra0, sA, tid);
     TB::sstore(rb0, sB, tid);
-    TA::template gload<EDGE>(ra1, g.A, g.lda, m0, g.M, ktile(1), ke, tid);      // tile 1 -> set 1
-    TB::template gload<EDGE>(rb1, g.B, g.ldb, n0, g.N, ktile(1), ke, tid);
+    loadA(ra1, 1);                                                              // tile 1 -> set 1
+    loadB(rb1, 1);
     __syncthreads();
 
     float a[2][TM][4], b[2][TN][4];
@@ -193,8 +205,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
         TA::sstore(RA_NEXT, nA, tid);                                                                         \
         TB::sstore(RB_NEXT, nB, tid);                                                                         \
         /* the freed register set starts fetching tile KT+3?  no: tile KT+2 lives in the FAR set; refill NEXT */\
-        TA::template gload<EDGE>(RA_NEXT, g.A, g.lda, m0, g.M, ktile((KT) + 3), ke, tid);                     \
-        TB::template gload<EDGE>(RB_NEXT, g.B, g.ldb, n0, g.N, ktile((KT) + 3), ke, tid);                     \
+        loadA(RA_NEXT, (KT) + 3);                                                                             \
+        loadB(RB_NEXT, (KT) + 3);                                                                             \
         /* k-block 2 (its fragments for k-block 3 are fetched BEFORE the barrier) */                          \
         frags(1, cA, cB, 3);                                                                                  \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
@@ -212,8 +224,8 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     //   tile kt   (even): NEXT = set1 (tile kt+1), after its store set1 is refilled with tile kt+3
     //   tile kt+1 (odd) : NEXT = set0 (tile kt+2), ...   set0 must then hold tile kt+2: fetched during tile kt-1.
     // Prologue therefore also fetches tile 2 into set 0 after its LDS store.
-    TA::template gload<EDGE>(ra0, g.A, g.lda, m0, g.M, ktile(2), ke, tid);
-    TB::template gload<EDGE>(rb0, g.B, g.ldb, n0, g.N, ktile(2), ke, tid);
+    loadA(ra0, 2);
+    loadB(rb0, 2);
     int kt = 0;
     for (; kt + 1 < nk; kt += 2) {
         STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
@@ -267,6 +279,33 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     }
 }
 
+// the same with the fused epilogue of gemm_common.h (bias, bias2, add, rowadd, tanh, Cact, mul, accumulate)
+__global__ void splitk_reduce_epi_kernel(const GemmArgs g, int slices) {
+    const size_t n4 = (size_t)g.M * g.N / 4, MN = (size_t)g.M * g.N;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
+        float4 a = ld4(g.ws + 4 * i);
+        for (int z = 1; z < slices; ++z) {
+            const float4 b = ld4(g.ws + (size_t)z * MN + 4 * i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        const size_t e = 4 * i, row = e / g.N, col = e % g.N;
+        float v[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const size_t c = col + q;
+            float x = g.alpha * v[q] + (g.bias ? g.bias[c] : 0.f) + (g.bias2 ? g.bias2[c] : 0.f);
+            if (g.add) x += g.add[row * g.ldadd + c];
+            if (g.rowadd) x += g.rowadd[(row / g.rowgroup) * g.ldrow + c];
+            if (g.act == 1) x = fast_tanh(x);
+            if (g.Cact) g.Cact[row * g.ldcact + c] = x;
+            if (g.mul) x *= g.mul[row * g.ldmul + c];
+            float* o = g.C + row * g.ldc + c;
+            if (g.accumulate) x += *o;
+            *o = x;
+        }
+    }
+}
+
 template <int TM, int TN>
 hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
     const int BM = 64 * TM, BN = 64 * TN;
@@ -274,9 +313,10 @@ hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
     dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1), block(256);
     {
         // predicate-free loads when no tile straddles an edge that is NOT handled by clamping
-        int per = g.K;
-        if (g.kslices > 1) per = ((g.K + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
-        const bool edge = (g.K % BK != 0) || (g.kslices > 1 && (size_t)per * (g.kslices - 1) >= (size_t)g.K) ||
+        const int Kt = g.K + (g.A2 ? g.K2 : 0);
+        int per = Kt;
+        if (g.kslices > 1) per = ((Kt + g.kslices - 1) / g.kslices + BK - 1) / BK * BK;
+        const bool edge = (Kt % BK != 0) || (g.kslices > 1 && (size_t)per * (g.kslices - 1) >= (size_t)Kt) ||
                           (tA && g.M % BM != 0);
         if (edge) {
             if (!tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, true>), grid, block, 0, s, g);
@@ -328,6 +368,13 @@ void gemm_clock_dump() {
     g_clk_rec->clear();
 }
 #endif
+
+hipError_t launch_splitk_reduce_epilogue(hipStream_t s, const GemmArgs& g, int slices) {
+    const size_t n4 = (size_t)g.M * g.N / 4;
+    int nb = (int)((n4 + 255) / 256); if (nb > 2048) nb = 2048;
+    hipLaunchKernelGGL(splitk_reduce_epi_kernel, dim3(nb), dim3(256), 0, s, g, slices);
+    return hipGetLastError();
+}
 
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, float* C, int ldc, int M, int N, int slices, float alpha, int accumulate) {
     const size_t n4 = (size_t)M * N / 4;
@@ -395,7 +442,7 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, 
 }
 
 hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
-    if (gin.split && gemm_split_supported(gin, tA, tB)) return launch_gemm_split(s, gin, tA, tB);
+    if (gin.split && !gin.A2 && gemm_split_supported(gin, tA, tB)) return launch_gemm_split(s, gin, tA, tB);
     GemmArgs g = gin;
     g.kslices = 1;
 #ifdef STATTN_PROBES
@@ -419,19 +466,30 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     if (tA && (g.M % 4 != 0)) return hipErrorInvalidValue;
     auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
     const bool n128 = (g.N % 128 == 0);
-    if (g.ws && !g.bias && !g.add && !g.rowadd && !g.mul && !g.act && !g.Cact) {
-        // split-K (weight-gradient shapes): 64x64 tiles, ~4 resident blocks per CU
+    if (g.A2 && (tA || tB || g.K % BK != 0 || g.K2 % BK != 0 || g.K2 <= 0)) return hipErrorInvalidValue;
+    const int Kt = g.K + (g.A2 ? g.K2 : 0);
+    if (g.ws) {
+        // split-K (weight-gradient shapes, and small-output forward GEMMs that would leave most CUs idle): 64x64 tiles,
+        // ~4 resident blocks per CU; the partial tiles are summed in a fixed order, by the plain reduction or -- when the
+        // launch has a fused epilogue -- by the one that applies it
+        const bool epi = g.bias || g.bias2 || g.add || g.rowadd || g.mul || g.act || g.Cact;
         const int t11 = blocks(64, 64);
-        if (t11 < 768 && g.K >= 1024) {
+        if (t11 < 768 && Kt >= 1024) {
             int ks = (1024 + t11 - 1) / t11;
-            if (ks > g.K / 512) ks = g.K / 512;
+            static const char* fks = getenv("STATTN_FWD_KS");            // tools: slice count of epilogue-carrying split-K launches
+            if (epi && fks) ks = atoi(fks);
+            else if (ks > Kt / 512) ks = Kt / 512;
+            // (a launch with an epilogue pays for it once more in the reduction: slices of at least 1024 -- measured on the
+            // readout pair 1920 x 512 x 2048: 2 / 3 / 4 / 6 / 8 slices 55.5 / 55.9 / 57.4 / 58.9 / 61.9 us, unsplit 69.0)
+            if (epi && !fks && ks > Kt / 1024) ks = Kt / 1024;
             if (ks > 32) ks = 32;
             while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
-            if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
+            if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0 && g.N % 4 == 0) {
                 g.kslices = ks;
                 hipError_t e = launch_cfg<1, 1>(s, g, tA, tB);
                 if (e != hipSuccess) return e;
-                return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
+                return epi ? launch_splitk_reduce_epilogue(s, g, ks)
+                           : launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
             }
         }
     }

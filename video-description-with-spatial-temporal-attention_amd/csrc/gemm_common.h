@@ -41,7 +41,7 @@ __device__ __forceinline__ void epilogue(const GemmArgs& g, const f32x16 (&acc)[
 #pragma unroll
         for (int j = 0; j < NT; ++j) {
             const int col = n0 + wn * 32 * NT + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
+            const float bias = (g.bias ? g.bias[col] : 0.f) + (g.bias2 ? g.bias2[col] : 0.f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * MT + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;

@@ -18,6 +18,10 @@ struct GemmArgs {
     int M, N, K;
     float alpha;
     const float* bias;                 // [N] or null
+    const float* bias2;                // second [N] bias (two layers summed into one pre-activation), or null
+    // optional second operand pair, K-concatenated: C = A.B + A2.B2 (NN, fp32-MFMA kernel only; K % 32 == 0, K2 % 32 == 0).
+    // The readout's a = tanh(hd.Wl1 + ctx.Wl2 + ...) (model_attention.py:687-699) is one launch this way.
+    const float* A2; const float* B2; int lda2, ldb2, K2;
     const float* add; int ldadd;       // [M,N] or null
     const float* rowadd; int ldrow; int rowgroup;  // [M/rowgroup, N] or null
     const float* mul; int ldmul;       // [M,N] elementwise multiplier applied after act, or null
@@ -26,7 +30,7 @@ struct GemmArgs {
     float* Cact; int ldcact;           // optional second output: the activation BEFORE `mul` (tanh(z) for backward)
     // deterministic split-K (weight-gradient shapes: small MxN, huge K): when `ws` is given and the tile grid
     // would leave most CUs idle, K is cut into slices that write partial tiles to ws, and a second kernel
-    // sums them in a fixed order.  Only alpha / accumulate are honoured on that path.
+    // sums them in a fixed order (with the fused epilogue, when there is one).
     float* ws; size_t ws_floats;
     int kbeg, kend, kslices;           // internal
     int xcd_remap;                     // internal: XCD-aware tile order on/off
@@ -43,6 +47,7 @@ struct GemmGroup { GemmArgs g[GEMM_GROUP_MAX]; int tile_start[GEMM_GROUP_MAX + 1
 hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool transA = false, bool transB = false);
 void gemm_clock_dump();   // tools only (STATTN_GEMM_CLK=1)
 hipError_t launch_splitk_reduce(hipStream_t s, const float* ws, float* C, int ldc, int M, int N, int slices, float alpha, int accumulate);
+hipError_t launch_splitk_reduce_epilogue(hipStream_t s, const GemmArgs& g, int slices);     // the same with g's fused epilogue
 
 // ----------------------------------------------------------------------------
 // fp32 GEMM on the bf16 matrix cores (gemm_split.hip): same problem description and epilogue as above, every operand

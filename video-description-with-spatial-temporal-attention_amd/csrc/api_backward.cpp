@@ -133,10 +133,16 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
     const bool reg = alpha_c > 0.f;
     if (reg) {
-        HIPCHK(h, launch_alpha_reg(s, ag, rg, sqg, t, MT, alpha_c / T));
-        HIPCHK(h, launch_alpha_reg(s, am, rm, sqm, t, MT, alpha_c / T));
-        HIPCHK(h, launch_alpha_reg(s, alt, rlt, sqlt, t, MT, alpha_c / T));
-        HIPCHK(h, launch_alpha_reg(s, al, rl, sql, t, MTK, alpha_c / (T * K)));
+        AlphaRegArgs ar{};
+        const float* als[4] = {ag, am, alt, al};
+        float* rs[4] = {rg, rm, rlt, rl};
+        float* sqs[4] = {sqg, sqm, sqlt, sql};
+        for (int i = 0; i < 4; ++i) {
+            ar.alpha[i] = als[i]; ar.r[i] = rs[i]; ar.sq[i] = sqs[i]; ar.n[i] = i < 3 ? MT : MTK;
+            ar.coef[i] = i < 3 ? alpha_c / T : alpha_c / (T * K);
+        }
+        ar.count = 4;
+        HIPCHK(h, launch_alpha_reg(s, ar, t));
         MultiSumArgs ms{};
         const float* srcs[4] = {sqg, sqm, sqlt, sql};
         for (int i = 0; i < 4; ++i) {

@@ -76,15 +76,18 @@ __global__ __launch_bounds__(256) void dlogit_kernel(const float* __restrict__ p
     }
 }
 
-// r tensors of the doubly-stochastic regulariser (:1140-1147): d/d alpha[s,...] = -2 alpha_c / n * (1 - sum_s alpha)
-__global__ void alpha_reg_kernel(const float* __restrict__ alpha, float* __restrict__ r, float* __restrict__ sq,
-                                 int steps, size_t n, float coef) {
-    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// r tensors of the doubly-stochastic regulariser (:1140-1147): d/d alpha[s,...] = -2 alpha_c / n * (1 - sum_s alpha).
+// All four attentions in one launch (blockIdx.y = which): they were four 13 us latency-bound launches of a 30-step loop.
+__global__ void alpha_reg_kernel(const AlphaRegArgs a, int steps) {
+    const int w = blockIdx.y;
+    const size_t n = a.n[w], i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
+    const float* __restrict__ alpha = a.alpha[w];
     float s = 0.f;
+#pragma unroll 6
     for (int t = 0; t < steps; ++t) s += alpha[(size_t)t * n + i];
-    r[i] = -2.f * coef * (1.f - s);
-    if (sq) sq[i] = (1.f - s) * (1.f - s);
+    a.r[w][i] = -2.f * a.coef[w] * (1.f - s);
+    if (a.sq[w]) a.sq[w][i] = (1.f - s) * (1.f - s);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -711,9 +714,11 @@ hipError_t launch_dlogit(hipStream_t s, const float* probs, int ldp, const int64
     hipLaunchKernelGGL(dlogit_kernel, dim3(rows), dim3(256), 0, s, probs, ldp, x, mask, nll_scale, dl, ldd, V, Vp);
     return hipGetLastError();
 }
-hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* sq, int steps, size_t n, float coef) {
-    if (!n) return hipSuccess;
-    hipLaunchKernelGGL(alpha_reg_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, alpha, r, sq, steps, n, coef);
+hipError_t launch_alpha_reg(hipStream_t s, const AlphaRegArgs& a, int steps) {
+    size_t nmax = 0;
+    for (int w = 0; w < a.count; ++w) nmax = a.n[w] > nmax ? a.n[w] : nmax;
+    if (!nmax) return hipSuccess;
+    hipLaunchKernelGGL(alpha_reg_kernel, dim3((unsigned)((nmax + 255) / 256), a.count), dim3(256), 0, s, a, steps);
     return hipGetLastError();
 }
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a) {

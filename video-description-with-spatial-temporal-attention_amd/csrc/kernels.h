@@ -284,6 +284,7 @@ hipError_t launch_softmax_nll(hipStream_t s, const float* logits, int ldl, float
 hipError_t launch_cost(hipStream_t s, const float* nll, const float* mask, float* cost, int t, int m);
 // Bernoulli(0.5) in {0,1} from a counter-based hash
 hipError_t launch_bernoulli(hipStream_t s, float* p, size_t n, uint64_t seed, uint64_t stream_id);
+hipError_t launch_bernoulli3(hipStream_t s, float* p0, size_t n0, float* p1, size_t n1, float* p2, size_t n2, uint64_t seed, uint64_t stream0);   // streams stream0, +1, +2 in one launch
 // uniform in [-1, 1)
 hipError_t launch_uniform(hipStream_t s, float* p, size_t n, uint64_t seed, uint64_t stream_id);
 
@@ -350,7 +351,8 @@ struct CtxGradArgs {
 
 hipError_t launch_dlogit(hipStream_t s, const float* probs, int ldp, const int64_t* x, const float* mask, float nll_scale,
                          float* dl, int ldd, int rows, int V, int Vp);
-hipError_t launch_alpha_reg(hipStream_t s, const float* alpha, float* r, float* sq, int steps, size_t n, float coef);
+struct AlphaRegArgs { const float* alpha[4]; float* r[4]; float* sq[4]; size_t n[4]; float coef[4]; int count; };
+hipError_t launch_alpha_reg(hipStream_t s, const AlphaRegArgs& a, int steps);    // up to four [steps, n] tensors in one launch
 hipError_t launch_lstm_bwd(hipStream_t s, const LstmBwdArgs& a);
 hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a);
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,

@@ -165,6 +165,20 @@ __global__ void bernoulli_kernel(float* __restrict__ p, size_t n, uint64_t seed,
     }
 }
 
+// the three dropout masks of a pass (LSTM gates, h, readout) in one launch: segment y draws stream stream0 + y, element
+// for element what three bernoulli_kernel launches draw
+struct Bern3 { float* p[3]; size_t n[3]; };
+__global__ void bernoulli3_kernel(const Bern3 b, uint64_t seed, uint64_t stream0) {
+    const int y = blockIdx.y;
+    float* __restrict__ p = b.p[y];
+    const size_t n = b.n[y];
+    const uint64_t key = mix64(seed ^ ((stream0 + y) * 0x9E3779B97F4A7C15ull));
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+        const uint64_t h = mix64(key + (i >> 6));
+        p[i] = (float)((h >> (i & 63)) & 1ull);
+    }
+}
+
 // uniform in [-1, 1) from the same hash (bench / timing data: full-range signs, never zeros)
 __global__ void uniform_kernel(float* __restrict__ p, size_t n, uint64_t seed, uint64_t stream_id) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
@@ -219,6 +233,14 @@ hipError_t launch_cost(hipStream_t s, const float* nll, const float* mask, float
 hipError_t launch_bernoulli(hipStream_t s, float* p, size_t n, uint64_t seed, uint64_t stream_id) {
     if (!n) return hipSuccess;
     hipLaunchKernelGGL(bernoulli_kernel, dim3(grid_for(n, 256)), dim3(256), 0, s, p, n, seed, stream_id);
+    return hipGetLastError();
+}
+
+hipError_t launch_bernoulli3(hipStream_t s, float* p0, size_t n0, float* p1, size_t n1, float* p2, size_t n2, uint64_t seed, uint64_t stream0) {
+    Bern3 b{{p0, p1, p2}, {n0, n1, n2}};
+    size_t nmax = n0 > n1 ? n0 : n1; nmax = nmax > n2 ? nmax : n2;
+    if (!nmax) return hipSuccess;
+    hipLaunchKernelGGL(bernoulli3_kernel, dim3(grid_for(nmax, 256), 3), dim3(256), 0, s, b, seed, stream0);
     return hipGetLastError();
 }
 

@@ -384,9 +384,7 @@ int prepare_masks(stattn_handle* h, int t, int m, float** dp, float** d1, float*
         return STATTN_OK;
     }
     if (h->use_noise != 0.f) {   // trng.binomial(p=0.5) (:474-477, common.py:94-99); own counter-based generator
-        HIPCHK(h, launch_bernoulli(h->stream, *dp, n_dp, h->seed, 3 * h->draw + 0));
-        HIPCHK(h, launch_bernoulli(h->stream, *d1, n_d1, h->seed, 3 * h->draw + 1));
-        HIPCHK(h, launch_bernoulli(h->stream, *d2, n_d2, h->seed, 3 * h->draw + 2));
+        HIPCHK(h, launch_bernoulli3(h->stream, *dp, n_dp, *d1, n_d1, *d2, n_d2, h->seed, 3 * h->draw));
         h->draw++;
         h->masks_state = 2; h->masks_t = t; h->masks_m = m;
     } else if (!(h->masks_state == 1 && h->masks_t >= t && h->masks_m >= m && h->masks_t * h->masks_m >= t * m)) {

@@ -474,6 +474,25 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
         // launch has a fused epilogue -- by the one that applies it
         const bool epi = g.bias || g.bias2 || g.add || g.rowadd || g.mul || g.act || g.Cact;
         const int t11 = blocks(64, 64);
+        // Long-K weight gradients with many output tiles (dff_local_W = ctxl^T.dL: 4096 x 1024 x 13312): 128 x 128 tiles,
+        // K cut so that two workgroups per CU are resident -- half the L2 -> LDS traffic per flop of the 64 x 64 tile at the
+        // same fill (982 -> 909 us).  Shorter K or fewer tiles lose (dU 1024 x 4096 x 1920: 154 -> 163 us; da NT 221 -> 275).
+        static const char* nobig = getenv("STATTN_SPLITK_NOBIG");       // A/B switch for tools
+        if (!nobig && !epi && tA && n128 && g.M % 128 == 0 && Kt >= 2048 && blocks(128, 128) >= 128) {
+            const int t22 = blocks(128, 128);
+            int ks = (512 + t22 - 1) / t22;
+            if (ks > Kt / 512) ks = Kt / 512;
+            while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
+            if (t22 * ks >= 384 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0) {
+                if (ks > 1) {
+                    g.kslices = ks;
+                    hipError_t e = launch_cfg<2, 2>(s, g, tA, tB);
+                    if (e != hipSuccess) return e;
+                    return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
+                }
+                return launch_cfg<2, 2>(s, g, tA, tB);
+            }
+        }
         if (t11 < 768 && Kt >= 1024) {
             int ks = (1024 + t11 - 1) / t11;
             static const char* fks = getenv("STATTN_FWD_KS");            // tools: slice count of epilogue-carrying split-K launches

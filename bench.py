@@ -634,7 +634,8 @@ def main():
         else:
             bl += [("dWcg+dWcm+4xdWd", "TN", [(D, D, MT)] * 2 + [(D, D, R)] * 4)]
         bl += [("dW=emb^T.dpre", "TN", [(E, 4 * D, R)]), ("dff_state_W", "TN", [(D, D, B)]), ("dff_memory_W", "TN", [(D, D, B)]),
-               ("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
+               ] + ([("dL+=dPL.Wcl^T+dLW.Wclt^T", "NT", [(MTK, D, 2 * D)])] if args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR")
+                    else [("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)])]) + [("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
                ("dMo+=dPM.Wcm^T", "NT", [(MT, D, D)]), ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)]), ("demb=dpre.W^T", "NT", [(R, E, 4 * D)])]
         for (nm, kind, shapes), ms in zip(bl, bgms):
             kernels["bwd_gemm_" + nm] = mfma("%s %s %s" % (gname.replace("false,false", kind) if len(shapes) == 1 else ggroup + " " + kind,

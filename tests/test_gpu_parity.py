@@ -77,6 +77,8 @@ def test_paired_gemm_with_split_k_epilogue_matches_float64(stattn_mod, O, M, N, 
     out = dec.gemm(A, B, bias=bias, add=add, act=1, alpha=0.05, kind=5)
     np.testing.assert_allclose(out, np.tanh(0.05 * ref + bias + add), atol=1e-5, rtol=1e-5)
     np.testing.assert_array_equal(out, dec.gemm(A, B, bias=bias, add=add, act=1, alpha=0.05, kind=5))     # fixed summation order
+    # NT form (B given as [N, K]): the backward pass's dL += dPL.Wcl^T + dLW.Wclt^T
+    np.testing.assert_allclose(dec.gemm(A, np.ascontiguousarray(B.T), transB=True, kind=5), ref, atol=2e-5 * np.sqrt(K), rtol=1e-5)
 
 
 @pytest.mark.parametrize("M,N,K", [(1, 64, 16), (5, 128, 1024), (64, 8192, 1024), (64, 12032, 512), (160, 256, 256), (17, 192, 48)])

@@ -371,8 +371,21 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
     HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
     CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
-    HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
-    HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+    static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools (also the forward readout pair)
+    if (h->opt.precision == 0 && D % 32 == 0 && !nopair) {
+        // dL += dPL.Wcl^T + dLW.Wclt^T as ONE K-concatenated NT GEMM: dL is read and written once instead of twice
+        GemmArgs g;
+        gemm_defaults(g);
+        g.A = dPL; g.lda = D; g.B = w.Wcl; g.ldb = D; g.K = D;
+        g.A2 = dLW; g.lda2 = D; g.B2 = w.Wclt; g.ldb2 = D; g.K2 = D;
+        g.C = dL; g.ldc = D; g.M = (int)MTK; g.N = D; g.accumulate = 1;
+        const int seq = h->bwd_seq++;
+        Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
+        HIPCHK(h, launch_gemm(s, g, false, true));
+    } else {
+        HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
+        HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+    }
     HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
     CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);

@@ -32,12 +32,13 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         if (kind == 5) {
             // the same product as TWO K-concatenated operand pairs (k < K / 2 from the first, the rest from the second: the
             // readout's joint launch) with a split-K workspace, so that the epilogue-applying reduction runs when it qualifies
-            if (transA || transB || K % 64 != 0) return fail(h, STATTN_EINVAL, "paired GEMM: NN only, K % 64 == 0");
+            if (transA || K % 64 != 0) return fail(h, STATTN_EINVAL, "paired GEMM: NN or NT, K % 64 == 0");
             float* dws;
             const size_t WSF = (size_t)8 * M * N;
             CHK(getbuf_t(h, "dbg_ws", WSF, &dws));
             g.K = K / 2;
-            g.A2 = dA + K / 2; g.lda2 = K; g.B2 = dB + (size_t)(K / 2) * N; g.ldb2 = N; g.K2 = K / 2;
+            g.A2 = dA + K / 2; g.lda2 = K; g.K2 = K / 2;
+            if (transB) { g.B2 = dB + K / 2; g.ldb2 = K; } else { g.B2 = dB + (size_t)(K / 2) * N; g.ldb2 = N; }
             g.ws = dws; g.ws_floats = WSF;
         }
         if (g.split && !gemm_split_supported(g, transA != 0, transB != 0))

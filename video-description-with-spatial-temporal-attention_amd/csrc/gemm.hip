@@ -466,7 +466,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     if (tA && (g.M % 4 != 0)) return hipErrorInvalidValue;
     auto blocks = [&](int bm, int bn) { return ((g.M + bm - 1) / bm) * (g.N / bn); };
     const bool n128 = (g.N % 128 == 0);
-    if (g.A2 && (tA || tB || g.K % BK != 0 || g.K2 % BK != 0 || g.K2 <= 0)) return hipErrorInvalidValue;
+    if (g.A2 && (tA || g.K % BK != 0 || g.K2 % BK != 0 || g.K2 <= 0)) return hipErrorInvalidValue;   // NN or NT
     const int Kt = g.K + (g.A2 ? g.K2 : 0);
     if (g.ws) {
         // split-K (weight-gradient shapes, and small-output forward GEMMs that would leave most CUs idle): 64x64 tiles,

@@ -19,7 +19,7 @@ struct GemmArgs {
     float alpha;
     const float* bias;                 // [N] or null
     const float* bias2;                // second [N] bias (two layers summed into one pre-activation), or null
-    // optional second operand pair, K-concatenated: C = A.B + A2.B2 (NN, fp32-MFMA kernel only; K % 32 == 0, K2 % 32 == 0).
+    // optional second operand pair, K-concatenated: C = A.B + A2.B2 (NN or NT, fp32-MFMA kernel only; K % 32 == 0, K2 % 32 == 0).
     // The readout's a = tanh(hd.Wl1 + ctx.Wl2 + ...) (model_attention.py:687-699) is one launch this way.
     const float* A2; const float* B2; int lda2, ldb2, K2;
     const float* add; int ldadd;       // [M,N] or null

@@ -633,10 +633,14 @@ def main():
             bl += [("dWcg", "TN", [(D, D, MT)]), ("dWcm", "TN", [(D, D, MT)])] + [("dWd%d" % i, "TN", [(D, D, R)]) for i in range(4)]
         else:
             bl += [("dWcg+dWcm+4xdWd", "TN", [(D, D, MT)] * 2 + [(D, D, R)] * 4)]
-        bl += [("dW=emb^T.dpre", "TN", [(E, 4 * D, R)]), ("dff_state_W", "TN", [(D, D, B)]), ("dff_memory_W", "TN", [(D, D, B)]),
-               ] + ([("dL+=dPL.Wcl^T+dLW.Wclt^T", "NT", [(MTK, D, 2 * D)])] if args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR")
-                    else [("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)])]) + [("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
-               ("dMo+=dPM.Wcm^T", "NT", [(MT, D, D)]), ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)]), ("demb=dpre.W^T", "NT", [(R, E, 4 * D)])]
+        bl += [("dW=emb^T.dpre", "TN", [(E, 4 * D, R)]), ("dff_state_W", "TN", [(D, D, B)]), ("dff_memory_W", "TN", [(D, D, B)])]
+        if args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR") and not os.environ.get("STATTN_GEMM_NOGROUP"):
+            # one grouped NT launch: demb, the K-concatenated dL pair, dMo
+            bl += [("demb+dL(pair)+dMo", "NT", [(R, E, 4 * D), (MTK, D, 2 * D), (MT, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
+                   ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)])]
+        else:
+            bl += [("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
+                   ("dMo+=dPM.Wcm^T", "NT", [(MT, D, D)]), ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)]), ("demb=dpre.W^T", "NT", [(R, E, 4 * D)])]
         for (nm, kind, shapes), ms in zip(bl, bgms):
             kernels["bwd_gemm_" + nm] = mfma("%s %s %s" % (gname.replace("false,false", kind) if len(shapes) == 1 else ggroup + " " + kind,
                                                            kind, " + ".join("%dx%dx%d" % x_ for x_ in shapes)),

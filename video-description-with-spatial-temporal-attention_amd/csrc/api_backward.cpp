@@ -372,16 +372,26 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
     CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
     static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools (also the forward readout pair)
-    if (h->opt.precision == 0 && D % 32 == 0 && !nopair) {
-        // dL += dPL.Wcl^T + dLW.Wclt^T as ONE K-concatenated NT GEMM: dL is read and written once instead of twice
-        GemmArgs g;
-        gemm_defaults(g);
-        g.A = dPL; g.lda = D; g.B = w.Wcl; g.ldb = D; g.K = D;
-        g.A2 = dLW; g.lda2 = D; g.B2 = w.Wclt; g.ldb2 = D; g.K2 = D;
-        g.C = dL; g.ldc = D; g.M = (int)MTK; g.N = D; g.accumulate = 1;
-        const int seq = h->bwd_seq++;
-        Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
-        HIPCHK(h, launch_gemm(s, g, false, true));
+    const bool ntgroup = h->opt.precision == 0 && D % 32 == 0 && !nopair && !getenv("STATTN_GEMM_NOGROUP");
+    // demb = dpre.W^T (+ dz through prev2out: dz is copied in first and the product accumulated onto it), scattered to the
+    // rows of Wemb further down (:613-617)
+    if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
+    if (ntgroup) {
+        // The three input-gradient GEMMs that are left, in ONE grouped NT launch (longest K first): demb (240 tiles,
+        // K = 4 D), dL += dPL.Wcl^T + dLW.Wclt^T as one K-concatenated problem (dL read and written once instead of twice),
+        // dMo += dPM.Wcm^T (416 tiles).  On their own the two small ones left most of the chip idle or paid a split-K pass.
+        GemmArgs g3[3];
+        gemm_defaults(g3[0]);
+        g3[0].A = dpre; g3[0].lda = 4 * D; g3[0].B = w.W; g3[0].ldb = 4 * D; g3[0].C = demb; g3[0].ldc = E;
+        g3[0].M = (int)R; g3[0].N = E; g3[0].K = 4 * D; g3[0].accumulate = h->opt.prev2out ? 1 : 0;
+        gemm_defaults(g3[1]);
+        g3[1].A = dPL; g3[1].lda = D; g3[1].B = w.Wcl; g3[1].ldb = D; g3[1].K = D;
+        g3[1].A2 = dLW; g3[1].lda2 = D; g3[1].B2 = w.Wclt; g3[1].ldb2 = D; g3[1].K2 = D;
+        g3[1].C = dL; g3[1].ldc = D; g3[1].M = (int)MTK; g3[1].N = D; g3[1].accumulate = 1;
+        gemm_defaults(g3[2]);
+        g3[2].A = dPM; g3[2].lda = D; g3[2].B = w.Wcm; g3[2].ldb = D; g3[2].C = dMo; g3[2].ldc = D;
+        g3[2].M = (int)MT; g3[2].N = D; g3[2].K = D; g3[2].accumulate = 1;
+        HIPCHK(h, gemm_grp(g3, 3, false, true));
     } else {
         HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
         HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
@@ -389,16 +399,14 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
     CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);
-    HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
+    if (!ntgroup) HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
     HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
     HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
     CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
     CHK(region_done("ff_state_W", "decoder_W"));
-    // -- region Wemb: demb = dpre.W^T (+ dz through prev2out), scattered to the rows of Wemb (:613-617)
-    // (dz is copied in first and the product accumulated onto it: without an `add` operand the 1920 x 512 x 4096 problem
-    // -- 240 tiles of 64 x 64 -- may be cut along K, which fills the chip)
-    if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, h->opt.prev2out ? 1 : 0));
+    // -- region Wemb
+    // (without an `add` operand the 1920 x 512 x 4096 problem -- 240 tiles of 64 x 64 -- may be cut along K, which fills the chip)
+    if (!ntgroup) HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, h->opt.prev2out ? 1 : 0));
     {
         const EmbedPlan pl = device_embed_plan(h, h->cur_set);
         float* epart;

@@ -627,17 +627,19 @@ def main():
         else:
             bl += [("dWo+dWl1+dWl2", "TN", [(E, Vp, R), (D, E, R)] + ([(D, E, R)] if options["ctx2out"] else [])),
                    ("dhd+dctx_r", "NT", [(R, D, E)] + ([(R, D, E)] if options["ctx2out"] else []))]
-        bl += [("dWcl=L^T.dPL", "TN", [(D, D, MTK)]), ("dWclt=L^T.dLW", "TN", [(D, D, MTK)]),
-               ("dU=H^T.dpre", "TN", [(D, 4 * D, R)]), ("dWc=ctx^T.dpre", "TN", [(D, 4 * D, R)])]
-        if os.environ.get("STATTN_GEMM_NOGROUP"):
-            bl += [("dWcg", "TN", [(D, D, MT)]), ("dWcm", "TN", [(D, D, MT)])] + [("dWd%d" % i, "TN", [(D, D, R)]) for i in range(4)]
+        bl += [("dWcl=L^T.dPL", "TN", [(D, D, MTK)]), ("dWclt=L^T.dLW", "TN", [(D, D, MTK)])]
+        nogroup = bool(os.environ.get("STATTN_GEMM_NOGROUP"))
+        ntgroup = args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR") and not nogroup
+        if ntgroup:       # one grouped NT launch: demb, the K-concatenated dL pair, dMo
+            bl += [("demb+dL(pair)+dMo", "NT", [(R, E, 4 * D), (MTK, D, 2 * D), (MT, D, D)])]
+        ga = [("dU", D, 4 * D, R), ("dWc", D, 4 * D, R), ("dW", E, 4 * D, R)] + ([("dff_motion_W", Fm, D, MT)] if ntgroup else [])
+        gq = [("dWcg", D, D, MT), ("dWcm", D, D, MT)] + [("dWd%d" % i, D, D, R) for i in range(4)] + [("dff_state_W", D, D, B), ("dff_memory_W", D, D, B)]
+        if nogroup:
+            bl += [(n_, "TN", [(a_, b_, c_)]) for n_, a_, b_, c_ in ga + gq]
         else:
-            bl += [("dWcg+dWcm+4xdWd", "TN", [(D, D, MT)] * 2 + [(D, D, R)] * 4)]
-        bl += [("dW=emb^T.dpre", "TN", [(E, 4 * D, R)]), ("dff_state_W", "TN", [(D, D, B)]), ("dff_memory_W", "TN", [(D, D, B)])]
-        if args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR") and not os.environ.get("STATTN_GEMM_NOGROUP"):
-            # one grouped NT launch: demb, the K-concatenated dL pair, dMo
-            bl += [("demb+dL(pair)+dMo", "NT", [(R, E, 4 * D), (MTK, D, 2 * D), (MT, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
-                   ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)])]
+            bl += [("+".join(x_[0] for x_ in ga), "TN", [x_[1:] for x_ in ga]), ("dWcg+dWcm+4xdWd+dff_state_W+dff_memory_W", "TN", [x_[1:] for x_ in gq])]
+        if ntgroup:
+            bl += [("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)])]
         else:
             bl += [("dL+=dPL.Wcl^T", "NT", [(MTK, D, D)]), ("dL+=dLW.Wclt^T", "NT", [(MTK, D, D)]), ("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)]),
                    ("dMo+=dPM.Wcm^T", "NT", [(MT, D, D)]), ("dff_motion_W=ctxm^T.dMo", "TN", [(Fm, D, MT)]), ("demb=dpre.W^T", "NT", [(R, E, 4 * D)])]

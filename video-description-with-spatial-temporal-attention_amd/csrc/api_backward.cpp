@@ -345,34 +345,9 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, gemm(true, false, L, D, dLW, D, G_("decoder_Wclt_att"), D, D, D, (int)MTK, 0));
     CSADD(dPG, D, (int)MT, D, G_("decoder_bg_att"), 0, nullptr);
     CSADD(dPM, D, (int)MT, D, G_("decoder_bm_att"), 0, nullptr);
-    // recurrent weights: one batched TN GEMM over all (t*m) rows each
-    HIPCHK(h, gemm(true, false, hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R, 0));
-    HIPCHK(h, gemm(true, false, ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R, 0));
-    {   // the six D x D weight gradients with a short K (frames or steps x rows): 256 tiles each -- alone they needed a
-        // split-K pass each; as ONE grouped launch of 1536 tiles they fill the chip directly
-        GemmArgs gq[6];
-        auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int Kd) {
-            gemm_defaults(q); q.split = h->opt.precision != 0;
-            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = D; q.M = D; q.N = D; q.K = Kd;
-        };
-        tn(gq[0], Gc, D, dPG, D, G_("decoder_Wcg_att"), (int)MT);
-        tn(gq[1], Mo, D, dPM, D, G_("decoder_Wcm_att"), (int)MT);
-        const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
-        for (int i = 0; i < 4; ++i) tn(gq[2 + i], hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), (int)R);
-        static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
-        if (nogroup) { for (const GemmArgs& q : gq) HIPCHK(h, gemm(true, false, q.A, q.lda, q.B, q.ldb, q.C, q.ldc, q.M, q.N, q.K, 0)); }
-        else HIPCHK(h, gemm_grp(gq, 6, true, false));
-    }
-    HIPCHK(h, gemm(true, false, emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R, 0));
-    CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
-    CHK(region_done("decoder_W", "ff_logit_lstm_W"));
-    // -- region ff_*: initial state (:657-660), then back through tanh(ff_local), tanh(ff_motion) (:664-667)
-    HIPCHK(h, gemm(true, false, mean, D, dph0, D, G_("ff_state_W"), D, D, D, m, 0));
-    CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
-    HIPCHK(h, gemm(true, false, mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m, 0));
-    CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
     static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools (also the forward readout pair)
-    const bool ntgroup = h->opt.precision == 0 && D % 32 == 0 && !nopair && !getenv("STATTN_GEMM_NOGROUP");
+    static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");
+    const bool ntgroup = h->opt.precision == 0 && D % 32 == 0 && !nopair && !nogroup;
     // demb = dpre.W^T (+ dz through prev2out: dz is copied in first and the product accumulated onto it), scattered to the
     // rows of Wemb further down (:613-617)
     if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
@@ -392,16 +367,53 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         g3[2].A = dPM; g3[2].lda = D; g3[2].B = w.Wcm; g3[2].ldb = D; g3[2].C = dMo; g3[2].ldc = D;
         g3[2].M = (int)MT; g3[2].N = D; g3[2].K = D; g3[2].accumulate = 1;
         HIPCHK(h, gemm_grp(g3, 3, false, true));
-    } else {
+        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
+        HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
+    }
+    {   // Weight gradients over all (t*m) rows / all frames, K = 1664..1920 (and the two initial-state ones, K = m), as
+        // TWO grouped TN launches: [dU, dWc, dW, dff_motion_W] (3584 tiles) and the six D x D ones with ff_state / ff_memory
+        // (2048 tiles: alone the 256-tile problems needed a split-K pass each).  Each launch used to ramp up and drain on its own.
+        GemmArgs ga[4], gq[8];
+        auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int Kd) {
+            gemm_defaults(q); q.split = h->opt.precision != 0;
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = Kd;
+        };
+        int na = 0, nq = 0;
+        tn(ga[na++], hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R);
+        tn(ga[na++], ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R);
+        tn(ga[na++], emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R);
+        if (ntgroup) tn(ga[na++], rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT);
+        tn(gq[nq++], Gc, D, dPG, D, G_("decoder_Wcg_att"), D, D, D, (int)MT);
+        tn(gq[nq++], Mo, D, dPM, D, G_("decoder_Wcm_att"), D, D, D, (int)MT);
+        const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
+        for (int i = 0; i < 4; ++i) tn(gq[nq++], hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), D, D, D, (int)R);
+        tn(gq[nq++], mean, D, dph0, D, G_("ff_state_W"), D, D, D, m);
+        tn(gq[nq++], mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m);
+        if (nogroup) {
+            for (int i = 0; i < na; ++i) HIPCHK(h, gemm(true, false, ga[i].A, ga[i].lda, ga[i].B, ga[i].ldb, ga[i].C, ga[i].ldc, ga[i].M, ga[i].N, ga[i].K, 0));
+            for (int i = 0; i < nq; ++i) HIPCHK(h, gemm(true, false, gq[i].A, gq[i].lda, gq[i].B, gq[i].ldb, gq[i].C, gq[i].ldc, gq[i].M, gq[i].N, gq[i].K, 0));
+        } else {
+            HIPCHK(h, gemm_grp(ga, na, true, false));
+            HIPCHK(h, gemm_grp(gq, nq, true, false));
+        }
+    }
+    CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
+    CHK(region_done("decoder_W", "ff_logit_lstm_W"));
+    // -- region ff_*: initial state (:657-660), then back through tanh(ff_local), tanh(ff_motion) (:664-667)
+    CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
+    CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
+    if (!ntgroup) {
         HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
         HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
     }
-    HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
     CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);
-    if (!ntgroup) HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
-    HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
-    HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
+    if (!ntgroup) {
+        HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
+        HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
+        HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
+    }
     CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
     CHK(region_done("ff_state_W", "decoder_W"));
     // -- region Wemb

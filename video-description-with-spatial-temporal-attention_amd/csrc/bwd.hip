@@ -344,136 +344,140 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 //   dMo      = sum_s am_s dcsum_s
 // and the per-(b,t) partials of dUl, dUlt, dUg, dUm (summed over rows by colsum afterwards).
 
-// Work split: NG = ceil(K / 4) workgroups per (b,t) item, each owning four regions over ALL steps; the last group also
-// does the frame-level tensors, group 0 the dUlt partial.  The groups of an item read the same per-step operands
+// Work split: NG + 1 workgroups per (b,t) item, NG = ceil(K / 4): region group g < NG owns four regions over ALL steps,
+// workgroup NG the frame-level tensors and the dUlt partial.  The workgroups of an item read the same per-step operands
 // (sproj, dcsum, dplt rows: 120 KB per item over the 30 steps).  When one workgroup walked the region groups one after
 // the other, the second walk came 30 steps after the first and found nothing of it in the 4 MB L2 of its XCD (measured:
-// 1.39 GB through the fabric for 0.6 GB of distinct bytes).  Now the groups of an item are separate workgroups placed
-// on the SAME XCD and dispatched together (block n: XCD n % 8 by the round-robin dispatch; item = (n / (8 NG)) * 8 +
-// n % 8, group = (n / 8) % NG), so they run side by side and the second reader hits L2.
+// 1.39 GB through the fabric for 0.6 GB of distinct bytes).  Now they are separate workgroups placed on the SAME XCD and
+// dispatched together (block n: XCD n % 8 by the round-robin dispatch), so they run side by side and the later readers hit L2.
+//
+// The step loop is a chain of (load the step's rows -> a few hundred VALU cycles); at three waves per SIMD nothing
+// covered the load latency (313 us for a kernel whose VALU and HBM floors are 110 / 150 us).  Every workgroup kind therefore
+// requests step s + 1 before it computes step s, and the kinds are split so that each fits 168 VGPRs with the second
+// operand set (the dUlt partial needs the frame's whole LW slab in registers: it moved to the frame workgroup).
 __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, const int NG) {
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
+    const int NW = NG + 1;
     const int n = blockIdx.x;
     int bt, grp;
-    if (M & 7) { bt = (n / (8 * NG)) * 8 + (n & 7); grp = (n >> 3) % NG; }
+    if (M & 7) { bt = (n / (8 * NW)) * 8 + (n & 7); grp = (n >> 3) % NW; }
     else {      // whole batch rows per XCD as well: the 30 steps' sproj / dcsum rows of a row are shared by its T frames
-        const int x = n & 7, i = n >> 3, it = i / NG;
-        grp = i - it * NG;
+        const int x = n & 7, i = n >> 3, it = i / NW;
+        grp = i - it * NW;
         bt = (x + 8 * (it / T)) * T + it % T;
     }
     if (bt >= M * T) return;                       // (grid rounded up to whole groups of 8 items)
     const int b = bt / T, tid = threadIdx.x;
     const int nd4 = D >> 2;
     const size_t slab = (size_t)bt * K * D, MT = (size_t)M * T;
-    for (int d4 = tid; d4 < nd4; d4 += 256) {
-        const float4 ul = ld4(a.Ul + 4 * d4), blt = ld4(a.blt + 4 * d4);
-        // frame-level tensors
-        if (grp == NG - 1) {
+    if (grp == NG) {
+        // ---- frame-level tensors and the dUlt partial
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
             const size_t fo = (size_t)bt * D + 4 * d4;
+            const float4 blt = ld4(a.blt + 4 * d4);
             // e^{2 PG}, e^{2 PM} once: tanh(P + s_step) = 1 - 2 r with r = 1 / (1 + e^{2P} e^{2s}) (devmath.h exp2x4); the sums
             // below carry r and r - r^2 and are turned into tanh / 1 - tanh^2 after the loop
             const float4 pg = exp2x4(ld4(a.PG + fo)), pm = exp2x4(ld4(a.PM + fo));
-            float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg;
+            float4 lw[8];                          // the frame's LW slab (K <= 8): plt = blt + sum_k alpha_k LW_k is recomputed per step
+#pragma unroll
+            for (int k = 0; k < 8; ++k) lw[k] = K <= 8 ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg, pult = dpg;
             float sdeg = 0.f, sdem = 0.f;
-            struct FrameIn { float4 sg, sm, dcs; float deg, dem, am; };
+            struct FrameIn { float4 sg, sm, slt, dcs; float deg, dem, am, delt; float al[8]; };
             auto fetch_f = [&](int s_) {
                 FrameIn r;
                 const float* sp = a.sproj + ((size_t)s_ * M + b) * 4 * D;
-                r.sg = ld4(sp + D + 4 * d4); r.sm = ld4(sp + 2 * D + 4 * d4);
+                r.sg = ld4(sp + D + 4 * d4); r.sm = ld4(sp + 2 * D + 4 * d4); r.slt = ld4(sp + 3 * D + 4 * d4);
                 r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
-                r.deg = a.deg[s_ * MT + bt]; r.dem = a.dem[s_ * MT + bt]; r.am = a.am[s_ * MT + bt];
+                r.deg = a.deg[s_ * MT + bt]; r.dem = a.dem[s_ * MT + bt]; r.am = a.am[s_ * MT + bt]; r.delt = a.delt[s_ * MT + bt];
+                const float* als = a.alphal + (s_ * MT + bt) * K;
+#pragma unroll
+                for (int k = 0; k < 8; ++k) r.al[k] = als[min(k, K - 1)];
                 return r;
             };
+            FrameIn nx = fetch_f(0);
             for (int s = 0; s < S; ++s) {
-                const FrameIn cf = fetch_f(s);
+                const FrameIn cf = nx;
+                nx = fetch_f(min(s + 1, S - 1));   // (unconditional: a branch around the loads would drain the queue)
                 const float4 rg = rcp1p4(pg, exp2x4(cf.sg)), rm = rcp1p4(pm, exp2x4(cf.sm));
                 fma4(dpg, cf.deg, r_minus_sq(rg)); fma4(ug, cf.deg, rg); sdeg += cf.deg;
                 fma4(dpm, cf.dem, r_minus_sq(rm)); fma4(um, cf.dem, rm); sdem += cf.dem;
                 fma4(dmo, cf.am, cf.dcs);
+                // dUlt partial: delt * tanh(plt + slt), plt recomputed from all K regions
+                float4 plt = blt;
+                if (K <= 8) {
+#pragma unroll
+                    for (int k = 0; k < 8; ++k) if (k < K) fma4(plt, cf.al[k], lw[k]);
+                } else {
+                    const float* als = a.alphal + (s * MT + bt) * K;
+                    for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
+                }
+                fma4(pult, cf.delt, tanh4s(plt, cf.slt));
             }
             st4(a.dPG + fo, mul4(scale4(dpg, 4.f), ld4(a.Ug + 4 * d4)));        // sum deg (1 - tanh^2) = 4 sum deg (r - r^2)
             st4(a.dPM + fo, mul4(scale4(dpm, 4.f), ld4(a.Um + 4 * d4)));
             st4(a.dMo + fo, dmo);
             st4(a.pUg + fo, make_float4(sdeg - 2.f * ug.x, sdeg - 2.f * ug.y, sdeg - 2.f * ug.z, sdeg - 2.f * ug.w));   // sum deg tanh = sum deg (1 - 2 r)
             st4(a.pUm + fo, make_float4(sdem - 2.f * um.x, sdem - 2.f * um.y, sdem - 2.f * um.z, sdem - 2.f * um.w));
+            st4(a.pUlt + fo, pult);
         }
-        // region-level tensors, 4 regions at a time.  (8 at a time meant 40 float4 accumulators = one wave per SIMD for a
-        // kernel whose floor is VALU issue -- 0.4 G tanh -- not bandwidth; 4 at a time re-reads the per-step operands
-        // K / 4 times (L2 hits) and runs three waves per SIMD.)
-        float4 pul = make_float4(0.f, 0.f, 0.f, 0.f), pult = pul;
-        float sde_all = 0.f;
-        {
-            const int k0 = 4 * grp;
-            float4 pl[4], lw[4], lwx[4], dpl[4], dl[4], dlw[4];
+        return;
+    }
+    // ---- region-level tensors, the four regions k0 .. k0 + 3.  (Eight at a time meant 40 float4 accumulators = one wave per
+    // SIMD; four at a time re-reads the per-step operands K / 4 times -- L2 hits -- and runs three waves per SIMD.)
+    const int k0 = 4 * grp;
+    for (int d4 = tid; d4 < nd4; d4 += 256) {
+        const float4 ul = ld4(a.Ul + 4 * d4);
+        float4 pul = make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 pl[4], dpl[4], dl[4], dlw[4];
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            pl[kk] = exp2x4(ld4(a.PL + slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4));       // e^{2 PL} (see the frame part)
+            dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
+        }
+        struct StepIn { float4 sl, dcs, dp; float alt; float al[4], de[4]; };
+        auto fetch = [&](int s_) {
+            StepIn r;
+            r.sl = ld4(a.sproj + ((size_t)s_ * M + b) * 4 * D + 4 * d4);
+            r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
+            r.dp = ld4(a.dplt + (s_ * MT + bt) * D + 4 * d4);
+            r.alt = a.alt[s_ * MT + bt];
+            const float* als = a.alphal + (s_ * MT + bt) * K;
+            const float* des = a.del + (s_ * MT + bt) * K;
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                const size_t o = slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
-                pl[kk] = exp2x4(ld4(a.PL + o)); lw[kk] = ld4(a.LW + o);       // pl holds e^{2 PL} (see the frame-level part)
-                // first pass, K <= 8: regions 4..7 of LW as well -- plt below needs every region of the frame
-                lwx[kk] = (k0 == 0 && K > 4 && K <= 8) ? ld4(a.LW + slab + (size_t)min(4 + kk, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
-                dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
+                const int k = min(k0 + kk, K - 1);
+                r.al[kk] = als[k]; r.de[kk] = des[k];
             }
-            struct StepIn { float4 sl, dcs, dp, slt; float alt, delt; float al[4], de[4], alx[4]; };
-            auto fetch = [&](int s_) {
-                StepIn r;
-                const float* sp = a.sproj + ((size_t)s_ * M + b) * 4 * D;
-                r.sl = ld4(sp + 4 * d4);
-                r.slt = ld4(sp + 3 * D + 4 * d4);
-                r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
-                r.dp = ld4(a.dplt + (s_ * MT + bt) * D + 4 * d4);
-                r.alt = a.alt[s_ * MT + bt];
-                r.delt = a.delt[s_ * MT + bt];
-                const float* als = a.alphal + (s_ * MT + bt) * K;
-                const float* des = a.del + (s_ * MT + bt) * K;
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const int k = min(k0 + kk, K - 1);
-                    r.al[kk] = als[k]; r.de[kk] = des[k]; r.alx[kk] = als[min(4 + kk, K - 1)];
-                }
-                return r;
-            };
-            float sde = 0.f;
-            for (int s = 0; s < S; ++s) {
-                const StepIn cur = fetch(s);
-                const float4 dcl = scale4(cur.dcs, cur.alt);
-                const float4 esl = exp2x4(cur.sl);
-#pragma unroll
-                for (int kk = 0; kk < 4; ++kk) {
-                    const float4 r = rcp1p4(pl[kk], esl);
-                    fma4(dpl[kk], cur.de[kk], r_minus_sq(r));
-                    if (k0 + kk < K) { fma4(pul, cur.de[kk], r); sde += cur.de[kk]; }
-                    fma4(dl[kk], cur.al[kk], dcl);
-                    fma4(dlw[kk], cur.al[kk], cur.dp);
-                }
-                if (k0 == 0) {   // dUlt partial: delt * tanh(plt + slt), plt = blt + sum_k alpha_k LW_k recomputed (all K regions)
-                    float4 plt = blt;
-                    if (K <= 8) {
-#pragma unroll
-                        for (int kk = 0; kk < 4; ++kk) {
-                            if (kk < K) fma4(plt, cur.al[kk], lw[kk]);
-                            if (4 + kk < K) fma4(plt, cur.alx[kk], lwx[kk]);
-                        }
-                    } else {
-                        const float* als = a.alphal + (s * MT + bt) * K;
-                        for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
-                    }
-                    fma4(pult, cur.delt, tanh4s(plt, cur.slt));
-                }
-            }
+            return r;
+        };
+        float sde = 0.f;
+        StepIn nx = fetch(0);
+        for (int s = 0; s < S; ++s) {
+            const StepIn cur = nx;
+            nx = fetch(min(s + 1, S - 1));
+            const float4 dcl = scale4(cur.dcs, cur.alt);
+            const float4 esl = exp2x4(cur.sl);
 #pragma unroll
             for (int kk = 0; kk < 4; ++kk) {
-                if (k0 + kk < K) {
-                    const size_t o = slab + (size_t)(k0 + kk) * D + 4 * d4;
-                    st4(a.dPL + o, mul4(scale4(dpl[kk], 4.f), ul));
-                    st4(a.dL + o, dl[kk]);
-                    st4(a.dLW + o, dlw[kk]);
-                }
+                const float4 r = rcp1p4(pl[kk], esl);
+                fma4(dpl[kk], cur.de[kk], r_minus_sq(r));
+                if (k0 + kk < K) { fma4(pul, cur.de[kk], r); sde += cur.de[kk]; }
+                fma4(dl[kk], cur.al[kk], dcl);
+                fma4(dlw[kk], cur.al[kk], cur.dp);
             }
-            sde_all = sde;
         }
-        pul = make_float4(sde_all - 2.f * pul.x, sde_all - 2.f * pul.y, sde_all - 2.f * pul.z, sde_all - 2.f * pul.w);   // sum de tanh = sum de (1 - 2 r)
+#pragma unroll
+        for (int kk = 0; kk < 4; ++kk) {
+            if (k0 + kk < K) {
+                const size_t o = slab + (size_t)(k0 + kk) * D + 4 * d4;
+                st4(a.dPL + o, mul4(scale4(dpl[kk], 4.f), ul));
+                st4(a.dL + o, dl[kk]);
+                st4(a.dLW + o, dlw[kk]);
+            }
+        }
+        pul = make_float4(sde - 2.f * pul.x, sde - 2.f * pul.y, sde - 2.f * pul.z, sde - 2.f * pul.w);   // sum de tanh = sum de (1 - 2 r)
         st4(a.pUl + ((size_t)grp * MT + bt) * D + 4 * d4, pul);        // one partial per region group (summed by the column sums)
-        if (grp == 0) st4(a.pUlt + (size_t)bt * D + 4 * d4, pult);
     }
 }
 
@@ -745,7 +749,7 @@ int ctxgrad_groups(int K) { return (K + 3) / 4; }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
     const int NG = ctxgrad_groups(a.K);
     const int items8 = (a.M * a.T + 7) / 8;
-    hipLaunchKernelGGL(ctxgrad_kernel, dim3(items8 * 8 * NG), dim3(256), 0, s, a, NG);
+    hipLaunchKernelGGL(ctxgrad_kernel, dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
     return hipGetLastError();
 }
 // dst[n] (+)= sum_r X[r, n]; `part` must hold colsum_parts(rows, N) * N floats

@@ -414,6 +414,9 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
 // The slab is walked in groups of 8 regions held in registers (32 VGPRs); per hypothesis only the 8 partial scores,
 // the attended feature and its LW twin are carried (H x (8 + 4 + 4) VGPRs), the softmax lives in LDS.
 template <int H>
+#ifndef STATTN_SHARED_RG
+#define STATTN_SHARED_RG 4
+#endif
 __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArgs a) {
     __shared__ float s_red[4 * 2 * H];
     __shared__ float s_e[H][KMAX];
@@ -508,15 +511,22 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         float4 c4[H], w4[H];
 #pragma unroll
         for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
-        constexpr int RG = 4;                          // regions per round: 2 RG x 16 B per lane in flight together
-        for (int k0 = 0; k0 < K; k0 += RG) {
-            float4 l4[RG], q4[RG];
+        // RG regions per round, the NEXT round's rows requested before this round's FMAs (the rounds used to be a chain of
+        // K / RG exposed load latencies: this phase alone was 174 us at configs[4] for 0.67 GB)
+        constexpr int RG = STATTN_SHARED_RG;
+        float4 l4[RG], q4[RG], ln[RG], qn[RG];
+        auto rows = [&](float4 (&l)[RG], float4 (&q)[RG], int k0) {
 #pragma unroll
             for (int kk = 0; kk < RG; ++kk) {
                 const int k = min(k0 + kk, K - 1);
-                l4[kk] = ld4(L + (size_t)k * D + 4 * d4);
-                q4[kk] = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                l[kk] = ld4(L + (size_t)k * D + 4 * d4);
+                q[kk] = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        };
+        rows(l4, q4, 0);
+        for (int k0 = 0; k0 < K; k0 += RG) {
+            rows(ln, qn, min(k0 + RG, K - 1));
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int kk = 0; kk < RG; ++kk) {
 #pragma unroll
@@ -527,6 +537,8 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int kk = 0; kk < RG; ++kk) { l4[kk] = ln[kk]; q4[kk] = qn[kk]; }
         }
         const float4 bl = LW ? ld4(a.blt + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll

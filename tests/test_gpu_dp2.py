@@ -20,7 +20,7 @@ pytestmark = pytest.mark.gpu
 HERE = os.path.dirname(os.path.abspath(__file__))
 
 
-def _run_ranks(tmp, mode, world=2, timeout=420):
+def _run_ranks(tmp, mode, world=2, timeout=240):
     procs = []
     for r in range(world):
         env = dict(os.environ)

@@ -115,3 +115,28 @@ def test_shared_var_and_zipp_unzip_unbound():
     assert not common.unzip(tp)['w'].any()
     with pytest.raises(ValueError):
         sv.set_value(np.zeros((3, 2)))
+
+
+def test_one_hip_runtime_whichever_of_libstattn_and_torch_is_loaded_first():
+    """libstattn.so needs libamdhip64.so.7, torch's libraries ask for their bundled copy as libamdhip64.so: loaded in the
+    order (libstattn, torch) a process used to end up with TWO HIP + HSA runtimes, and torch's RCCL -- bound to the
+    uninitialised one -- failed ncclCommInitRank with "no ROCm-capable device" (found by the two-rank run of
+    tests/test_gpu_dp2.py).  _native.load_library() loads torch's copy first when torch is installed.  Needs no GPU."""
+    import subprocess
+    import sys
+    code = (
+        "import sys; sys.path.insert(0, %r)\n"
+        "import stattn\n"
+        "from stattn import _native\n"
+        "_native.load_library()\n"
+        "try:\n"
+        "    import torch\n"
+        "except ImportError:\n"
+        "    torch = None\n"
+        "hip = sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l})\n"
+        "print(len(hip), hip)\n" % os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    for order in ("stattn_first", "torch_first"):
+        src = code if order == "stattn_first" else "import torch\n" + code
+        out = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=300)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.split()[0] == "1", (order, out.stdout)

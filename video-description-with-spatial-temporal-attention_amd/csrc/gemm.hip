@@ -393,6 +393,7 @@ hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, b
     for (int i = 0; i < n; ++i) {
         GemmArgs g = gs[i];
         if (g.M <= 0 || g.N <= 0 || g.K <= 0 || g.N % BN != 0 || (!tA && g.K % 4 != 0) || (tA && g.M % 4 != 0)) return hipErrorInvalidValue;   // (tB: K % 4 == 0 as well, covered)
+        if (g.A2 && (tA || g.K % BK != 0 || g.K2 % BK != 0 || g.K2 <= 0)) return hipErrorInvalidValue;   // second operand pair: NN / NT, whole k-tiles
         g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
         edge = edge || g.K % BK != 0 || (tA && g.M % BM != 0);
         G.g[i] = g;

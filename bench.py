@@ -579,7 +579,7 @@ def main():
     slab_bytes = 2.0 if bf16 else 4.0                 # bf16 path: the region tensors are stored in bf16
     sp_bytes = B * T * D * (slab_bytes * nslab * K + 4.0 * 3)    # + PG, PM reads and the CL write
     # the off-critical-path halves of the recurrent GEMMs ride in the attention launches
-    fwd_rider = not bf16 and D % 1024 == 0 and 17 <= B <= 64 and not os.environ.get("STATTN_NO_RIDER")
+    fwd_rider = D % 1024 == 0 and 17 <= B <= 64 and not os.environ.get("STATTN_NO_RIDER")
     bwd_rider = 17 <= B <= 64 and not os.environ.get("STATTN_NO_RIDER") and not os.environ.get("STATTN_NO_PANELS")
     if fwd_rider:
         sp_bytes += 4.0 * D * 4 * D                   # the riding h.U GEMM streams decoder_U once per launch

@@ -328,8 +328,14 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
     constexpr int NW = NT / 64;
     __shared__ float s_red[NW * 10];
     __shared__ float s_e[KMAX];
+    // the first rider.nblocks workgroups compute the rider GEMM (h.U of this step) instead of an attention item (see spatial2_kernel)
+    if ((int)blockIdx.x < a.rider.nblocks) {
+        __shared__ __attribute__((aligned(16))) float s_rider[NW * 64 * 16];
+        rider_tile<NW>(a.rider, (int)blockIdx.x, s_rider);
+        return;
+    }
     const int T = a.T, K = a.K, D = a.D;
-    const int bt = blockIdx.x, b = bt / T, t = bt % T;
+    const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, t = bt % T;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
     const size_t slab = ((size_t)v * T + t) * K * D;
@@ -687,7 +693,7 @@ static bool spatial_shared_path(const SpatialArgs& a) {
 bool spatial_rider_supported(const SpatialArgs& a) {
     static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
     static const char* v1 = getenv("STATTN_SPATIAL1");
-    return !norider && !a.bf16 && !spatial_shared_path(a) && a.D % 1024 == 0 && !v1;
+    return !norider && (a.bf16 || !spatial_shared_path(a)) && a.D % 1024 == 0 && !v1;
 }
 
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
@@ -696,8 +702,8 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
     if (a.rider.nblocks && (!spatial_rider_supported(a) || !rider_shape_ok(a.rider))) return hipErrorInvalidValue;
     if (a.bf16) {
         if (a.D % 8 != 0 || !a.LW) return hipErrorInvalidValue;
-        if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T), dim3(128), 0, s, a);
-        else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T), dim3(256), 0, s, a);
+        if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
+        else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
         return hipGetLastError();
     }
     // beam search: the `group` consecutive rows of a video share its region tensors -> one pass over each slab

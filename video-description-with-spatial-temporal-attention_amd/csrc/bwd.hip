@@ -355,9 +355,14 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 // covered the load latency (313 us for a kernel whose VALU and HBM floors are 110 / 150 us).  Every workgroup kind therefore
 // requests step s + 1 before it computes step s, and the kinds are split so that each fits 168 VGPRs with the second
 // operand set (the dUlt partial needs the frame's whole LW slab in registers: it moved to the frame workgroup).
+// KR = 8 (K <= 8): the frame workgroup also forms the dUlt partial, the frame's LW slab in registers (NG + 1 workgroups per
+// item).  KR = 16 (K > 8): the dUlt partial has a workgroup of its own with up to 16 LW rows in registers (NG + 2): with the
+// rows re-read from L2 every step, configs[3] (K = 16) took 1065 us; split at K <= 8 as well it is slower (291 vs 237 us).
+template <int KR>
 __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, const int NG) {
+    constexpr bool WITH_ULT = KR <= 8;           // frame workgroup also does the dUlt partial
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
-    const int NW = NG + 1;
+    const int NW = NG + (WITH_ULT ? 1 : 2);
     const int n = blockIdx.x;
     int bt, grp;
     if (M & 7) { bt = (n / (8 * NW)) * 8 + (n & 7); grp = (n >> 3) % NW; }
@@ -380,19 +385,20 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             const float4 pg = exp2x4(ld4(a.PG + fo)), pm = exp2x4(ld4(a.PM + fo));
             float4 lw[8];                          // the frame's LW slab (K <= 8): plt = blt + sum_k alpha_k LW_k is recomputed per step
 #pragma unroll
-            for (int k = 0; k < 8; ++k) lw[k] = K <= 8 ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 8; ++k) lw[k] = (WITH_ULT && K <= 8) ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg, pult = dpg;
             float sdeg = 0.f, sdem = 0.f;
             struct FrameIn { float4 sg, sm, slt, dcs; float deg, dem, am, delt; float al[8]; };
             auto fetch_f = [&](int s_) {
                 FrameIn r;
                 const float* sp = a.sproj + ((size_t)s_ * M + b) * 4 * D;
-                r.sg = ld4(sp + D + 4 * d4); r.sm = ld4(sp + 2 * D + 4 * d4); r.slt = ld4(sp + 3 * D + 4 * d4);
+                r.sg = ld4(sp + D + 4 * d4); r.sm = ld4(sp + 2 * D + 4 * d4);
+                r.slt = WITH_ULT ? ld4(sp + 3 * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
                 r.dcs = ld4(a.dcsum + ((size_t)s_ * M + b) * D + 4 * d4);
                 r.deg = a.deg[s_ * MT + bt]; r.dem = a.dem[s_ * MT + bt]; r.am = a.am[s_ * MT + bt]; r.delt = a.delt[s_ * MT + bt];
                 const float* als = a.alphal + (s_ * MT + bt) * K;
 #pragma unroll
-                for (int k = 0; k < 8; ++k) r.al[k] = als[min(k, K - 1)];
+                for (int k = 0; k < 8; ++k) r.al[k] = WITH_ULT ? als[min(k, K - 1)] : 0.f;
                 return r;
             };
             FrameIn nx = fetch_f(0);
@@ -403,6 +409,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
                 fma4(dpg, cf.deg, r_minus_sq(rg)); fma4(ug, cf.deg, rg); sdeg += cf.deg;
                 fma4(dpm, cf.dem, r_minus_sq(rm)); fma4(um, cf.dem, rm); sdem += cf.dem;
                 fma4(dmo, cf.am, cf.dcs);
+                if (!WITH_ULT) continue;
                 // dUlt partial: delt * tanh(plt + slt), plt recomputed from all K regions
                 float4 plt = blt;
                 if (K <= 8) {
@@ -419,6 +426,45 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             st4(a.dMo + fo, dmo);
             st4(a.pUg + fo, make_float4(sdeg - 2.f * ug.x, sdeg - 2.f * ug.y, sdeg - 2.f * ug.z, sdeg - 2.f * ug.w));   // sum deg tanh = sum deg (1 - 2 r)
             st4(a.pUm + fo, make_float4(sdem - 2.f * um.x, sdem - 2.f * um.y, sdem - 2.f * um.z, sdem - 2.f * um.w));
+            if (WITH_ULT) st4(a.pUlt + fo, pult);
+        }
+        return;
+    }
+    if (!WITH_ULT && grp == NG + 1) {
+        // ---- dUlt partial alone: sum_s delt_s tanh(plt_s + slt_s), plt_s = blt + sum_k alpha_{s,k} LW_k recomputed from the
+        // frame's LW slab, in registers for K <= KR (a step's attention weights are uniform over the workgroup: scalar loads,
+        // requested a step ahead like the rows)
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            const size_t fo = (size_t)bt * D + 4 * d4;
+            const float4 blt = ld4(a.blt + 4 * d4);
+            float4 lw[KR];
+#pragma unroll
+            for (int k = 0; k < KR; ++k) lw[k] = K <= KR ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 pult = make_float4(0.f, 0.f, 0.f, 0.f);
+            struct UltIn { float4 slt; float delt; float al[KR]; };
+            auto fetch_u = [&](int s_) {
+                UltIn r;
+                r.slt = ld4(a.sproj + ((size_t)s_ * M + b) * 4 * D + 3 * D + 4 * d4);
+                r.delt = a.delt[s_ * MT + bt];
+                const float* als = a.alphal + (s_ * MT + bt) * K;
+#pragma unroll
+                for (int k = 0; k < KR; ++k) r.al[k] = als[min(k, K - 1)];
+                return r;
+            };
+            UltIn nx = fetch_u(0);
+            for (int s = 0; s < S; ++s) {
+                const UltIn cu = nx;
+                nx = fetch_u(min(s + 1, S - 1));
+                float4 plt = blt;
+                if (K <= KR) {
+#pragma unroll
+                    for (int k = 0; k < KR; ++k) if (k < K) fma4(plt, cu.al[k], lw[k]);
+                } else {
+                    const float* als = a.alphal + (s * MT + bt) * K;
+                    for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
+                }
+                fma4(pult, cu.delt, tanh4s(plt, cu.slt));
+            }
             st4(a.pUlt + fo, pult);
         }
         return;
@@ -749,7 +795,8 @@ int ctxgrad_groups(int K) { return (K + 3) / 4; }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
     const int NG = ctxgrad_groups(a.K);
     const int items8 = (a.M * a.T + 7) / 8;
-    hipLaunchKernelGGL(ctxgrad_kernel, dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
+    if (a.K <= 8) hipLaunchKernelGGL(ctxgrad_kernel<8>, dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
+    else hipLaunchKernelGGL(ctxgrad_kernel<16>, dim3(items8 * 8 * (NG + 2)), dim3(256), 0, s, a, NG);
     return hipGetLastError();
 }
 // dst[n] (+)= sum_r X[r, n]; `part` must hold colsum_parts(rows, N) * N floats

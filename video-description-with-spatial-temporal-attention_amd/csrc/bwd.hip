@@ -154,8 +154,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
 // partials (a few 4 KB vectors from L2); frame 0 stores it for the deferred context gradients.
 //
 // Spatial part: dplt, spatial softmax backward (del), per-frame dsl / dsg / dsm.
-__global__ __launch_bounds__(256, 4) void spatial_bwd_kernel(const SpatialBwdArgs a) {     // 4 waves per SIMD: at most 128 VGPRs
-    __shared__ float s_red[4 * 8];
+// KR = regions whose LW rows a lane holds in registers across the two uses (plt, then the d alpha dot products): 8 at four
+// waves per SIMD (128 VGPRs), 16 at three (168) -- for 8 < K <= 16 (configs[3]) that saves the second pass over the LW slab
+// of the generic path.
+template <int KR>
+__global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const SpatialBwdArgs a) {
+    __shared__ float s_red[4 * KR];
     __shared__ float s_al[KMAX], s_da[KMAX];
     // the first rider.nblocks workgroups compute the rider GEMM (dhU = dpre.U^T, needed only by the NEXT reverse step's
     // lstm_bwd) on the matrix cores this HBM-bound kernel leaves idle
@@ -180,7 +184,7 @@ __global__ __launch_bounds__(256, 4) void spatial_bwd_kernel(const SpatialBwdArg
     // (half of them: all eight would not fit the 128-VGPR budget next to the temporal part's own loads)
     constexpr int NPF = 4;
     float4 lw0[NPF];
-    if (K <= 8) {
+    if (K <= KR) {
 #pragma unroll
         for (int kk = 0; kk < NPF; ++kk) lw0[kk] = ld4(LW + (size_t)min(kk, K - 1) * D + 4 * min(tid, nd4 - 1));
     }
@@ -251,29 +255,29 @@ __global__ __launch_bounds__(256, 4) void spatial_bwd_kernel(const SpatialBwdArg
 
     // pass 1+2 fused per lane: recompute plt = sum_k alpha_k LW_k + blt, dplt = delt Ult (1 - tanh^2(plt + slt)) (:416-422),
     // then dalpha_k = <alt dcsum, L_k> + <dplt, LW_k> + r_k (CL = sum alpha L :383).  dplt of a lane only needs the
-    // lane's own columns, so for K <= 8 the LW slab is read ONCE and held in registers for both uses.
-    if (K <= 8) {
-        float p[8];
+    // lane's own columns, so for K <= KR the LW slab is read ONCE and held in registers for both uses.
+    if (K <= KR) {
+        float p[KR];
 #pragma unroll
-        for (int i = 0; i < 8; ++i) p[i] = 0.f;
+        for (int i = 0; i < KR; ++i) p[i] = 0.f;
         for (int d4 = tid; d4 < nd4; d4 += 256) {
-            float4 lw[8];
+            float4 lw[KR];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < KR; ++kk)
                 lw[kk] = (kk < NPF && d4 == tid) ? lw0[kk < NPF ? kk : 0] : ld4(LW + (size_t)min(kk, K - 1) * D + 4 * d4);
             float4 pl = ld4(a.blt + 4 * d4);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
+            for (int kk = 0; kk < KR; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
             const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
             const float4 dpl = scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt);
             st4(a.dplt + (size_t)bt * D + 4 * d4, dpl);
             const float4 dcl = scale4(dcs_lds ? ld4(&s_dcs[4 * d4]) : scale4(form_dcs(d4), sel), alt);
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk)
+            for (int kk = 0; kk < KR; ++kk)
                 p[kk] += dot4(dcl, ld4(L + (size_t)min(kk, K - 1) * D + 4 * d4)) + dot4(dpl, lw[kk]);
         }
-        block_sum<8>(p, s_red, tid, 4);
-        if (tid < 8 && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
+        block_sum<KR>(p, s_red, tid, 4);
+        if (tid < KR && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
         __syncthreads();
     } else {
         for (int d4 = tid; d4 < nd4; d4 += 256) {
@@ -782,7 +786,8 @@ hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     if (a.K > KMAX) return hipErrorInvalidValue;
     if (a.rider.nblocks && !rider_shape_ok(a.rider)) return hipErrorInvalidValue;
     if (!a.cparts || !a.csum || !a.dctxP || !a.dcsum || !a.dselpre) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(spatial_bwd_kernel, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
+    if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL(spatial_bwd_kernel<16>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
+    else hipLaunchKernelGGL(spatial_bwd_kernel<8>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,

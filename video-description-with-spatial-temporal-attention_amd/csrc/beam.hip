@@ -35,8 +35,8 @@ __device__ __forceinline__ void block_select(float (&lc)[KB], int (&li)[KB], int
         if (lane == 0) { s_cost[w] = c; s_idx[w] = idx; s_owner[w] = owner; }
         __syncthreads();
         c = s_cost[0]; idx = s_idx[0]; owner = s_owner[0];
-#pragma unroll
-        for (int i = 1; i < 4; ++i)
+        const int nwv = (int)blockDim.x >> 6;
+        for (int i = 1; i < nwv; ++i)
             if (cand_less(s_cost[i], s_idx[i], c, idx)) { c = s_cost[i]; idx = s_idx[i]; owner = s_owner[i]; }
         if (tid == 0) { res_c[r] = c; res_i[r] = idx; }
         if (tid == owner) {
@@ -103,16 +103,18 @@ __global__ __launch_bounds__(256) void beam_topk_part_kernel(const BeamArgs a, i
 
 // Stage 2 + bookkeeping, one workgroup per video: merge the nsplit * KB slice winners (<= 256) into the selection
 // (:923-928), then build the new hypotheses, retire the finished ones and gather the states (:939-985).
-__global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int nsplit, const float* __restrict__ pcost,
+// 256 threads per video, or 1024 on the small-batch path (launch_beam_update): a single video's selection is one workgroup's
+// serial work -- lse, candidate scan, selection, gathers -- and at k = 5 it was half of the decoded word
+__global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int nsplit, const float* __restrict__ pcost,
                                                           const int* __restrict__ pidx) {
     __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
     __shared__ int s_n, s_ended, s_rows;
-    __shared__ float s_cost[4];
-    __shared__ int s_idx[4];
-    __shared__ int s_owner[4];
+    __shared__ float s_cost[16];
+    __shared__ int s_idx[16];
+    __shared__ int s_owner[16];
     __shared__ float res_c[KB];
     __shared__ int res_i[KB];
-    const int v = blockIdx.x, tid = threadIdx.x;
+    const int v = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int k = a.k, D = a.D, L = a.maxlen, V = a.V, step = *a.step;
     const int nsel = a.live_k[v] > 0 ? k - a.dead_k[v] : 0;    // how many candidates survive (:923)
     if (nsel > 0 && a.stats) {
@@ -120,12 +122,12 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
         // the tile max, sum exp(v - max) and its best values; here: log-sum-exp per live row, then
         // cost = hyp_score - log p = hyp_score + lse - v for the tiles' candidates, merged like the slice winners above.
         __shared__ float s_lse[KB];
-        __shared__ float s_m[4][KB], s_s[4][KB];
+        __shared__ float s_m[16][KB], s_s[16][KB];
         const int live = a.live_k[v], nt = a.ntile, lane = tid & 63, w = tid >> 6;
         for (int j = 0; j < live; ++j) {   // per-thread running (max, sum) over its tiles, wave merge; ONE barrier for all rows
             const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
             float rm = -INFINITY, rs = 0.f;
-            for (int t = tid; t < nt; t += 256) {
+            for (int t = tid; t < nt; t += NT) {
                 const float tm = rec[(size_t)t * PN_STATS_REC], ts = rec[(size_t)t * PN_STATS_REC + 1];
                 if (tm > -INFINITY) {
                     const float nm = fmaxf(rm, tm);
@@ -139,10 +141,11 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
         }
         __syncthreads();
         if (tid < live) {
-            const float m = fmaxf(fmaxf(s_m[0][tid], s_m[1][tid]), fmaxf(s_m[2][tid], s_m[3][tid]));
+            const int nwv = NT >> 6;
+            float m = -INFINITY;
+            for (int q = 0; q < nwv; ++q) m = fmaxf(m, s_m[q][tid]);
             float ssum = 0.f;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) if (s_m[q][tid] > -INFINITY) ssum += s_s[q][tid] * __expf(s_m[q][tid] - m);
+            for (int q = 0; q < nwv; ++q) if (s_m[q][tid] > -INFINITY) ssum += s_s[q][tid] * __expf(s_m[q][tid] - m);
             s_lse[tid] = m + logf(ssum);
         }
         __syncthreads();
@@ -150,15 +153,26 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
         const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
-        for (int j = 0; j < live; ++j) {
-            const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
-            const float base = a.stochastic ? 0.f : a.hyp_score[v * k + j] + s_lse[j];
-            for (int e = tid; e < per; e += 256) {
-                const int t = e / nsel, i = e - t * nsel;
-                const float val = rec[(size_t)t * PN_STATS_REC + 2 + i];       // (stochastic: the tile's best PERTURBED value)
-                if (val > -INFINITY)
-                    list_insert(lc, li, base - val, j * V + reinterpret_cast<const int*>(rec)[(size_t)t * PN_STATS_REC + 2 + PN_STATS_KB + i]);
+        // one flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they are
+        // inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
+        const int C = live * per;
+        for (int c0 = 0; c0 < C; c0 += 4 * NT) {
+            float cv[4]; int ci[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int e = c0 + u * NT + tid;
+                cv[u] = INFINITY; ci[u] = 0x7fffffff;
+                if (e < C) {
+                    const int j = e / per, rem = e - j * per, t = rem / nsel, i = rem - t * nsel;
+                    const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
+                    const float val = rec[2 + i];                              // (stochastic: the tile's best PERTURBED value)
+                    const float base = a.stochastic ? 0.f : a.hyp_score[v * k + j] + s_lse[j];
+                    if (val > -INFINITY) { cv[u] = base - val; ci[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i]; }
+                }
             }
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+                if (ci[u] != 0x7fffffff) list_insert(lc, li, cv[u], ci[u]);
         }
         block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
         if (a.stochastic && tid == 0 && res_i[0] != 0x7fffffff) {
@@ -207,42 +221,50 @@ __global__ __launch_bounds__(256) void beam_update_kernel(const BeamArgs a, int 
     }
     __syncthreads();
     const int n = s_n;
-    for (int r = 0; r < n; ++r) {
-        const int ti = s_ti[r], slot = s_slot[r];
-        const int* __restrict__ src = a.tok_in + (size_t)(v * k + ti) * L;
-        int* __restrict__ dst = (s_fin[r] ? a.fin_tok : a.tok_out) + (size_t)(v * k + slot) * L;
-        for (int i = tid; i < step; i += 256) dst[i] = src[i];
-        if (tid == 0) dst[step] = s_wi[r];
-        if (!s_fin[r]) {                                       // gather the state of the parent hypothesis (:943-945)
-            const float* __restrict__ hs = a.h_step + (size_t)(v * k + ti) * D;
-            const float* __restrict__ cs = a.c_step + (size_t)(v * k + ti) * D;
-            float* __restrict__ hd = a.h_next + (size_t)(v * k + slot) * D;
-            float* __restrict__ cd = a.c_next + (size_t)(v * k + slot) * D;
-            for (int d = tid; d < D; d += 256) { hd[d] = hs[d]; cd[d] = cs[d]; }
-            if (a.proj_next) {   // the next step's state projections travel with the hypothesis (linear in h: gathered, not recomputed)
-                const float* __restrict__ ps = a.proj_step + (size_t)(v * k + ti) * a.nproj;
-                float* __restrict__ pd = a.proj_next + (size_t)(v * k + slot) * a.nproj;
-                for (int d = tid * 4; d < a.nproj; d += 1024) *reinterpret_cast<float4*>(pd + d) = *reinterpret_cast<const float4*>(ps + d);
-            }
-            if (a.h_next_pk)
-                for (int d = tid; d < D; d += 256) a.h_next_pk[pn_pack_offset(v * k + slot, d, D >> 4)] = hs[d];
-            // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here,
-            // so the word loop needs no separate lookup launch
-            if (a.emb_next) {
-                const float* __restrict__ we = a.Wemb + (size_t)s_wi[r] * a.E;
-                for (int e = tid; e < a.E; e += 256) {
-                    const float x = we[e];
-                    a.emb_next[(size_t)(v * k + slot) * a.E + e] = x;
-                    if (a.emb_next_pk) a.emb_next_pk[pn_pack_offset(v * k + slot, e, a.E >> 4)] = x;
-                }
-            }
+    // Copies of the n surviving candidates: tokens, then -- for the ones that stay live -- the parent's state, the next
+    // step's state projections, the packed h and the embedding of the chosen word.  One flat index space per field over ALL
+    // candidates: the loads of every row are in flight together.  (A loop over the candidates around per-row loops was a
+    // chain of n x 5 dependent read -> write round trips: 50 us of a 93 us word at k = 5.)
+    for (int i = tid; i < n * step; i += NT) {
+        const int r = i / step, j = i - r * step;
+        const int* __restrict__ src = a.tok_in + (size_t)(v * k + s_ti[r]) * L;
+        int* __restrict__ dst = (s_fin[r] ? a.fin_tok : a.tok_out) + (size_t)(v * k + s_slot[r]) * L;
+        dst[j] = src[j];
+    }
+    if (tid < n) ((s_fin[tid] ? a.fin_tok : a.tok_out) + (size_t)(v * k + s_slot[tid]) * L)[step] = s_wi[tid];
+    for (int i = tid; i < n * D; i += NT) {                   // gather the state of the parent hypothesis (:943-945)
+        const int r = i / D, d = i - r * D;
+        if (s_fin[r]) continue;
+        const size_t so = (size_t)(v * k + s_ti[r]) * D + d, dO = (size_t)(v * k + s_slot[r]) * D + d;
+        const float hv = a.h_step[so], cv = a.c_step[so];
+        a.h_next[dO] = hv; a.c_next[dO] = cv;
+        if (a.h_next_pk) a.h_next_pk[pn_pack_offset(v * k + s_slot[r], d, D >> 4)] = hv;
+    }
+    if (a.proj_next) {   // the next step's state projections travel with the hypothesis (linear in h: gathered, not recomputed)
+        const int np4 = a.nproj >> 2;
+        for (int i = tid; i < n * np4; i += NT) {
+            const int r = i / np4, d4 = i - r * np4;
+            if (s_fin[r]) continue;
+            reinterpret_cast<float4*>(a.proj_next + (size_t)(v * k + s_slot[r]) * a.nproj)[d4] =
+                reinterpret_cast<const float4*>(a.proj_step + (size_t)(v * k + s_ti[r]) * a.nproj)[d4];
+        }
+    }
+    // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here, so the
+    // word loop needs no separate lookup launch
+    if (a.emb_next) {
+        for (int i = tid; i < n * a.E; i += NT) {
+            const int r = i / a.E, e = i - r * a.E;
+            if (s_fin[r]) continue;
+            const float x = a.Wemb[(size_t)s_wi[r] * a.E + e];
+            a.emb_next[(size_t)(v * k + s_slot[r]) * a.E + e] = x;
+            if (a.emb_next_pk) a.emb_next_pk[pn_pack_offset(v * k + s_slot[r], e, a.E >> 4)] = x;
         }
     }
     // the video's loop ends with this word (:974-977): gen_sample returns f_next's state outputs of this very call,
     // one row per hypothesis that was live going in -- kept aside, later words overwrite h_step
     if (s_ended && a.end_h) {
         const size_t base = (size_t)v * k * D;
-        for (int i = tid; i < s_rows * D; i += 256) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
+        for (int i = tid; i < s_rows * D; i += NT) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
     }
     // Advance the word counter.  Every workgroup read *a.step when it started; the LAST one to get here (a ticket)
     // knows all of them did, so it may write step + 1 for the next word's kernels (was a one-thread launch of its own).
@@ -271,7 +293,7 @@ hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* par
     if (!a.ticket) return hipErrorInvalidValue;
     if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB || (a.stochastic && (a.k != 1 || a.tile_cols < 1)))) return hipErrorInvalidValue;
     if (a.proj_next && (!a.proj_step || a.nproj % 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
+    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(a.stats ? 1024 : 256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
     return hipGetLastError();
 }
 

@@ -48,6 +48,49 @@ __device__ __forceinline__ void block_select(float (&lc)[KB], int (&li)[KB], int
     }
 }
 
+// The same selection with ONE workgroup barrier instead of 2 n: every wave first selects its own n best (n rounds of a
+// wave-wide arg-min, no barrier), then wave 0 merges the <= 16 n wave winners.  s_c / s_i: [16 * KB] each.
+__device__ __forceinline__ void block_select2(float (&lc)[KB], int (&li)[KB], int n, float* s_c, int* s_i, float* res_c, int* res_i) {
+    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nwv = (int)blockDim.x >> 6;
+    for (int r = 0; r < n; ++r) {
+        float c = lc[0]; int idx = li[0]; int owner = lane;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
+            if (cand_less(oc, oi, c, idx)) { c = oc; idx = oi; owner = oo; }
+        }
+        if (lane == 0) { s_c[w * KB + r] = c; s_i[w * KB + r] = idx; }
+        if (lane == owner) {
+#pragma unroll
+            for (int i = 0; i < KB - 1; ++i) { lc[i] = lc[i + 1]; li[i] = li[i + 1]; }
+            lc[KB - 1] = INFINITY; li[KB - 1] = 0x7fffffff;
+        }
+    }
+    __syncthreads();
+    if (w == 0) {
+        float mc[2]; int mi[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int e = lane + 64 * u;                       // candidate e = (wave e / n, rank e % n)
+            const bool in = e < nwv * n;
+            mc[u] = in ? s_c[(e / n) * KB + e % n] : INFINITY;
+            mi[u] = in ? s_i[(e / n) * KB + e % n] : 0x7fffffff;
+        }
+        if (cand_less(mc[1], mi[1], mc[0], mi[0])) { const float tc = mc[0]; mc[0] = mc[1]; mc[1] = tc; const int ti = mi[0]; mi[0] = mi[1]; mi[1] = ti; }
+        for (int r = 0; r < n; ++r) {
+            float c = mc[0]; int idx = mi[0]; int owner = lane;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) {
+                const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
+                if (cand_less(oc, oi, c, idx)) { c = oc; idx = oi; owner = oo; }
+            }
+            if (lane == 0) { res_c[r] = c; res_i[r] = idx; }
+            if (lane == owner) { mc[0] = mc[1]; mi[0] = mi[1]; mc[1] = INFINITY; mi[1] = 0x7fffffff; }
+        }
+    }
+    __syncthreads();
+}
+
 __device__ __forceinline__ void list_insert(float (&lc)[KB], int (&li)[KB], float c, int flat) {
     if (cand_less(c, flat, lc[KB - 1], li[KB - 1])) {
         lc[KB - 1] = c; li[KB - 1] = flat;
@@ -109,25 +152,29 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
                                                           const int* __restrict__ pidx) {
     __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
     __shared__ int s_n, s_ended, s_rows;
-    __shared__ float s_cost[16];
-    __shared__ int s_idx[16];
-    __shared__ int s_owner[16];
+    __shared__ float s_c2[16 * KB];
+    __shared__ int s_i2[16 * KB];
     __shared__ float res_c[KB];
     __shared__ int res_i[KB];
     const int v = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
     const int k = a.k, D = a.D, L = a.maxlen, V = a.V, step = *a.step;
-    const int nsel = a.live_k[v] > 0 ? k - a.dead_k[v] : 0;    // how many candidates survive (:923)
+    const int live0 = a.live_k[v], dead0 = a.dead_k[v];
+    const int nsel = live0 > 0 ? k - dead0 : 0;                // how many candidates survive (:923)
     if (nsel > 0 && a.stats) {
         // Small-batch decode: no probabilities were materialised.  The logits launch left, per (row, vocabulary tile),
         // the tile max, sum exp(v - max) and its best values; here: log-sum-exp per live row, then
         // cost = hyp_score - log p = hyp_score + lse - v for the tiles' candidates, merged like the slice winners above.
         __shared__ float s_lse[KB];
         __shared__ float s_m[16][KB], s_s[16][KB];
-        const int live = a.live_k[v], nt = a.ntile, lane = tid & 63, w = tid >> 6;
-        for (int j = 0; j < live; ++j) {   // per-thread running (max, sum) over its tiles, wave merge; ONE barrier for all rows
+        const int live = live0, nt = a.ntile, lane = tid & 63, w = tid >> 6;
+        // Rows in parallel when there are waves enough (1024 threads): wave w takes row w % live and every (nwv / live)-th group
+        // of 64 tiles of it -- one load latency for all rows instead of one per row; else row after row over all threads.
+        const int nwv_ = NT >> 6, wpr = nwv_ / live;              // waves per row (0: fewer waves than rows)
+        for (int j = wpr ? w % live : 0; j < live; j += wpr ? live : 1) {
             const float* rec = a.stats + (size_t)(v * k + j) * nt * PN_STATS_REC;
             float rm = -INFINITY, rs = 0.f;
-            for (int t = tid; t < nt; t += NT) {
+            const int t0 = wpr ? (w / live) * 64 + lane : tid, tstep = wpr ? wpr * 64 : NT;
+            for (int t = (wpr && w / live >= wpr) ? nt : t0; t < nt; t += tstep) {
                 const float tm = rec[(size_t)t * PN_STATS_REC], ts = rec[(size_t)t * PN_STATS_REC + 1];
                 if (tm > -INFINITY) {
                     const float nm = fmaxf(rm, tm);
@@ -138,6 +185,8 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
             const float wm = wave_max(rm);
             const float ws = wave_sum(rm > -INFINITY ? rs * __expf(rm - wm) : 0.f);
             if (lane == 0) { s_m[w][j] = wm; s_s[w][j] = ws; }
+            if (wpr && lane == 0)                      // the other rows' slots of this wave: neutral elements
+                for (int o = 0; o < live; ++o) if (o != j) { s_m[w][o] = -INFINITY; s_s[w][o] = 0.f; }
         }
         __syncthreads();
         if (tid < live) {
@@ -174,7 +223,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
             for (int u = 0; u < 4; ++u)
                 if (ci[u] != 0x7fffffff) list_insert(lc, li, cv[u], ci[u]);
         }
-        block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
+        block_select2(lc, li, nsel, s_c2, s_i2, res_c, res_i);
         if (a.stochastic && tid == 0 && res_i[0] != 0x7fffffff) {
             // the draw is word res_i[0]; gen_sample's stochastic "score" is the running SUM of the drawn words'
             // probabilities (model_attention.py:916): p = exp(v - lse) with v the unperturbed logit kept by the tile
@@ -187,36 +236,45 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
         if (tid < nsplit * KB) { lc[0] = pcost[(size_t)v * nsplit * KB + tid]; li[0] = pidx[(size_t)v * nsplit * KB + tid]; }
-        block_select(lc, li, nsel, s_cost, s_idx, s_owner, res_c, res_i);
+        block_select2(lc, li, nsel, s_c2, s_i2, res_c, res_i);
     }
     __syncthreads();
-    if (tid == 0) {
-        int n = nsel;
-        for (int r = 0; r < nsel; ++r)                         // fewer candidates than slots (live * V < k - dead): argsort()[:n]
-            if (res_i[r] == 0x7fffffff) { n = r; break; }      // is simply shorter (:923); never index with the sentinel
-        int dead = a.dead_k[v], nl = 0;
-        for (int r = 0; r < n; ++r) {
-            const int ti = res_i[r] / V, wi = res_i[r] % V;    // trans_indices = ranks_flat // voc_size, word_indices = % (:926-927)
-            const float cost = res_c[r];
-            s_ti[r] = ti; s_wi[r] = wi;
-            if (wi == 0) {                                     // <eos>: the hypothesis dies (:958-962)
-                s_fin[r] = 1; s_slot[r] = dead;
-                a.fin_score[v * k + dead] = cost;
-                a.fin_len[v * k + dead] = step + 1;
-                ++dead;
+    if (tid < 64) {
+        // Bookkeeping of the nsel <= 8 winners, one lane each (it was a serial loop of thread 0: 10 us at k = 5).  Fewer
+        // candidates than slots (live * V < k - dead): argsort()[:n] is simply shorter (:923) -- n = the leading run of
+        // non-sentinel entries; never index with the sentinel.
+        const bool valid = tid < nsel && res_i[tid < KB ? tid : 0] != 0x7fffffff;
+        const unsigned long long bv = __ballot(valid);
+        const int n = __ffsll((long long)~bv) - 1;
+        const bool act = tid < n;
+        const int flat = act ? res_i[tid] : 1;
+        const int ti = flat / V, wi = flat % V;                // trans_indices = ranks_flat // voc_size, word_indices = % (:926-927)
+        const bool fin = act && wi == 0;                       // <eos>: the hypothesis dies (:958-962)
+        const unsigned long long bf = __ballot(fin), bl = __ballot(act && !fin), below = (1ull << tid) - 1ull;
+        if (act) {
+            const float cost = res_c[tid];
+            s_ti[tid] = ti; s_wi[tid] = wi; s_fin[tid] = fin ? 1 : 0;
+            if (fin) {
+                const int slot = dead0 + __popcll(bf & below);
+                s_slot[tid] = slot;
+                a.fin_score[v * k + slot] = cost;
+                a.fin_len[v * k + slot] = step + 1;
             } else {                                           // stays live (:963-970)
-                s_fin[r] = 0; s_slot[r] = nl;
-                a.hyp_score_out[v * k + nl] = cost;
-                a.next_w[v * k + nl] = wi;
-                ++nl;
+                const int slot = __popcll(bl & below);
+                s_slot[tid] = slot;
+                a.hyp_score_out[v * k + slot] = cost;
+                a.next_w[v * k + slot] = wi;
             }
         }
-        s_n = n; s_ended = 0; s_rows = a.live_k[v];
-        if (nsel > 0) {
-            a.dead_k[v] = dead;
-            const int live = (nl < 1 || dead >= k) ? 0 : nl;   // :974-977
-            a.live_k[v] = live;
-            if (live == 0) { s_ended = 1; if (a.end_rows) a.end_rows[v] = s_rows; }
+        if (tid == 0) {
+            const int dead = dead0 + __popcll(bf), nl = __popcll(bl);
+            s_n = n; s_ended = 0; s_rows = live0;
+            if (nsel > 0) {
+                a.dead_k[v] = dead;
+                const int live = (nl < 1 || dead >= k) ? 0 : nl;   // :974-977
+                a.live_k[v] = live;
+                if (live == 0) { s_ended = 1; if (a.end_rows) a.end_rows[v] = s_rows; }
+            }
         }
     }
     __syncthreads();
@@ -232,32 +290,67 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         dst[j] = src[j];
     }
     if (tid < n) ((s_fin[tid] ? a.fin_tok : a.tok_out) + (size_t)(v * k + s_slot[tid]) * L)[step] = s_wi[tid];
-    for (int i = tid; i < n * D; i += NT) {                   // gather the state of the parent hypothesis (:943-945)
-        const int r = i / D, d = i - r * D;
-        if (s_fin[r]) continue;
-        const size_t so = (size_t)(v * k + s_ti[r]) * D + d, dO = (size_t)(v * k + s_slot[r]) * D + d;
-        const float hv = a.h_step[so], cv = a.c_step[so];
-        a.h_next[dO] = hv; a.c_next[dO] = cv;
-        if (a.h_next_pk) a.h_next_pk[pn_pack_offset(v * k + s_slot[r], d, D >> 4)] = hv;
+    // (every gather below: four independent loads per thread in flight, then their stores)
+    for (int i0 = tid; i0 < n * D; i0 += 4 * NT) {             // gather the state of the parent hypothesis (:943-945)
+        float hv[4], cv[4]; size_t dO[4]; int rr[4], dd[4]; bool on[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int i = i0 + u * NT;
+            on[u] = i < n * D;
+            const int r = on[u] ? i / D : 0, d = on[u] ? i - r * D : 0;
+            on[u] = on[u] && !s_fin[r];
+            rr[u] = r; dd[u] = d;
+            const size_t so = (size_t)(v * k + s_ti[r]) * D + d;
+            dO[u] = (size_t)(v * k + s_slot[r]) * D + d;
+            hv[u] = on[u] ? a.h_step[so] : 0.f; cv[u] = on[u] ? a.c_step[so] : 0.f;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            if (!on[u]) continue;
+            a.h_next[dO[u]] = hv[u]; a.c_next[dO[u]] = cv[u];
+            if (a.h_next_pk) a.h_next_pk[pn_pack_offset(v * k + s_slot[rr[u]], dd[u], D >> 4)] = hv[u];
+        }
     }
     if (a.proj_next) {   // the next step's state projections travel with the hypothesis (linear in h: gathered, not recomputed)
         const int np4 = a.nproj >> 2;
-        for (int i = tid; i < n * np4; i += NT) {
-            const int r = i / np4, d4 = i - r * np4;
-            if (s_fin[r]) continue;
-            reinterpret_cast<float4*>(a.proj_next + (size_t)(v * k + s_slot[r]) * a.nproj)[d4] =
-                reinterpret_cast<const float4*>(a.proj_step + (size_t)(v * k + s_ti[r]) * a.nproj)[d4];
+        for (int i0 = tid; i0 < n * np4; i0 += 4 * NT) {
+            float4 pv[4]; float4* dst[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                dst[u] = nullptr;
+                if (i < n * np4) {
+                    const int r = i / np4, d4 = i - r * np4;
+                    if (!s_fin[r]) {
+                        pv[u] = reinterpret_cast<const float4*>(a.proj_step + (size_t)(v * k + s_ti[r]) * a.nproj)[d4];
+                        dst[u] = reinterpret_cast<float4*>(a.proj_next + (size_t)(v * k + s_slot[r]) * a.nproj) + d4;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) if (dst[u]) *dst[u] = pv[u];
         }
     }
     // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here, so the
     // word loop needs no separate lookup launch
     if (a.emb_next) {
-        for (int i = tid; i < n * a.E; i += NT) {
-            const int r = i / a.E, e = i - r * a.E;
-            if (s_fin[r]) continue;
-            const float x = a.Wemb[(size_t)s_wi[r] * a.E + e];
-            a.emb_next[(size_t)(v * k + s_slot[r]) * a.E + e] = x;
-            if (a.emb_next_pk) a.emb_next_pk[pn_pack_offset(v * k + s_slot[r], e, a.E >> 4)] = x;
+        for (int i0 = tid; i0 < n * a.E; i0 += 4 * NT) {
+            float xv[4]; int rr[4], ee[4]; bool on[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int i = i0 + u * NT;
+                on[u] = i < n * a.E;
+                const int r = on[u] ? i / a.E : 0, e = on[u] ? i - r * a.E : 0;
+                on[u] = on[u] && !s_fin[r];
+                rr[u] = r; ee[u] = e;
+                xv[u] = on[u] ? a.Wemb[(size_t)s_wi[r] * a.E + e] : 0.f;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (!on[u]) continue;
+                a.emb_next[(size_t)(v * k + s_slot[rr[u]]) * a.E + ee[u]] = xv[u];
+                if (a.emb_next_pk) a.emb_next_pk[pn_pack_offset(v * k + s_slot[rr[u]], ee[u], a.E >> 4)] = xv[u];
+            }
         }
     }
     // the video's loop ends with this word (:974-977): gen_sample returns f_next's state outputs of this very call,

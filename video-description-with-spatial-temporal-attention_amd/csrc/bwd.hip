@@ -69,6 +69,16 @@ __global__ __launch_bounds__(256) void dlogit_kernel(const float* __restrict__ p
     const float px = p[xi];
     const float w = nll_scale * mask[r] * px / (px + 1e-8f);
     float* d = dl + (size_t)r * ldd;
+    if (((ldp | ldd | Vp) & 3) == 0) {               // 16-byte loads and stores (the padded vocabulary always qualifies)
+        const int x4 = (int)xi >> 2, xc = (int)xi & 3;
+        for (int j4 = threadIdx.x; j4 < (Vp >> 2); j4 += 256) {
+            float4 q = ld4(p + 4 * j4);
+            if (j4 == x4) { if (xc == 0) q.x -= 1.f; else if (xc == 1) q.y -= 1.f; else if (xc == 2) q.z -= 1.f; else q.w -= 1.f; }
+            const int j = 4 * j4;
+            st4(d + j, make_float4(j < V ? w * q.x : 0.f, j + 1 < V ? w * q.y : 0.f, j + 2 < V ? w * q.z : 0.f, j + 3 < V ? w * q.w : 0.f));
+        }
+        return;
+    }
     for (int j = threadIdx.x; j < Vp; j += 256) {
         float v = 0.f;
         if (j < V) v = w * (p[j] - (j == (int)xi ? 1.f : 0.f));

@@ -622,7 +622,8 @@ __global__ __launch_bounds__(256) void multi_sum_part_kernel(const MultiSumArgs 
     const float* __restrict__ x = a.src[job];
     const size_t n = a.n[job];
     float acc = 0.f;
-    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)MS_BLOCKS * 256) acc += x[i];
+#pragma unroll 8
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (size_t)MS_BLOCKS * 256) acc += x[i];     // (unrolled: eight loads in flight)
     acc = wave_sum(acc);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = acc;
     __syncthreads();

@@ -20,10 +20,12 @@ __global__ __launch_bounds__(256) void ctx_mean_kernel(const float* __restrict__
                                                        float* __restrict__ mean, int T, int D) {
     const int b = blockIdx.x;
     float cnt = 0.f;
+#pragma unroll 8
     for (int t = 0; t < T; ++t) cnt += mask[(size_t)b * T + t];
     const float inv = 1.0f / cnt;
     for (int d = blockIdx.y * 256 + threadIdx.x; d < D; d += gridDim.y * 256) {
         float s = 0.f;
+#pragma unroll 8
         for (int t = 0; t < T; ++t) s += G[((size_t)b * T + t) * D + d];
         mean[(size_t)b * D + d] = s * inv;
     }
@@ -148,7 +150,8 @@ __global__ void cost_kernel(const float* __restrict__ nll, const float* __restri
     const int b = blockIdx.x * blockDim.x + threadIdx.x;
     if (b >= m) return;
     float s = 0.f;
-    for (int i = 0; i < t; ++i) s += mask[(size_t)i * m + b] * nll[(size_t)i * m + b];
+#pragma unroll 8
+    for (int i = 0; i < t; ++i) s += mask[(size_t)i * m + b] * nll[(size_t)i * m + b];      // (unrolled: the loads of eight steps in flight)
     cost[b] = s;
 }
 

@@ -683,7 +683,8 @@ __global__ __launch_bounds__(128) void embed_bwd_piece_kernel(const EmbedPlan pl
     float* __restrict__ dst = single ? dWemb + (size_t)pl.word_id[wi] * E : part + (size_t)s * E;
     for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += 128) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int j = beg; j < end; ++j) add4(acc, ld4(demb + (size_t)(pl.perm[j] + shift) * E + 4 * e4));
+#pragma unroll 4
+        for (int j = beg; j < end; ++j) add4(acc, ld4(demb + (size_t)(pl.perm[j] + shift) * E + 4 * e4));     // (same order; four rows in flight)
         st4(dst + 4 * e4, acc);
     }
 }
@@ -692,6 +693,7 @@ __global__ __launch_bounds__(128) void embed_bwd_word_kernel(const EmbedPlan pl,
     const int beg = pl.word_piece_start[wi], end = pl.word_piece_start[wi + 1];
     for (int e4 = threadIdx.x; e4 < (E >> 2); e4 += 128) {
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll 8
         for (int s = beg; s < end; ++s) add4(acc, ld4(part + (size_t)s * E + 4 * e4));
         st4(dWemb + (size_t)pl.word_id[wi] * E + 4 * e4, acc);
     }

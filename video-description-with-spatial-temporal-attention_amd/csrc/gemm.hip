@@ -267,6 +267,7 @@ __global__ void splitk_reduce_kernel(const float* __restrict__ ws, float* __rest
     const size_t n4 = (size_t)M * N / 4;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 a = ld4(ws + 4 * i);
+#pragma unroll 4
         for (int z = 1; z < slices; ++z) {
             const float4 b = ld4(ws + (size_t)z * M * N + 4 * i);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
@@ -284,6 +285,7 @@ __global__ void splitk_reduce_epi_kernel(const GemmArgs g, int slices) {
     const size_t n4 = (size_t)g.M * g.N / 4, MN = (size_t)g.M * g.N;
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
         float4 a = ld4(g.ws + 4 * i);
+#pragma unroll 4
         for (int z = 1; z < slices; ++z) {
             const float4 b = ld4(g.ws + (size_t)z * MN + 4 * i);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

@@ -111,7 +111,9 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
     float4 dh = make_float4(0.f, 0.f, 0.f, 0.f);
     if (!a.last) {
         dh = ld4(a.dh_pass + idx);
-        for (int p = 0; p < a.nU; ++p) add4(dh, ld4(a.dhU + (size_t)p * MD + idx));
+#pragma unroll 4
+        for (int p = 0; p < a.nU; ++p) add4(dh, ld4(a.dhU + (size_t)p * MD + idx));      // (K-slice partials: loads in flight together)
+#pragma unroll 4
         for (int p = 0; p < a.nW; ++p) add4(dh, ld4(a.dhW + (size_t)p * MD + idx));
         if (a.W_sel) fma4(dh, a.dselpre[b], ld4(a.W_sel + d));
     }

@@ -41,6 +41,9 @@ def _check_grads(got, ref, rtol=1e-4):
     (MEDIUM, 9, 26, 8, 7, {}),
     (SMALL, 70, 3, 2, 4, {}),                     # more rows than one 64-row tile
     (SMALL, 4, 5, 11, 5, {}),                     # K > 8: second region group
+    (SMALL, 4, 5, 16, 4, {}),                     # K = 16: every register-held LW row of the K <= 16 kernels in use
+    (SMALL, 35, 4, 13, 3, {}),                    # 8 < K <= 16 on the row-panel path (riders in the attention launches)
+    (SMALL, 3, 3, 19, 3, {}),                     # K > 16: the generic region loops
     (SMALL, 4, 5, 3, 5, dict(selector=False)),
     (SMALL, 4, 5, 3, 5, dict(ctx2out=False, prev2out=False)),
 ])
@@ -146,6 +149,21 @@ def test_clip_and_adadelta_update_match_oracle():
             scale = np.abs(d_ref).max()
             # (c*_att: zero gradient by shift invariance -> deltas ~1e-10; absolute floor)
             assert np.abs(d_got - d_ref).max() < 2e-2 * scale + 1e-7, (it, k)
+
+
+def test_c4_msrvtt_shape_gradients():
+    """BASELINE configs[3] shapes (T = 40, K = 16 regions, feat = 2048, hidden = 1024) through the backward pass on the
+    row-panel path (20 rows): all 41 gradients against the autograd oracle at the 1e-4 bar."""
+    from oracle import stattn_oracle_grad as OG
+    dims = dict(dim=1024, dim_word=512, n_words=1000, ctxg_dim=1024, ctxl_dim=2048, ctxm_dim=2048, ctxglm_dim=1024)
+    O, opt, P, dec = _setup(dims, 23)
+    batch = O.synthetic_batch(opt, B=20, T=40, K=16, t=3, seed=61)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    dec.backward(alpha_c=0.70602)
+    ref = OG.loss_and_grads(P, opt, batch, decay_c=0.0, alpha_c=0.70602)
+    _check_grads(dec.get_grads(), ref['grads'])
+    np.testing.assert_allclose(dec.get_loss(0.0), ref['loss'], rtol=2e-4)
 
 
 def test_sharded_gradient_equals_full_batch_gradient():

@@ -455,8 +455,10 @@ def test_c5_long_context_beam_shape(stattn_mod, O):
 
 
 # ------------------------------------------------------------------ batched device-side beam search
-@pytest.mark.parametrize("k", [1, 3, 5])
-def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
+# (k, videos): 6 videos x 1 and 8 x 2, 2 x 8 rows run the <= 16-row word (statistics epilogue, 1024-thread selection), the others
+# the general one; k = 8 is the widest beam the statistics records hold
+@pytest.mark.parametrize("k,nvid", [(1, 6), (3, 6), (5, 6), (2, 8), (8, 2)])
+def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k, nvid):
     """stattn_beam_search (device-side bookkeeping, many videos at once) against gen_sample per video --
     both the product's host-driven loop and the oracle's.  <eos> is made likely so hypotheses die at
     different steps (dead_k bookkeeping, early termination, dump of the remaining live ones)."""
@@ -467,7 +469,7 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k):
     model = stattn_mod.Attention()
     tparams = model.init_tparams(P)
     f_init, f_next = model.build_sampler(tparams, opt, None, None)
-    nvid, T, K, maxlen = 6, 5, 4, 9
+    T, K, maxlen = 5, 4, 9
     b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=70)
     f_next.device_loop = False        # gen_sample below = the host-driven loop, compared with the device-side one
     res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)

@@ -30,7 +30,7 @@ def pytest_collection_modifyitems(config, items):
 # Every GPU parity test of these modules runs twice: on a precision = 0 handle (fp32-input MFMA, the headline
 # configuration) and on a precision = 2 one (the same fp32 GEMMs as three-term bf16 operands on the bf16 matrix cores,
 # DESIGN.md section 12) -- same oracle, same fp32 tolerances.  A handle created with an explicit `precision=` keeps it.
-BOTH_PRECISIONS = {"test_gpu_parity", "test_gpu_backward", "test_gpu_edge_shapes", "test_data_and_metrics"}
+BOTH_PRECISIONS = {"test_gpu_parity", "test_gpu_backward", "test_gpu_edge_shapes", "test_data_and_metrics", "test_gpu_properties"}
 
 
 @pytest.fixture(autouse=True)

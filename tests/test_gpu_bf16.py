@@ -113,6 +113,81 @@ def test_bf16_c4_msrvtt_shape():
     assert np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() < TOL_LOGIT
 
 
+@pytest.mark.parametrize("B,t", [(20, 5), (64, 3)])
+def test_bf16_c4_bench_shape_rider_and_row_panel_path(B, t, tmp_path):
+    """configs[3] AT THE SHAPE bench.py --config c4 RUNS: D = 1024, T = 40, K = 16, F = 2048 and
+    17 <= rows <= 64, so `spatial_bf16_kernel` carries the h.U rider, the state projections / LSTM / reverse-scan GEMMs
+    are the row-panel kernels and `spatial_bwd` carries the dhU rider.  Checked: (1) the path counters say so; (2) all
+    four attention weights and the logits against the float64 oracle on ALL rows at the bf16 tolerances; (3) all 41
+    gradients within 5 % of their scale against the float64 autograd oracle and within 3 % of an fp32 handle's; (4) a
+    two-row subset run on an fp32 handle (other kernels: skinny GEMMs, no rider) agrees with those rows of the batch;
+    (5) a child process with STATTN_NO_RIDER=1 (same weights and batch, no rider in either direction) returns the same
+    numbers.  Reference: model_attention.py:366-459 (_step), :1193 (tensor.grad)."""
+    import os
+    import subprocess
+    import sys
+    import stattn
+    from oracle import stattn_oracle_grad as OG
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import _c4_worker as W
+    O, opt, P, batch, dec = W.case(B, t, "bf16")
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    ref = OG.loss_and_grads(P, opt, batch, decay_c=0.0, alpha_c=0.70602)
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name] - ref[name]).max() < TOL_ALPHA, (name, np.abs(out[name] - ref[name]).max())
+        np.testing.assert_allclose(out[name].sum(-1), 1.0, atol=1e-5)
+    V = opt['n_words']
+    assert np.abs(out['logit'].reshape(t, B, V) - ref['logit']).max() < TOL_LOGIT
+    np.testing.assert_allclose(out['cost'], ref['cost'], rtol=2e-2, atol=2e-2)
+    dec.backward(alpha_c=0.70602)
+    pc = dec.path_counts()
+    assert pc == dict(fwd_rider=t, fwd_panel=t, bwd_rider=t, bwd_panel=t), pc         # (1)
+    got = dec.get_grads()
+    f32 = stattn.Decoder(opt, lt_mode=1, precision="fp32")
+    f32.set_params(P); f32.set_batch(**batch); f32.forward_train()
+    o32 = f32.get_forward(logits=True)
+    f32.backward(alpha_c=0.70602)
+    g32 = f32.get_grads()
+    assert len(got) == 41 and list(got) == list(ref['grads'])
+    worst = {}
+    for k in got:                                                                      # (3)
+        scale = np.abs(np.asarray(ref['grads'][k])).max()
+        assert np.isfinite(got[k]).all(), k
+        e64 = np.abs(got[k] - ref['grads'][k]).max(); e32 = np.abs(got[k] - g32[k]).max()
+        worst[k] = (float(e64 / (scale + 1e-30)), float(e32 / (scale + 1e-30)))
+        assert e64 <= 5e-2 * scale + 5e-6, (k, worst[k])
+        assert e32 <= 3e-2 * scale + 5e-6, (k, worst[k])
+    np.testing.assert_allclose(dec.get_loss(0.0), ref['loss'], rtol=2e-2)
+    # the fp32 handle on this shape is itself at the fp32 bar (the K = 16 row-panel + rider path in fp32)
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(o32[name] - ref[name]).max() < 1e-4, name
+    # (4) a two-row subset on the fp32 handle: different kernels (skinny GEMMs, no riders), same rows of the same captions
+    rows = [1, B - 2]
+    sub = {k: np.ascontiguousarray(v[:, rows] if k in ('x', 'mask') else v[rows]) for k, v in batch.items()}
+    f32.set_batch(**sub); f32.forward_train()
+    osub = f32.get_forward(logits=True)
+    assert f32.path_counts()['fwd_rider'] == 0 and f32.path_counts()['fwd_panel'] == 0
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name][:, rows] - osub[name]).max() < TOL_ALPHA, name
+    assert np.abs(out['logit'].reshape(t, B, V)[:, rows] - osub['logit'].reshape(t, 2, V)).max() < TOL_LOGIT
+    # (5) the same pass without riders, in a child process (the switch is read once per process)
+    npz = str(tmp_path / "norider.npz")
+    env = dict(os.environ, STATTN_NO_RIDER="1")
+    subprocess.run([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "_c4_worker.py"),
+                    str(B), str(t), "bf16", npz], check=True, env=env, timeout=600)
+    nr = np.load(npz)
+    assert int(nr['pc_fwd_rider']) == 0 and int(nr['pc_bwd_rider']) == 0 and int(nr['pc_fwd_panel']) == t
+    for name in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[name] - nr[name]).max() < 2e-6, name
+    # (fp32-rounding-level differences in h flip bf16 roundings of the readout GEMM's operands: 2^-9 relative per flip)
+    assert np.abs(out['logit'] - nr['logit']).max() < 2e-3
+    for k in W.GRADS:
+        scale = np.abs(got[k]).max()
+        assert np.abs(got[k] - nr['g_' + k]).max() <= 1e-4 * scale + 1e-7, k
+
+
 def test_bf16_sampler_and_beam_search_agree_with_fp32_captions():
     """f_init / f_next / beam search run on the bf16-projected context: probabilities stay within tolerance of the
     oracle's, and the device beam search returns the same hypotheses as the host loop over the same handle."""

@@ -1,5 +1,5 @@
 """Randomised parity sweep (tools/fuzz_parity.py): random decoder shapes, option flags, batch shapes, lt_mode and precision
-(fp32 / split) against the float64 forward oracle and the autograd gradient oracle at the fp32 bar."""
+(fp32 / split / bf16) against the float64 forward oracle and the autograd gradient oracle at the fp32 bar."""
 import os
 import sys
 

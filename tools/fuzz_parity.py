@@ -1,7 +1,8 @@
 #!/usr/bin/env python
 """Randomised parity sweep (GPU): random decoder shapes / option flags / batch shapes, forward quantities and all
-gradients of a handle against the float64 / autograd oracle at the fp32 bar (1e-4), for precision fp32 and split and
-both lt_modes.  usage: fuzz_parity.py [n_cases] [seed] | large [n] [seed] | beam [n] [seed].  Prints one line per case and the worst ratios; exit code 1 on
+gradients of a handle against the float64 / autograd oracle at the fp32 bar (1e-4) for precision fp32 and split and
+both lt_modes, and -- every third case -- a bf16 handle (lt_mode 1) at the bf16 bars of tests/test_gpu_bf16.py (attention
+weights 2e-3, logits 3e-2, gradients 5 % of their scale).  usage: fuzz_parity.py [n_cases] [seed] | large [n] [seed] | beam [n] [seed].  Prints one line per case and the worst ratios; exit code 1 on
 a violation."""
 import os
 import sys
@@ -33,7 +34,12 @@ def run(n, seed, large=False):
                         selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
             B, T, K, t = int(rng.randint(1, 40)), int(rng.randint(1, 30)), int(rng.randint(1, 20)), int(rng.randint(2, 9))
         lt_mode = int(rng.randint(2))
-        precision = ["fp32", "split"][case % 2]
+        precision = ["fp32", "split", "bf16"][case % 3]
+        if precision == "bf16":
+            lt_mode = 1
+            if large and case % 2:
+                D = 1024; dims.update(dim=D, ctxg_dim=D, ctxglm_dim=D)     # the D % 1024 == 0 kernel with the rider
+        bar_a, bar_l, bar_g = (2e-3, 3e-2, 5e-2) if precision == "bf16" else (1e-4, 1e-4, 1e-4)
         opt = O.default_options(**dims)
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
         batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=int(rng.randint(1 << 30)))
@@ -44,8 +50,8 @@ def run(n, seed, large=False):
         out = dec.get_forward(logits=True)
         ref = O.build_model_forward(O.cast_params(P, np.float64), opt,
                                     **{k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()})
-        ef = max(np.abs(out[k] - ref[k]).max() for k in ('alphal', 'alphag', 'alpham', 'alphalt'))
-        ef = max(ef, np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max())
+        ef = max(np.abs(out[k] - ref[k]).max() for k in ('alphal', 'alphag', 'alpham', 'alphalt')) / bar_a
+        ef = max(ef, np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() / bar_l) * 1e-4   # in units of the fp32 bar
         alpha_c = float(rng.choice([0.0, 0.70602]))
         dec.backward(alpha_c=alpha_c)
         got = dec.get_grads()
@@ -53,7 +59,7 @@ def run(n, seed, large=False):
         eg, which = 0.0, ""
         for k in got:
             scale = np.abs(np.asarray(rg['grads'][k])).max()
-            r = np.abs(got[k] - rg['grads'][k]).max() / (1e-4 * scale + 5e-6)      # <= 1 passes (zero-gradient floor 5e-6)
+            r = np.abs(got[k] - rg['grads'][k]).max() / (bar_g * scale + 5e-6)      # <= 1 passes (zero-gradient floor 5e-6)
             if r > eg:
                 eg, which = r, k
         ok = ef < 1e-4 and eg <= 1.0

@@ -621,6 +621,13 @@ class Decoder(object):
         """hipGraph replays (two words each) in the last beam_search; 0 = the kernels were launched eagerly."""
         return int(self._lib.stattn_dbg_counter(self._h, 0))
 
+    def path_counts(self):
+        """Which kernels the decoder steps ran on: steps of the last forward_train (or f_next calls since) whose
+        attention launch carried the h.U rider / that used the row-panel kernels, and the same for the reverse steps of
+        the last backward.  Tests assert with it that a shape exercises the path it is meant to."""
+        names = ("fwd_rider", "fwd_panel", "bwd_rider", "bwd_panel")
+        return {n: int(self._lib.stattn_dbg_counter(self._h, i + 1)) for i, n in enumerate(names)}
+
     def time_gemm_bf16(self, M, N, K, tile=0, iters=20):
         ms = C.c_float()
         self._chk(self._lib.stattn_dbg_time_gemm_bf16(self._h, M, N, K, int(tile), iters, C.byref(ms)))

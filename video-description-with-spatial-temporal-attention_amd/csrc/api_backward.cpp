@@ -199,6 +199,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // at once -- waits for
     static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
     const bool rider = panels && m <= 64 && !norider;
+    h->path_bwd_rider = h->path_bwd_panel = 0;
     int kz1 = KZ1, kz2 = KZ2;
     float *dpre_pk = nullptr, *dsproj_pk = nullptr;
     int kzU = 256 / (D / 16); kzU = kzU < 1 ? 1 : (kzU > KZ1 ? KZ1 : kzU);          // K-slices of the riding dhU GEMM
@@ -228,6 +229,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     for (int st = t - 1; st >= 0; --st) {
         const size_t r0 = (size_t)st * m;
         const bool last = (st == t - 1);
+        h->path_bwd_rider += rider; h->path_bwd_panel += panels;
         {
             LstmBwdArgs a{};
             a.dh_pass = dhp_in; a.dhU = dhUP; a.nU = rider ? kzU : kz1; a.dhW = dhWP; a.nW = kz2;

@@ -169,6 +169,10 @@ int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, i
 long stattn_dbg_counter(const stattn_handle* h, int which) {
     if (!h) return -1;
     if (which == 0) return h->beam_graph_replays;
+    if (which == 1) return h->path_fwd_rider;
+    if (which == 2) return h->path_fwd_panel;
+    if (which == 3) return h->path_bwd_rider;
+    if (which == 4) return h->path_bwd_panel;
     return -1;
 }
 

@@ -127,6 +127,7 @@ int stattn_forward_train(stattn_handle* h) {
     const Weights& w = h->w;
     hipStream_t s = h->stream;
     const size_t R = (size_t)t * m;
+    h->path_fwd_rider = h->path_fwd_panel = 0;
 
     int64_t* dx = (int64_t*)h->bufs[bcur(h, "x")].p;
     float* dmask = findbuf(h, bcur(h, "mask").c_str());

@@ -115,6 +115,10 @@ struct stattn_handle {
     hipGraphExec_t beam_gexec8 = nullptr;   // eight words: a replay costs 10-16 us of launch overhead whatever it holds
     std::vector<uintptr_t> beam_gsig;
     long beam_graph_replays = 0;        // replays in the last stattn_beam_search (0 = eager launches)
+    // which code path the decoder steps took (stattn_dbg_counter 1..4; reset by stattn_forward_train / stattn_backward):
+    // forward steps whose attention launch carried the h.U rider, forward steps on the row-panel kernels, reverse steps
+    // whose attention launch carried the dhU rider, reverse steps on the row-panel kernels
+    long path_fwd_rider = 0, path_fwd_panel = 0, path_bwd_rider = 0, path_bwd_panel = 0;
     bool ck_valid = false;
     // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
     // ~15 us); sn_m / sn_dp / sn_vid remember that the constant step inputs (video index, eval dropout) are in place

@@ -270,6 +270,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
     sa.M = io.M; sa.T = io.T; sa.K = io.K; sa.D = D;
     const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && !io.skip_hproj && spatial_rider_supported(sa);
     const int ldp = io.ldproj ? io.ldproj : 4 * D;
+    h->path_fwd_rider += rider; h->path_fwd_panel += io.pn != nullptr;
     if (io.skip_hproj) {
     } else if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
         Prof pr(h, KC_HPROJ);

@@ -140,6 +140,244 @@ def cpu_baseline(c, options, params, seed, train, budget_s=20.0):
                        % (what, rows, c["t"], dt))
 
 
+def host_info():
+    """CPU model, logical cores, and the thread counts the CPU legs actually use."""
+    model = None
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                model = line.split(":", 1)[1].strip()
+                break
+    except Exception:
+        pass
+    blas = None
+    try:
+        import threadpoolctl
+        infos = threadpoolctl.threadpool_info()
+        blas = max([p.get("num_threads", 1) for p in infos] or [1])
+        lib = ", ".join(sorted({"%s %s" % (p.get("internal_api"), p.get("version")) for p in infos if p.get("user_api") == "blas"}))
+    except Exception:
+        lib = None
+    torch_threads = None
+    if "torch" in sys.modules:
+        torch_threads = sys.modules["torch"].get_num_threads()
+    return dict(cpu_model=model, logical_cores=os.cpu_count(), blas_threads=blas, blas_library=lib, torch_threads=torch_threads)
+
+
+def fast_features(nvid, T, K, F, D, seed):
+    """N(0,1) float32 features for `nvid` videos (Generator API draws float32 directly: 1.3 GB at configs[4] in a few seconds)."""
+    rng = np.random.default_rng(seed)
+    return dict(ctxg=rng.standard_normal((nvid, T, D), dtype=np.float32), mask_ctxg=np.ones((nvid, T), np.float32),
+                ctxl=rng.standard_normal((nvid, T, K, F), dtype=np.float32), ctxm=rng.standard_normal((nvid, T, F), dtype=np.float32))
+
+
+def word_loop_us(dec, k, long_len=30, short_len=14, reps=7):
+    """Microseconds per decoded word of the device word loop on the staged videos: (t(long) - t(short)) / (long - short),
+    medians over `reps` resident beam searches each -- the once-per-call projections, staging of the initial beam and the
+    result read-back cancel.  Both lengths are served by the captured 8-word and 2-word hipGraphs."""
+    ts = {}
+    for L in (long_len, short_len):
+        dec.beam_search(k=k, maxlen=L, suppress_eos=True, resident=True)
+        dec.sync()
+        xs = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            dec.beam_search(k=k, maxlen=L, suppress_eos=True, resident=True)
+            dec.sync()
+            xs.append(time.perf_counter() - t0)
+        ts[L] = float(np.median(xs))
+    return (ts[long_len] - ts[short_len]) / (long_len - short_len) * 1e6, ts[long_len] * 1e3
+
+
+def weight_bytes_per_word(c, lt_mode):
+    """fp32 weight bytes one decoded word streams: emb.W, h.U, h.[Wdl|Wdg|Wdm|Wdlt], ctx.Wc, the two readout
+    matrices, the vocabulary matrix (padded to 128 columns), and Wclt when it is applied per step (lt_mode 0)."""
+    D, E, Vp = c["D"], c["E"], (c["V"] + 127) // 128 * 128
+    return 4.0 * (E * 4 * D + 3 * 4 * D * D + 2 * D * E + E * Vp + (D * D if lt_mode == 0 else 0))
+
+
+def cpu_gen_sample(c, options, params, vids, k, maxlen, faithful):
+    """The oracle's gen_sample driven by the oracle's f_next on host cores (kind = port): `faithful` re-projects the video's
+    features F->D inside every f_next call like the reference graph (model_attention.py:782-785), else once per video."""
+    from oracle import stattn_oracle as O
+    cnt = [0]
+    cache = {}
+
+    def fn(x, g, gm, l, lm, m, mm, h, cc):
+        cnt[0] += x.shape[0]
+        cv = None
+        if not faithful:
+            if id(l) not in cache:
+                cache[id(l)] = O.project_video(params, options, g, l, m)
+            cv = cache[id(l)]
+        return O.f_next(params, options, x, g, gm, l, lm, m, mm, h, cc, cached=cv)
+    t0 = time.time()
+    for v in vids:
+        O.gen_sample(lambda g, m: O.f_init(params, options, g, m), fn, *v, k=k, maxlen=maxlen, suppress_eos=True)
+    dt = time.time() - t0
+    return cnt[0] / dt, cnt[0], dt
+
+
+def leg_decode_c1(args, local):
+    """BASELINE configs[0] (the reference's own evaluation loop, metrics.py:121-135: ONE video at a time through gen_sample):
+    4 videos, maxlen 30, <eos> suppressed, k = 1 and k = 5; host features handed over on every call (staged + projected inside).
+    `roofline`: bytes one greedy word has to stream (all decode weights once + one row's context tensors) / the measured time
+    per word of the device word loop / 8 TB/s."""
+    import stattn
+    c = CONFIGS["c1"]
+    options = make_options(c)
+    dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode)
+    params = fast_params(dec.param_shapes(), 1234)
+    dec.set_params(params)
+    f = fast_features(c["B"], c["T"], c["K"], c["F"], c["D"], 4321)
+    t = c["t"]
+    out = dict(workload="c1 decode: gen_sample per video (device word loop, host features staged + projected per call), %d videos, maxlen %d, "
+                        "<eos> suppressed, T=%d K=%d feat=%d hidden=%d E=%d vocab=%d" % (c["B"], t, c["T"], c["K"], c["F"], c["D"], c["E"], c["V"]),
+               unit="row-steps/s")
+    for k in (1, 5):
+        def one_pass():
+            for i in range(c["B"]):
+                dec.beam_search(f["ctxg"][i:i + 1], f["mask_ctxg"][i:i + 1], f["ctxl"][i:i + 1], f["ctxm"][i:i + 1], k=k, maxlen=t, suppress_eos=True)
+        one_pass()
+        dec.sync()
+        reps = 5
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            one_pass()
+        dec.sync()
+        dt = time.perf_counter() - t0
+        rs = c["B"] * (1 + k * (t - 1)) * reps
+        out["k%d" % k] = dict(value=rs / dt, ms_per_video=dt / reps / c["B"] * 1e3, graph_replays_per_video=dec.beam_graph_replays())
+    # the word loop alone, on one resident video, k = 1 and k = 5
+    dec.beam_stage(f["ctxg"][:1], f["mask_ctxg"][:1], f["ctxl"][:1], f["ctxm"][:1])
+    nslab = 3 if dec.lt_mode == 1 else 2
+    ctx_row = (nslab * c["K"] + 3) * c["T"] * c["D"] * 4.0
+    wb = weight_bytes_per_word(c, dec.lt_mode)
+    for k in (1, 5):
+        us, _ = word_loop_us(dec, k)
+        nbytes = wb + k * ctx_row
+        out["k%d" % k].update(us_per_word=us, roofline=dict(kernel="device word loop, one video, %d row(s): 6 launches per word" % k, bound="hbm",
+                                                             achieved=nbytes / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
+                                                             frac=nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None,
+                                                             bytes_per_word=nbytes, weight_bytes=wb, context_bytes_per_row=ctx_row))
+    # all four videos batched (stattn_beam_search over 4 videos, k = 1): the same work without the per-video serialisation
+    dec.beam_stage(f["ctxg"], f["mask_ctxg"], f["ctxl"], f["ctxm"])
+    us4, ms4 = word_loop_us(dec, 1)
+    out["batched4_k1"] = dict(value=c["B"] * t / (ms4 * 1e-3), ms_per_call=ms4, us_per_word=us4)
+    out["value"] = out["k1"]["value"]
+    out["roofline"] = out["k1"]["roofline"]
+    if not args.no_cpu_baseline:
+        vids = [(f["ctxg"][i], f["mask_ctxg"][i], f["ctxl"][i], None, f["ctxm"][i], None) for i in range(2)]
+        v_f, n_f, dt_f = cpu_gen_sample(c, options, params, vids[:1], 1, t, True)
+        v_c, n_c, dt_c = cpu_gen_sample(c, options, params, vids, 1, t, False)
+        hi = host_info()
+        out["cpu_baseline"] = dict(value=v_f, unit="row-steps/s", cores=hi["blas_threads"] or hi["logical_cores"], kind="port",
+                                   sample="oracle gen_sample(k=1, maxlen=%d) driven by the oracle's f_next, float32 numpy: reference-faithful "
+                                          "(F->D re-projection inside every f_next call, model_attention.py:782-785) on 1 video = %d row-steps in %.1f s; "
+                                          "projection cached on 2 videos = %d row-steps in %.1f s" % (t, n_f, dt_f, n_c, dt_c),
+                                   value_projection_cached=v_c, **hi)
+        out["speedup_vs_cpu_reference_faithful"] = out["k1"]["value"] / v_f
+        out["speedup_vs_cpu_projection_cached"] = out["k1"]["value"] / v_c
+    del dec
+    return out
+
+
+def leg_beam_c5(args, local, params):
+    """BASELINE configs[4]: 32 videos x beam 5, T = 80, K = 32, batched device beam search with the hipGraph-captured word loop,
+    inputs resident in HBM.  Per-kernel figures come from one profiled (eagerly launched) call: HIP events on the library's stream."""
+    import stattn
+    c = CONFIGS["c5"]
+    options = make_options(c)
+    dec = stattn.Decoder(options, device=local, lt_mode=args.lt_mode)
+    dec.set_params(params)                                # configs[1]'s weights: same architecture and sizes
+    k, t = 5, c["t"]
+    nv, T, K, D, E, F = c["B"], c["T"], c["K"], c["D"], c["E"], c["F"]
+    Vp = (c["V"] + 127) // 128 * 128
+    f = fast_features(nv, T, K, F, D, 777)
+    dec.beam_stage(f["ctxg"], f["mask_ctxg"], f["ctxl"], f["ctxm"])
+    dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
+    dec.sync()
+    reps = 5
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
+    dec.sync()
+    dt = time.perf_counter() - t0
+    replays = dec.beam_graph_replays()
+    M = nv * k
+    rs = nv * (1 + k * (t - 1))
+    us, _ = word_loop_us(dec, k, reps=3)
+    dec.set_profiling(True)
+    dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
+    kms = dec.kernel_ms()
+    dec.set_profiling(False)
+    nslab = 3 if dec.lt_mode == 1 else 2
+    # one pass over every (video, frame) slab for all k hypotheses + per hypothesis: CL written, state projections read; PG, PM per video
+    sp_bytes = nv * T * (nslab * K * D * 4.0) + M * T * D * 4.0 + 2.0 * nv * T * D * 4.0 + M * 4 * D * 4.0
+
+    def hbm(name, nbytes, ms):
+        return dict(kernel=name, bound="hbm", achieved=nbytes / (ms * 1e-3) / 1e9 if ms else None, peak=HBM_PEAK_GBS, unit="GB/s",
+                    frac=nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS if ms else None, traffic=None, bytes_per_launch=nbytes, ms_per_launch=ms)
+
+    def mfma(name, flops, ms):
+        return dict(kernel=name, bound="mfma", achieved=flops / (ms * 1e-3) / 1e12 if ms else None, peak=MFMA_F32_PEAK_TF, unit="TFLOP/s",
+                    frac=flops / (ms * 1e-3) / 1e12 / MFMA_F32_PEAK_TF if ms else None, flops_per_launch=flops, ms_per_launch=ms)
+    rec_flops = 2.0 * M * D * 8 * D + 2.0 * M * (D + E) * 4 * D
+    ro_flops = 2.0 * M * 2 * D * E + 2.0 * M * E * Vp
+    rec_ms = kms["hproj"][0] + kms["lstm"][0]
+    out = dict(workload="c5 beam: batched device beam search, %d videos x beam %d, maxlen %d, <eos> suppressed, T=%d K=%d feat=%d hidden=%d E=%d "
+                        "vocab=%d, inputs resident in HBM, the F->D projections redone in every call" % (nv, k, t, T, K, F, D, E, c["V"]),
+               value=rs * reps / dt, unit="row-steps/s", ms_per_call=dt / reps * 1e3, graph_replays=replays, us_per_word=us,
+               value_word_loop_only=M * 1e6 / us, projections_ms_per_call=kms["prologue"][0],
+               roofline_hbm=hbm("spatial_shared_kernel<%d>" % k, sp_bytes, kms["spatial"][0]),
+               recurrent_gemms=mfma("160-row state projections h.[Wd*|U] + LSTM [ctx|emb].[Wc|W] (2 launches per word)", rec_flops, rec_ms),
+               kernels=dict(state_proj=mfma("h.[Wdl|Wdg|Wdm|Wdlt|U] %dx%dx%d" % (M, 8 * D, D), 2.0 * M * D * 8 * D, kms["hproj"][0]),
+                            lstm=mfma("[ctx|emb].[Wc|W] + gates %dx%dx%d" % (M, 4 * D, D + E), 2.0 * M * (D + E) * 4 * D, kms["lstm"][0]),
+                            readout_logits_softmax=mfma("readout %dx%dx%d + logits %dx%dx%d (+ softmax), scope" % (M, E, 2 * D, M, Vp, E), ro_flops, kms["readout"][0]),
+                            temporal=hbm("temporal_kernel", M * T * D * 4.0 * 3, kms["temporal"][0]),
+                            select=dict(kernel="beam_topk_part + merge + beam_update (scope)", bound="latency", ms_per_launch=kms["select"][0])),
+               word_us_by_events=sum(kms[x][0] for x in ("hproj", "spatial", "temporal", "lstm", "readout", "select")) * 1e3)
+    out["roofline"] = out["roofline_hbm"]
+    if not args.no_cpu_baseline:
+        short = 4
+        vids = [(f["ctxg"][0], f["mask_ctxg"][0], f["ctxl"][0], None, f["ctxm"][0], None)]
+        v_f, n_f, dt_f = cpu_gen_sample(c, options, params, vids, k, short, True)
+        v_c, n_c, dt_c = cpu_gen_sample(c, options, params, vids, k, short, False)
+        hi = host_info()
+        out["cpu_baseline"] = dict(value=v_f, unit="row-steps/s", cores=hi["blas_threads"] or hi["logical_cores"], kind="port",
+                                   sample="oracle gen_sample(k=%d, maxlen=%d) on ONE video of the same shapes, float32 numpy: reference-faithful (re-projection "
+                                          "inside every f_next call) %d row-steps in %.1f s; projection cached %d row-steps in %.1f s"
+                                          % (k, short, n_f, dt_f, n_c, dt_c), value_projection_cached=v_c, **hi)
+    del dec, f
+    return out
+
+
+def leg_h2d_prefetch(dec, batch, core, steps):
+    """The train step with the minibatch moved host -> device on EVERY step like the reference's f_grad_shared (host numpy in,
+    model_attention.py:1251-1259): pinned arrays, stattn_prefetch_batch on the copy stream while the previous step computes,
+    stattn_swap_batch.  Never the headline value."""
+    pinned = {}
+    nbytes = 0
+    for k_, v_ in batch.items():
+        pinned[k_] = dec.pinned_empty(v_.shape, v_.dtype)
+        pinned[k_][...] = v_
+        nbytes += v_.nbytes
+    dec.prefetch_batch(**pinned)
+
+    def step():
+        dec.swap_batch()
+        dec.prefetch_batch(**pinned)
+        core()
+    for _ in range(3):
+        step()
+    dec.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    dec.sync()
+    return (time.perf_counter() - t0) / steps * 1e3, nbytes
+
+
 def decode_bench(args, c, options, params, dec, batch, rank, world, dist):
     """BASELINE.md section 3 protocol: gen_sample (model_attention.py:852-994) per video through f_init / f_next,
     <eos> suppressed so every hypothesis runs maxlen = caption length steps; row-steps = hypotheses x steps.
@@ -400,6 +638,11 @@ def main():
                                                                "the `traffic` fields live (falls back to profiles/pmc_traffic.json)")
     ap.add_argument("--no-split", action="store_true", help="skip the extra precision='split' measurement reported beside the fp32 headline")
     ap.add_argument("--kernel-breakdown", action="store_true", help="print per-kernel-class ms to stderr")
+    ap.add_argument("--no-legs", action="store_true", help="default train run at N = 1: skip the extra legs measured in the same run "
+                    "(decode_c1, beam_c5, h2d_prefetch_ms)")
+    ap.add_argument("--overlap", type=int, default=1, choices=[0, 1], help="N > 1: 1 = regions of the gradient buffer are all-reduced on a "
+                    "side stream while backward still runs (default), 0 = one all-reduce after backward; the other setting is "
+                    "measured beside it over a few untimed steps (comm_ab)")
     args = ap.parse_args()
     args.beam_set = args.beam is not None
     if args.beam is None:
@@ -457,6 +700,8 @@ def main():
         ncomm = dec.comm_info()[1]
         if world > 1 and ncomm != world:
             raise SystemExit("RCCL communicator has %d ranks, expected %d" % (ncomm, world))
+        if world > 1:
+            dec.comm_set_overlap(args.overlap)
     else:
         dec.set_seed(1234 + rank)
     step_fn = dp.DataParallelStep(dec, global_batch=c["B"] * world, alpha_c=0.70602, decay_c=1e-4, clip_c=10.0) \
@@ -494,7 +739,14 @@ def main():
         step_fn()
     barrier()
     dt = time.perf_counter() - t0
+    rank_ms = None
     if world > 1:
+        # per-rank compute time of a step WITHOUT the wait for the slowest rank is not observable from the wall clock
+        # (the all-reduce couples the ranks); what is: every rank's own wall time over the timed region (max = the line)
+        mine = torch.zeros(world, dtype=torch.float64)
+        mine[rank] = dt / args.steps * 1e3
+        dist.all_reduce(mine, op=dist.ReduceOp.SUM)
+        rank_ms = dict(min=float(mine.min()), max=float(mine.max()))
         tt = torch.tensor([dt], dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
@@ -521,6 +773,31 @@ def main():
             tt = torch.tensor([float(st["ranks"])], dtype=torch.float64)
             dist.all_reduce(tt, op=dist.ReduceOp.MIN)
             comm["rccl_ranks"] = int(tt.item())           # the smallest communicator any rank reports
+            comm["ms_per_step_rank_min"], comm["ms_per_step_rank_max"] = rank_ms["min"], rank_ms["max"]
+            # A/B of the overlapped exchange under real contention: a few untimed steps with each setting, wall time
+            # (max over ranks) and the exposed part of the all-reduce for both
+            ab = {}
+            for mode in (0, 1):
+                dec.comm_set_overlap(mode)
+                for _ in range(2):
+                    step_fn()
+                barrier()
+                t1 = time.perf_counter()
+                n_ab = 8
+                for _ in range(n_ab):
+                    step_fn()
+                barrier()
+                ms = (time.perf_counter() - t1) / n_ab * 1e3
+                ex = []
+                for _ in range(3):
+                    step_fn()
+                    ex.append(dec.comm_stats()["exposed_ms"])
+                tt = torch.tensor([ms, float(np.mean(ex))], dtype=torch.float64)
+                dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+                ab["overlap%d" % mode] = dict(ms_per_step=float(tt[0].item()), allreduce_exposed_ms=float(tt[1].item()),
+                                              regions=dec.comm_stats()["regions"])
+            dec.comm_set_overlap(args.overlap)
+            comm["comm_ab"] = ab
 
     # ---- rooflines, timed live with HIP events on the library's stream (forward pass: that is where the per-class events live)
     dec.set_profiling(True)
@@ -712,9 +989,23 @@ def main():
                                  gemm_peak_TFLOPs=MFMA_BF16_PEAK_TF / 6.0,
                                  note="same step with stattn_options.precision = 2: fp32 results at the fp32 parity bar (tests/test_gpu_split.py)")
         del alt
+    legs = (train and args.config == "c2" and world == 1 and args.h2d == "none" and args.precision == "fp32" and not args.no_legs
+            and not os.environ.get("STATTN_BENCH_CHILD"))
+    if legs:
+        # measured in the SAME run, never as `value`: the train step with the minibatch crossing PCIe on every step, the
+        # reference's own per-video decode loop (configs[0]) and the long-context beam search (configs[4])
+        core = dp.DataParallelStep(dec, global_batch=c["B"], alpha_c=0.70602, decay_c=1e-4, clip_c=10.0)
+        ms, nb = leg_h2d_prefetch(dec, batch, core, 20)
+        out["h2d_prefetch_ms"] = ms
+        out["h2d_prefetch"] = dict(ms_per_step=ms, value=c["B"] * c["t"] / (ms * 1e-3), unit="row-steps/s", bytes_per_step=nb,
+                                   note="every step's minibatch copied from pinned host arrays on a copy stream while the previous step computes "
+                                        "(stattn_prefetch_batch / stattn_swap_batch); the reference's f_grad_shared takes host numpy on every call")
+        out["decode_c1"] = leg_decode_c1(args, local)
+        out["beam_c5"] = leg_beam_c5(args, local, params)
     if rank == 0:
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(c, options, params, 99, train)
+            out["cpu_baseline"].update(host_info())
         print(json.dumps(out))
     sys.stdout.flush()
     os.dup2(2, 1)                         # whatever C libraries still hold in their stdio buffers goes to stderr at exit

@@ -263,14 +263,17 @@ int stattn_broadcast_params(stattn_handle* h, int root);
 int stattn_allreduce_scalars(stattn_handle* h, float* vals, int n);
 
 /* ---- measurement hooks (bench.py's per-kernel rooflines) -------------------------------------------- */
-/* Average duration (ms) of the named kernel class over the last stattn_forward_train
- * when profiling is enabled: 0 = spatial attention, 1 = state projections, 2 = local-
- * temporal GEMM, 3 = temporal fuse, 4 = lstm, 5 = prologue scope (sum), 6 = readout scope (sum), 7 = every plain (NN) launch of the
- * LDS-tiled GEMM in the forward pass; 8 + i = the i-th of those launches alone (i < 16, in launch order: ff_local,
- * ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits);
- * over the last stattn_backward: 24 + i = the i-th LDS-tiled GEMM launch of the pass (i < 24, launch order: da, readout weight
- * gradients, readout input gradients, ... ), 48 .. 54 = lstm_bwd, panel dctx (|dhU), [temporal_bwd: part of spatial_bwd since round 3, no launches], spatial_bwd, reduce_T, panel dhW
- * (one launch per reverse-scan step each) and the deferred ctxgrad kernel. */
+/* Average duration (ms) of the named kernel class over the last stattn_forward_train (or the stattn_beam_search /
+ * f_next calls since profiling was switched on; a profiled beam search launches its words eagerly instead of replaying
+ * its hipGraphs): 0 = spatial attention, 1 = state projections, 2 = local-temporal GEMM, 3 = temporal fuse, 4 = lstm,
+ * 5 = prologue scope (sum), 6 = readout scope (training: sum of the batched readout; beam search: readout + vocabulary
+ * launch [+ softmax] of one word), 7 = every plain (NN) launch of the LDS-tiled GEMM in the forward pass, 8 = beam search:
+ * candidate selection + beam update of one word; 9 + i = the i-th plain GEMM launch alone (i < 16, in launch order:
+ * ff_local, ff_motion, pctxg, pctxl, pctxm, L.Wclt [lt_mode 1], x projection, readout 1, readout 2 [ctx2out], logits);
+ * over the last stattn_backward: 25 + i = the i-th LDS-tiled GEMM launch of the pass (i < 24, launch order: da, readout
+ * weight gradients, readout input gradients, ... ), 49 .. 55 = lstm_bwd, panel dctx (|dhU), [temporal_bwd: part of
+ * spatial_bwd since round 3, no launches], spatial_bwd, reduce_T, panel dhW (one launch per reverse-scan step each) and
+ * the deferred ctxgrad kernel. */
 int stattn_set_profiling(stattn_handle* h, int enable);
 int stattn_get_kernel_ms(stattn_handle* h, int which, float* ms_avg, int* launches);
 

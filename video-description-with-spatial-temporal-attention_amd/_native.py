@@ -168,7 +168,7 @@ def _i64(a, name):
 OPTION_KEYS = ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim",
                "selector", "use_dropout", "prev2out", "ctx2out")
 
-KERNEL_CLASSES = ("spatial", "hproj", "lt_gemm", "temporal", "lstm", "prologue", "readout", "gemm_nn")
+KERNEL_CLASSES = ("spatial", "hproj", "lt_gemm", "temporal", "lstm", "prologue", "readout", "gemm_nn", "select")
 
 
 class Decoder(object):

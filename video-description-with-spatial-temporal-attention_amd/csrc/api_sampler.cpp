@@ -2,6 +2,8 @@
 // device for many videos at once (stattn_beam_search, :852-994).
 #include "steps.h"
 
+#include <memory>
+
 extern "C" {
 
 // ---- sampler ------------------------------------------------------------------------
@@ -426,6 +428,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             io.skip_hproj = true; io.sproj = proj; io.preh = proj + (size_t)4 * D; io.ldproj = 8 * D; io.h_out_pk = ho_pk;
         }
         CHK(run_step(h, io));
+        std::unique_ptr<Prof> pro(new Prof(h, KC_READOUT));        // readout + vocabulary launch (+ softmax) of this word
         if (small) {       // readout layer 1 + the next word's state projections (before the beam is re-ordered), then logits -> statistics
             PnArgs a{};
             a.M = M; a.nseg = 3;
@@ -485,6 +488,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             HIPCHK(h, launch_skinny(s, b));
             HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
         }
+        pro.reset();
+        Prof prs(h, KC_SELECT);                    // candidate selection + beam update of this word
         BeamArgs ba{};
         ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = d_step;
         ba.suppress_eos = suppress_eos;

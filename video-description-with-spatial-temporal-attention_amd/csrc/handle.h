@@ -43,7 +43,7 @@ struct DevBuf {
     void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
 };
 
-enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_COUNT };
+enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_SELECT, KC_COUNT };
 constexpr int KC_GEMM_SEQ = 16;      // the first 16 plain GEMM launches of a forward pass are also timed one by one
 constexpr int KC_BWD_SEQ = 24;       // every LDS-tiled GEMM launch of a backward pass, in launch order
 // kernels of one reverse-scan step and the deferred context-gradient kernel

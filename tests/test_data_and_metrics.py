@@ -130,3 +130,87 @@ def test_sample_files_match_oracle_beam_search(tmp_path):
     only_test = metrics.generate_sample_gpu_single_process('attention', None, opt, eng, model, f_init, f_next,
                                                            save_dir=str(tmp_path / 't'), beam=1, whichset='test')
     assert only_test[0] is None and len(only_test[1]) == 2 and not os.path.exists(str(tmp_path / 't' / 'valid_samples.txt'))
+
+
+# ------------------------------------------------------------------ the reference's training entry point (row b / f1)
+REF_TRAIN_KEYWORDS = ['random_seed', 'dim_word', 'ctxglm_dim', 'ctxg_dim', 'ctxl_dim', 'ctxm_dim', 'dim', 'n_layers_out', 'n_layers_init',
+                      'encoder', 'encoder_dim', 'prev2out', 'ctx2out', 'patience', 'max_epochs', 'dispFreq', 'decay_c', 'alpha_c',
+                      'alpha_entropy_r', 'lrate', 'selector', 'n_words', 'maxlen', 'optimizer', 'clip_c', 'batch_size',
+                      'valid_batch_size', 'save_model_dir', 'validFreq', 'saveFreq', 'sampleFreq', 'metric', 'dataset',
+                      'video_feature', 'use_dropout', 'reload_', 'from_dir', 'K', 'OutOf', 'verbose', 'debug']     # model_attention.py:1034-1076
+
+
+def _train_engine(n_vid=6, T=4, K=3, D=128, Fl=96, Fm=64):
+    rng = np.random.RandomState(3)
+    words = ['w%d' % i for i in range(2, 26)]
+    worddict = dict((w, i + 2) for i, w in enumerate(words))
+    feats, caps, tags = {}, {}, []
+    for v in range(n_vid):
+        vid = 'vid%d' % (v + 1)
+        feats[vid] = (rng.standard_normal((T, D)).astype(np.float32), rng.standard_normal((T, K, Fl)).astype(np.float32),
+                      rng.standard_normal((T, Fm)).astype(np.float32))
+        caps[vid] = [{'cap_id': str(c), 'tokenized': ' '.join(rng.choice(words, size=rng.randint(2, 6)))} for c in range(2)]
+        tags += ['%s_%d' % (vid, c) for c in range(2)]
+    return data_engine.MemoryEngine(feats, caps, worddict, n_words=30, maxlen=30, train=tags[:8], valid=tags[8:10], test=tags[10:],
+                                    mb_size_train=4, mb_size_test=2, train_ids=list(feats)[:4], valid_ids=list(feats)[4:5],
+                                    test_ids=list(feats)[5:])
+
+
+def test_train_keyword_surface_is_the_reference_s():
+    import inspect
+    from stattn import model_attention
+    sig = inspect.signature(model_attention.Attention.train_reference)
+    names = [n for n in sig.parameters if n != 'self']
+    assert names == REF_TRAIN_KEYWORDS + ['engine']
+    ref_defaults = dict(random_seed=1234, dim_word=256, dim=1000, n_layers_init=1, patience=10, max_epochs=5000, clip_c=2., batch_size=64,
+                        validFreq=10, optimizer='adadelta', use_dropout=False, debug=True, K=10, OutOf=240)
+    for k, v in ref_defaults.items():
+        assert sig.parameters[k].default == v, k
+    eng = _train_engine()
+    assert eng.kf_train == [[0, 1, 2, 3], [4, 5, 6, 7]] and eng.kf_valid == [[0, 1]] and eng.ctxglm_dim == 128
+    with pytest.raises(NotImplementedError):              # no engine: the h5 / pkl loader is out of scope, said loudly
+        model_attention.train_from_scratch({'attention': dict(dim=128)}, None)
+    with pytest.raises(TypeError):                        # unknown keywords are rejected like any Python call
+        model_attention.Attention().train(no_such_option=1)
+
+
+@pytest.mark.gpu
+def test_train_from_scratch_with_the_reference_config_block(tmp_path):
+    """train_model.py:82 -> model_attention.train_from_scratch(state, channel) -> Attention.train(**state.attention)
+    (model_attention.py:1558-1562) with config.py's keys (dims shrunk) and an injected MemoryEngine."""
+    from stattn import model_attention
+
+    class Channel(object):
+        saves = 0
+
+        def save(self):
+            Channel.saves += 1
+    save_dir = str(tmp_path) + os.sep
+    attention = dict(reload_=False, save_model_dir=save_dir, from_dir=None, dataset='youtube2text', video_feature='googlenet',
+                     dim_word=64, ctxglm_dim=-1, ctxg_dim=-1, ctxl_dim=-1, ctxm_dim=-1, dim=128, n_layers_out=1, n_layers_init=0,
+                     encoder_dim=300, prev2out=True, ctx2out=True, patience=20, max_epochs=4, decay_c=1e-4, alpha_entropy_r=0.,
+                     alpha_c=0.70602, lrate=0.0002, selector=True, n_words=30, maxlen=30, optimizer='adadelta', clip_c=10.,
+                     batch_size=4, valid_batch_size=2, dispFreq=10, validFreq=2, saveFreq=-1, sampleFreq=500, metric='everything',
+                     use_dropout=True, K=4, OutOf=None, verbose=False, debug=False)               # config.py:13-52
+    state = {'attention': attention, 'engine': _train_engine()}
+    train_err, valid_err, test_err = model_attention.train_from_scratch(state, Channel())
+    assert all(np.isfinite([train_err, valid_err, test_err])) and valid_err > 0 and test_err > 0
+    for f in ('model_options.pkl', 'model_current.npz', 'model_best.npz', 'train_valid_test.txt'):
+        assert os.path.isfile(save_dir + f), f
+    hist = np.loadtxt(save_dir + 'train_valid_test.txt')
+    assert hist.shape == (4, 22) and list(hist[:, 1]) == [2, 4, 6, 8]           # 8 updates, validated every 2; 22 columns (:1462-1469)
+    assert hist[-1, 2] < hist[0, 2]                                              # the train NLL went down
+    assert Channel.saves == 4
+    best = np.load(save_dir + 'model_best.npz')
+    assert {'train_err', 'valid_err', 'test_err', 'history_errs', 'Wemb', 'decoder_U', 'ff_logit_W'} <= set(best.files)
+    import pickle
+    mo = pickle.load(open(save_dir + 'model_options.pkl', 'rb'))
+    assert mo['dim'] == 128 and mo['alpha_c'] == 0.70602 and 'engine' not in mo
+    # reload_: continues from model_best_so_far.npz when the run produced one
+    if os.path.isfile(save_dir + 'model_best_so_far.npz'):
+        state['attention'].update(reload_=True, from_dir=str(tmp_path), max_epochs=1)
+        r2 = model_attention.train_from_scratch(state, None)
+        assert np.isfinite(r2[1])
+    # the reference's default debug=True: one update, no error passes
+    state['attention'].update(reload_=False, debug=True, max_epochs=3)
+    assert model_attention.train_from_scratch(state, None) == (-1, 0, 0)

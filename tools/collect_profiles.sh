@@ -6,6 +6,11 @@ r=$1
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out
+mkdir -p $o
+# HEAD the snapshot was taken from (written by the caller before gpurun: `git rev-parse HEAD > tools/.head`; .git does not travel)
+head=$(cat tools/.head 2>/dev/null || echo unknown)
+src=$(cat bench.py video-description-with-spatial-temporal-attention_amd/csrc/*.hip video-description-with-spatial-temporal-attention_amd/csrc/*.cpp video-description-with-spatial-temporal-attention_amd/csrc/*.h | sha256sum | cut -c1-16)
+echo "{\"round\": \"$r\", \"git_head\": \"$head\", \"sources_sha16\": \"$src\", \"collected\": \"$(date -u +%FT%TZ)\"}" > $o/${r}_STAMP.json
 python bench.py > $o/${r}_bench_c2_train.json 2> $o/${r}_bench_c2_train.err
 python bench.py --mode forward > $o/${r}_bench_c2_forward.json 2>> $o/${r}_bench.err
 python bench.py --config c2v20k --no-cpu-baseline > $o/${r}_bench_c2v20k_train.json 2>> $o/${r}_bench.err
@@ -23,4 +28,19 @@ for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
     tools/prof_pmc.sh ${r}_pmc_train $c python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split
 done
 tools/prof_pmc.sh ${r}_fetch_calibration FETCH_SIZE tools/bin/fetch_calib
+# stamp every collected file with the HEAD it was measured at
+for f in $o/${r}_*.csv; do sed -i "1i # git_head=$head sources_sha16=$src" $f; done
+for f in $o/${r}_*.json; do
+    [ -s $f ] && python - $f $head $src <<'PY'
+import json, sys
+p, head, src = sys.argv[1:4]
+try:
+    d = json.load(open(p))
+except Exception:
+    sys.exit(0)
+if isinstance(d, dict):
+    d["git_head"], d["sources_sha16"] = head, src
+    json.dump(d, open(p, "w"))
+PY
+done
 ls -la $o | grep ${r}_

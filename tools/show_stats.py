@@ -3,7 +3,7 @@
 import csv
 import sys
 
-rows = list(csv.DictReader(open(sys.argv[1])))
+rows = list(csv.DictReader(l for l in open(sys.argv[1]) if not l.startswith("#")))
 tot = sum(float(r['TotalDurationUs']) for r in rows)
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
 for r in rows[:n]:

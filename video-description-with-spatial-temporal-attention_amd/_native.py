@@ -99,19 +99,60 @@ EXPORTED_SYMBOLS = tuple(_SIGNATURES)
 DEBUG_SYMBOLS = tuple(_DBG_SIGNATURES)
 
 
+def _elf_dynamic_strings(path, tag):
+    """Values of the string-valued dynamic entries `tag` (1 = DT_NEEDED, 14 = DT_SONAME) of a 64-bit little-endian ELF
+    shared object; [] when the file is not one or cannot be parsed."""
+    import struct
+    try:
+        with open(path, "rb") as f:
+            data = f.read()
+        if data[:6] != b"\x7fELF\x02\x01":
+            return []
+        shoff, = struct.unpack_from("<Q", data, 0x28)
+        shentsize, shnum = struct.unpack_from("<HH", data, 0x3A)
+        secs = [struct.unpack_from("<IIQQQQIIQQ", data, shoff + i * shentsize) for i in range(shnum)]
+        out = []
+        for sec in secs:
+            if sec[1] != 6:                                   # SHT_DYNAMIC
+                continue
+            stroff = secs[sec[6]][4]                          # sh_link -> .dynstr
+            for o in range(sec[4], sec[4] + sec[5], 16):
+                t, v = struct.unpack_from("<qQ", data, o)
+                if t == 0:
+                    break
+                if t == tag:
+                    end = data.index(b"\0", stroff + v)
+                    out.append(data[stroff + v:end].decode())
+        return out
+    except Exception:
+        return []
+
+
+def _hip_runtimes_mapped():
+    """Distinct libamdhip64 files mapped into this process."""
+    try:
+        with open("/proc/self/maps") as f:
+            return sorted({os.path.realpath(l.split()[-1]) for l in f if "libamdhip64" in l and "/" in l})
+    except OSError:
+        return []
+
+
 def _one_hip_runtime():
     """One HIP runtime per process.  libstattn.so needs `libamdhip64.so.7`; torch ships its own copy under torch/lib
     and asks for it as `libamdhip64.so`, so whichever of the two libraries is loaded SECOND brings a second HIP + HSA
     runtime when libstattn came first (torch first is fine: its copy carries the soname libstattn asks for).  The
     second runtime cannot open the GPU again, and whatever binds to it -- torch.cuda, torch's RCCL -- finds no device.
     So when torch is installed (not necessarily imported) and no HIP runtime is loaded yet, torch's copy is loaded
-    first and libstattn binds to it."""
-    try:
-        with open("/proc/self/maps") as f:
-            if "libamdhip64" in f.read():
-                return
-    except OSError:
-        pass
+    first and libstattn binds to it -- but ONLY when that copy's SONAME is the very name libstattn's DT_NEEDED asks for
+    (a torch wheel built against another ROCm major would not satisfy the loader, and preloading it would CREATE the
+    two-runtime process this function exists to prevent).  STATTN_NO_HIP_PRELOAD=1 switches the preload off."""
+    if os.environ.get("STATTN_NO_HIP_PRELOAD"):
+        return
+    if _hip_runtimes_mapped():
+        return
+    needed = [n for n in _elf_dynamic_strings(library_path(), 1) if n.startswith("libamdhip64.so")]
+    if not needed:
+        return
     import importlib.util
     try:
         spec = importlib.util.find_spec("torch")
@@ -120,7 +161,7 @@ def _one_hip_runtime():
     if spec is None or not spec.origin:
         return
     cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
-    if os.path.exists(cand):
+    if os.path.exists(cand) and needed[0] in _elf_dynamic_strings(cand, 14):
         try:
             C.CDLL(cand, mode=C.RTLD_GLOBAL)
         except OSError:
@@ -138,6 +179,11 @@ def load_library():
                           "(or `make -C %s/csrc`).  stattn has no CPU fallback." % (path, _HERE))
     _one_hip_runtime()
     lib = C.CDLL(path)
+    mapped = _hip_runtimes_mapped()
+    if len(mapped) > 1:                    # two HIP + HSA runtimes: whatever binds to the second one finds no device
+        import warnings
+        warnings.warn("two HIP runtimes are mapped into this process (%s): import torch before stattn, or align the ROCm "
+                      "versions; RCCL / torch.cuda may report 'no ROCm-capable device'" % ", ".join(mapped), RuntimeWarning)
     for name, (res, args) in list(_SIGNATURES.items()) + list(_DBG_SIGNATURES.items()):
         fn = getattr(lib, name)            # AttributeError if the .so lacks a declared symbol
         fn.restype = res

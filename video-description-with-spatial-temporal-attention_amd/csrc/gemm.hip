@@ -425,7 +425,7 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, 
     if (n == 1) return launch_gemm(s, gs[0], tA, tB);
     {
         bool split = true;
-        for (int i = 0; i < n; ++i) split = split && gs[i].split && gemm_split_supported(gs[i], tA, tB);
+        for (int i = 0; i < n; ++i) split = split && gs[i].split && !gs[i].A2 && gemm_split_supported(gs[i], tA, tB);   // (the split kernels have no second operand pair)
         if (split) return launch_gemm_split_group(s, gs, n, tA, tB);
     }
     // Tile of a grouped launch.  64 x 64 is the default (13 tiles per CU on the biggest projection: no tail).  When every

@@ -8,6 +8,11 @@ the 8-tuple `x, x_mask, ctxg, ctxg_mask, ctxl, ctxl_mask, ctxm, ctxm_mask` that 
 are not part of the reference repository); `MemoryEngine` below stands in for it with features held in arrays."""
 import numpy
 
+try:
+    from .common import generate_minibatch_idx
+except ImportError:
+    from common import generate_minibatch_idx
+
 
 def ctx_mask(ctx, dim):
     """1.0 where a frame (or region) has any non-zero feature among its first `dim`, else 0.0 -- how the reference
@@ -87,7 +92,8 @@ class MemoryEngine(object):
     _filter_googlenet / _filter_rcnn / _filter_c3d (:39-60)."""
 
     def __init__(self, features, captions, worddict, n_words, maxlen=None, signature='youtube2text',
-                 train_ids=(), valid_ids=(), test_ids=(), n_frames=None):
+                 train_ids=(), valid_ids=(), test_ids=(), n_frames=None,
+                 train=(), valid=(), test=(), mb_size_train=None, mb_size_test=None):
         self.K = n_frames
         self.signature = signature
         self.CAP = captions
@@ -101,6 +107,13 @@ class MemoryEngine(object):
         g, l, m = next(iter(features.values()))
         self.ctxg_dim, self.ctxl_dim, self.ctxm_dim = g.shape[-1], l.shape[-1], m.shape[-1]
         self.train_ids, self.valid_ids, self.test_ids = list(train_ids), list(valid_ids), list(test_ids)
+        # what Attention.train / pred_probs walk (data_engine.py:225-227, 251-256): caption tags 'vid_cap' per split and
+        # their minibatch index lists; ctxglm_dim = ctxg_dim (the fused dimension, :247)
+        self.ctxglm_dim = self.ctxg_dim
+        self.train, self.valid, self.test = list(train), list(valid), list(test)
+        self.mb_size_train, self.mb_size_test = mb_size_train, mb_size_test
+        for name, tags, mb in (('train', self.train, mb_size_train), ('valid', self.valid, mb_size_test), ('test', self.test, mb_size_test)):
+            setattr(self, 'kf_' + name, generate_minibatch_idx(len(tags), min(mb, len(tags))) if tags and mb else [])
 
     def get_sub_frames(self, frames, jpegs=False):
         return frames if self.K is None else sub_frames(frames, self.K)

@@ -259,8 +259,138 @@ class Attention(object):
             dec.update(decay_c=decay_c, clip_c=clip_c)
         return f_grad_shared, f_update
 
-    def train(self, batches, options, valid_batches=None, max_epochs=1, decay_c=0., alpha_c=0., clip_c=0.,
-              patience=10, validFreq=-1, dispFreq=0, save_model_dir=None, reload_=False, from_dir=None, params=None):
+    def train(self, *args, **kwargs):
+        """Two call forms.
+        (1) The reference's: `model.train(**state.attention)` (model_attention.py:1034-1078, called from
+            train_from_scratch, :1558-1562) -- the keyword names and defaults of the reference, plus `engine=` to inject
+            the data engine (the h5 / pkl loader `data_engine.Movie2Caption` is out of scope: DESIGN.md section 13).
+            Returns (train_err, valid_err, test_err) like :1556.  See `train_reference`.
+        (2) `model.train(batches, options, ...)`: the loop over ready-made prepare_data() 8-tuples (`fit`)."""
+        if args or 'batches' in kwargs or 'options' in kwargs:
+            return self.fit(*args, **kwargs)
+        return self.train_reference(**kwargs)
+
+    def train_reference(self,
+                        random_seed=1234, dim_word=256, ctxglm_dim=-1, ctxg_dim=-1, ctxl_dim=-1, ctxm_dim=-1, dim=1000,
+                        n_layers_out=1, n_layers_init=1, encoder='none', encoder_dim=100, prev2out=False, ctx2out=False,
+                        patience=10, max_epochs=5000, dispFreq=100, decay_c=0., alpha_c=0., alpha_entropy_r=0., lrate=0.01,
+                        selector=False, n_words=100000, maxlen=100, optimizer='adadelta', clip_c=2., batch_size=64,
+                        valid_batch_size=64, save_model_dir='./', validFreq=10, saveFreq=10, sampleFreq=10, metric='blue',
+                        dataset='youtube2text', video_feature='googlenet', use_dropout=False, reload_=False, from_dir=None,
+                        K=10, OutOf=240, verbose=True, debug=True, engine=None):
+        """Attention.train with the reference's keyword surface (model_attention.py:1034-1557; names, defaults and
+        meaning as there, so config.py's `attention` block passes through unchanged).  What it keeps of the loop:
+        `model_options` = the keyword arguments (pickled to `<save_model_dir>model_options.pkl`, :1083-1084) with the
+        four feature dims taken from the engine (:1093-1096); reload from `<from_dir>/model_best_so_far.npz` (:1109-1113);
+        epochs over `engine.kf_train` with prepare_data per minibatch (:1239-1254), use_noise = 1, f_grad_shared +
+        f_update (:1259-1278), NaN check; every `validFreq` updates: model_current.npz, pred_probs on train / valid / test
+        with use_noise = 0 (:1392-1426), a `history_errs` row in the reference's 22-column layout (:1462-1469; the
+        caption-metric columns are 0 -- coco-caption scoring is out of scope), train_valid_test.txt, the reference's
+        best-model / early-stopping rule on column 6 (:1477-1499: nothing is saved at the first validation, exactly like
+        there); at the end the best parameters are put back (:1519-1520), valid / test errors recomputed and
+        model_best.npz written (:1543-1546).  `debug=True` (the reference's default!) stops after ONE update and
+        skips the error passes (:1504-1509, 1525).  `optimizer` must be 'adadelta' (the one the path implements;
+        `lrate` is ignored by it in the reference too, common.py:193).  sampleFreq printing and the caption metrics
+        are not reproduced.  `self.channel.save()` is called where the reference calls it."""
+        import os
+        import pickle as pkl
+        try:
+            from . import data_engine
+        except ImportError:
+            import data_engine
+        if optimizer != 'adadelta':
+            raise NotImplementedError("optimizer %r: the decoder path implements common.adadelta (config.py:34)" % (optimizer,))
+        if engine is None:
+            raise NotImplementedError("pass engine= (an object with the attributes of data_engine.Movie2Caption, e.g. "
+                                      "stattn.data_engine.MemoryEngine): the h5 / pkl feature loader is out of scope")
+        common.reset_rngs(random_seed)
+        model_options = dict(locals())
+        for k_ in ('self', 'engine', 'os', 'pkl', 'data_engine'):
+            model_options.pop(k_, None)
+        model_options = validate_options(model_options)
+        if save_model_dir and not os.path.isdir(save_model_dir):
+            os.makedirs(save_model_dir)
+        with open('%smodel_options.pkl' % save_model_dir, 'wb') as f:
+            pkl.dump(model_options, f)
+        self.engine = engine
+        for k_ in ('ctxglm_dim', 'ctxg_dim', 'ctxl_dim', 'ctxm_dim'):
+            model_options[k_] = getattr(engine, k_)
+        params = self.init_params(model_options)
+        if reload_:
+            saved = os.path.join(from_dir, 'model_best_so_far.npz')
+            assert os.path.isfile(saved)
+            params = common.load_params(saved, params)
+        tparams = self.init_tparams(params)
+        rv = self.build_model(tparams, model_options)
+        use_noise, inps, cost = rv[1], list(rv[2:10]), rv[14]
+        self.f_init, self.f_next = self.build_sampler(tparams, model_options, use_noise, rv[0])
+        f_log_probs = self.function(inps, -cost, tparams=tparams)
+        f_grad_shared, f_update = self.build_train_functions(tparams, model_options, decay_c, alpha_c, clip_c)
+        history_errs = []
+        if reload_:
+            history_errs = numpy.load(saved)['history_errs'].tolist()
+        best_p, bad_counter, uidx, estop = None, 0, 0, False
+        train_err = valid_err = test_err = -1
+        for eidx in range(max_epochs):
+            train_costs = []
+            for idx in engine.kf_train:
+                tags = [engine.train[i] for i in idx]
+                uidx += 1
+                use_noise.set_value(1.)
+                batch = data_engine.prepare_data(engine, tags)
+                if batch[0] is None:
+                    continue
+                c = f_grad_shared(*batch)[0]
+                if numpy.isnan(c) or numpy.isinf(c):
+                    raise FloatingPointError('NaN detected in cost')       # the reference drops into pdb (:1274-1276)
+                f_update(lrate)
+                train_costs.append(c)
+                if dispFreq and numpy.mod(uidx, dispFreq) == 0 and verbose:
+                    print('Epoch ', eidx, 'Update ', uidx, 'Train cost', c)
+                if validFreq != -1 and numpy.mod(uidx, validFreq) == 0:
+                    numpy.savez(save_model_dir + 'model_current.npz', history_errs=history_errs, **common.unzip(tparams))
+                    use_noise.set_value(0.)
+                    train_err = train_perp = valid_err = valid_perp = test_err = test_perp = -1
+                    if not debug:
+                        train_err, train_perp = self.pred_probs('train', f_log_probs, verbose=verbose)
+                        valid_err, valid_perp = self.pred_probs('valid', f_log_probs, verbose=verbose)
+                        test_err, test_perp = self.pred_probs('test', f_log_probs, verbose=verbose)
+                    history_errs.append([eidx, uidx, train_err, train_perp, valid_perp, test_perp, valid_err, test_err] + [0.] * 14)
+                    numpy.savetxt(save_model_dir + 'train_valid_test.txt', history_errs, fmt='%.3f')
+                    if len(history_errs) > 1 and valid_err < numpy.array(history_errs)[:-1, 6].min():
+                        best_p = common.unzip(tparams)
+                        bad_counter = 0
+                        numpy.savez(save_model_dir + 'model_best_so_far.npz', history_errs=history_errs, **best_p)
+                        with open('%smodel_options.pkl' % save_model_dir, 'wb') as f:
+                            pkl.dump(model_options, f)
+                    elif len(history_errs) > 1 and valid_err >= numpy.array(history_errs)[:-1, 6].min():
+                        bad_counter += 1
+                        if bad_counter > patience:
+                            estop = True
+                            break
+                    if self.channel:
+                        self.channel.save()
+                if debug:
+                    break
+            if estop or debug:
+                break
+        if best_p is not None:
+            common.zipp(best_p, tparams)
+        use_noise.set_value(0.)
+        valid_err = test_err = 0
+        if not debug:
+            valid_err, _ = self.pred_probs('valid', f_log_probs, verbose=verbose)
+            test_err, _ = self.pred_probs('test', f_log_probs, verbose=verbose)     # (commented out in the reference, :1530-1532)
+        final = best_p if best_p is not None else common.unzip(tparams)
+        numpy.savez(save_model_dir + 'model_best.npz', train_err=train_err, valid_err=valid_err, test_err=test_err,
+                    history_errs=history_errs, **final)
+        if history_errs != []:
+            numpy.savetxt(save_model_dir + 'train_valid_test.txt', numpy.asarray(history_errs), fmt='%.4f')
+        self.tparams = tparams
+        return train_err, valid_err, test_err
+
+    def fit(self, batches, options, valid_batches=None, max_epochs=1, decay_c=0., alpha_c=0., clip_c=0.,
+            patience=10, validFreq=-1, dispFreq=0, save_model_dir=None, reload_=False, from_dir=None, params=None):
         """Minimal counterpart of the optimisation loop of Attention.train (model_attention.py:1239-1517): epochs over
         `batches` (a re-iterable of prepare_data() 8-tuples, or a callable returning a fresh iterator per epoch), f_grad_shared + f_update per minibatch with use_noise = 1,
         validation NLL with use_noise = 0 (pred_probs), early stopping on it with `patience` (:1494-1503), and the
@@ -284,15 +414,22 @@ class Attention(object):
         # `batches` / `valid_batches`: a re-iterable (list, dataset object) or a callable returning a fresh iterator -- the
         # way to stream minibatches like the reference does (one prepare_data() 8-tuple alive at a time, :1250-1251).  A
         # one-shot generator cannot be replayed and holding all of it would keep every batch's features in host memory.
-        def replayable(src, what, uses):
+        def replayable(src, what):
             if callable(src):
                 return src
-            if iter(src) is src and uses > 1:
-                raise ValueError("%s is a one-shot generator but is needed %s: pass a list / re-iterable, or a callable "
-                                 "that returns a fresh iterator" % (what, "once per epoch" if what == 'batches' else "at every validation"))
-            return lambda: src
-        epoch_batches = replayable(batches, 'batches', max_epochs)
-        valid_iter = replayable(valid_batches, 'valid_batches', 2) if valid_batches is not None else None
+            if iter(src) is not src:
+                return lambda: src
+            used = [False]
+
+            def once():                 # a one-shot generator serves ONE pass; only a second pass is an error
+                if used[0]:
+                    raise ValueError("%s is a one-shot generator but is needed %s: pass a list / re-iterable, or a callable "
+                                     "that returns a fresh iterator" % (what, "once per epoch" if what == 'batches' else "at every validation"))
+                used[0] = True
+                return src
+            return once
+        epoch_batches = replayable(batches, 'batches')
+        valid_iter = replayable(valid_batches, 'valid_batches') if valid_batches is not None else None
         for eidx in range(max_epochs):
             for batch in epoch_batches():
                 if batch[0] is None:              # "Minibatch with zero sample under length" (:1252-1254)
@@ -348,9 +485,14 @@ class Attention(object):
         if dec is not None and stochastic and getattr(f_next, 'device_loop', False) and dec.precision != 'bf16':
             # ancestral sampling on the device as well (stattn_sample_search: Gumbel-max in the logits launch, no m x V
             # copy per word); `sample` is one flat word list and the score the summed probabilities, like :913-918
-            (sample, score), = dec.sample_search(ctxg_0[None], ctxg_mask[None], ctxl_0[None], ctxm_0[None], maxlen=maxlen)
-            (hh, cc), = dec.beam_final_state()
-            return sample, score, [hh], [cc]
+            try:
+                (sample, score), = dec.sample_search(ctxg_0[None], ctxg_mask[None], ctxl_0[None], ctxm_0[None], maxlen=maxlen)
+            except ValueError as e:                  # no row-panel path for this shape / STATTN_NO_PANELS: the host loop below
+                if 'row-panel' not in str(e):
+                    raise
+            else:
+                (hh, cc), = dec.beam_final_state()
+                return sample, score, [hh], [cc]
         if dec is not None and not stochastic and k <= 8 and getattr(f_next, 'device_loop', False):
             # the whole loop on the device (stattn_beam_search: hipGraph-captured word sequence, no per-word host
             # round trip); k = 1 is the greedy decode of :896-918
@@ -429,3 +571,21 @@ class Attention(object):
             nwords += float(numpy.asarray(batch[1]).sum())
         nll = numpy.concatenate(nll) if nll else numpy.zeros(0)
         return nll.mean(), 2 ** (nll.sum() / nwords / numpy.log(2))
+
+
+def train_from_scratch(state, channel):
+    """model_attention.py:1558-1562, the function train_model.py:82 calls: `state.attention` (config.py's block, any
+    mapping or attribute bag) goes to Attention.train as keyword arguments.  One key beyond the reference's:
+    `state.attention['engine']` (or `state.engine`) injects the data engine, because the h5 / pkl loader is out of scope."""
+    import time
+    t0 = time.time()
+    print('training an attention model')
+    model = Attention(channel)
+    kw = dict(state['attention'] if isinstance(state, dict) else state.attention)
+    if 'engine' not in kw:
+        eng = state.get('engine') if isinstance(state, dict) else getattr(state, 'engine', None)
+        if eng is not None:
+            kw['engine'] = eng
+    rv = model.train(**kw)
+    print('training time in total %.4f sec' % (time.time() - t0))
+    return rv

@@ -392,10 +392,15 @@ def test_hip_path_matches_committed_golden_vectors(stattn_mod, O):
 
 
 @pytest.mark.parametrize("M,N,K", [(64, 256, 128), (17, 48, 64), (33, 16, 32), (70, 96, 256), (160, 64, 512), (256, 32, 48), (320, 64, 256), (512, 32, 128),
-                                   (64, 8192, 1024), (64, 1024, 4096)])
+                                   (64, 8192, 1024), (64, 1024, 4096),
+                                   # the wide kernel (panelw.hip, > 64 rows, N % 32 == 0, K % 32 == 0): 1 .. 8 row blocks per workgroup,
+                                   # one and several row groups, the configs[4] shapes (160 rows)
+                                   (160, 8192, 1024), (160, 12032, 512), (160, 4096, 1536), (160, 512, 2048), (65, 6400, 64), (96, 6400, 96),
+                                   (128, 6400, 64), (192, 6400, 64), (224, 6400, 32), (256, 8192, 64), (250, 64, 256), (480, 96, 128)])
 def test_row_panel_gemm_matches_float64(stattn_mod, O, M, N, K):
     """panel.hip: every row in one workgroup, 16 / 32-column panels repacked in MFMA operand order -- all row-group
-    geometries (1..16 m-tiles), both tile widths, and the transposed-source packing of the reverse scan."""
+    geometries (1..16 m-tiles), both tile widths, and the transposed-source packing of the reverse scan; panelw.hip: the
+    32-column / 32x32x2-MFMA kernel that takes launches of more than 64 rows."""
     dec = _decoder(stattn_mod, O, SMALL, 1)[3]
     rng = np.random.RandomState(M + N + K)
     A = rng.uniform(-1, 1, (M, K)).astype(np.float32)

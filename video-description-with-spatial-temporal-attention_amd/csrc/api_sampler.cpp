@@ -382,10 +382,19 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     float *proj = nullptr, *proj_step = nullptr, *ho_pk = nullptr, *vstats = nullptr;
     int vtile = 0;
     PnArgs lgargs{};
-    if (small) {
-        CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
-        CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
-        HIPCHK(h, hipMemsetAsync(ho_pk, 0, packed_rows_floats(M, D) * sizeof(float), s));
+    // The vocabulary launch ends in the statistics epilogue (per row and column tile: max, sum exp, the k best logits) whenever
+    // the row-panel kernels run it: the logits are never stored and the softmax / top-k launches disappear.  Up to 16 rows
+    // panel.hip's kernel, beyond 64 rows the wide kernel (panelw.hip); in between (one row group of 16-column tiles, but more
+    // rows than a statistics pass per wave pays for) the logits are stored and the softmax + top-k launches run.
+    bool vocab_stats = small;
+    if (panels && !vocab_stats && !stochastic && h->opt.precision != 1) {
+        PnArgs probe{};
+        probe.M = M; probe.nseg = 1;
+        pn_seg_defaults(probe.seg[0]);
+        probe.seg[0].npairs = 1; probe.seg[0].p[0] = PnPair{a1_pk, E, pn.Wo, E, 1}; probe.seg[0].N = Vp;
+        vocab_stats = panel_wide_supported(probe);
+    }
+    if (vocab_stats) {
         // the logits launch (same arguments for every word)
         lgargs.M = M; lgargs.nseg = 1;
         PnSeg& so = lgargs.seg[0];
@@ -397,6 +406,11 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         vtile = Vp / panel_tile_cols(lgargs);
         CHK(getbuf_t(h, "bs_vstats", (size_t)M * vtile * PN_STATS_REC, &vstats));
         so.stats = vstats;
+    }
+    if (small) {
+        CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
+        CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
+        HIPCHK(h, hipMemsetAsync(ho_pk, 0, packed_rows_floats(M, D) * sizeof(float), s));
         // state projections of the first word from the initial states
         PnArgs a{};
         a.M = M; a.nseg = 2;
@@ -460,14 +474,18 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
             sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
             HIPCHK(h, launch_panel(s, a));
-            PnArgs b{};
-            b.M = M; b.nseg = 1;
-            PnSeg& so = b.seg[0];
-            pn_seg_defaults(so);
-            so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
-            so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
-            HIPCHK(h, launch_panel(s, b));
-            HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
+            if (vocab_stats) {
+                HIPCHK(h, launch_panel(s, lgargs));
+            } else {
+                PnArgs b{};
+                b.M = M; b.nseg = 1;
+                PnSeg& so = b.seg[0];
+                pn_seg_defaults(so);
+                so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
+                so.bias = w.bo; so.C = lg; so.ldc = Vp; so.N = Vp;
+                HIPCHK(h, launch_panel(s, b));
+                HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
+            }
         } else {
             SkArgs a{};
             a.M = M; a.nseg = 1;
@@ -499,9 +517,9 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
-        if (small) {
+        if (vocab_stats) {
             ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile; ba.tile_cols = Vp / vtile; ba.stochastic = stochastic;
-            ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D;
+            if (small) { ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D; }
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         }

@@ -202,6 +202,13 @@ struct LstmPnArgs {
     int M, D;
 };
 hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a);
+// panelw.hip: the same launches for 65 .. 2048 rows on 32-column blocks of v_mfma_f32_32x32x2 (launch_panel / launch_lstm_panel
+// route there when *_wide_supported; statistics records are then per 32 columns)
+bool panel_wide_supported(const PnArgs& a);
+bool lstm_panel_wide_supported(const LstmPnArgs& a);
+hipError_t launch_panel_wide(hipStream_t s, const PnArgs& a);
+hipError_t launch_lstm_panel_wide(hipStream_t s, const LstmPnArgs& a);
+int panel_wide_tile_cols();
 // dst (packed A layout, see panel.hip) = src [M][ld]; rows M .. roundup(M, 16) are zero filled
 hipError_t launch_pack_rows(hipStream_t s, const float* src, int ld, int M, int K, float* dst);
 size_t packed_rows_floats(int M, int K);

@@ -358,6 +358,7 @@ void pn_seg_defaults(PnSeg& s) {
 // column-tile width launch_panel uses for `a` (16, or 32 when that still fills the chip): what PnSeg::stats records are
 // counted in (N / width per row)
 int panel_tile_cols(const PnArgs& a) {
+    if (panel_wide_supported(a)) return panel_wide_tile_cols();
     int tiles = 0, min_steps = 1 << 30;
     const int kz = a.kz > 1 ? a.kz : 1;
     for (int i = 0; i < a.nseg; ++i) {
@@ -376,6 +377,7 @@ int panel_tile_cols(const PnArgs& a) {
 hipError_t launch_panel(hipStream_t s, const PnArgs& a) {
     if (a.M <= 0 || a.nseg <= 0) return hipSuccess;
     if (!panel_supported(a.M)) return hipErrorInvalidValue;
+    if (panel_wide_supported(a)) return launch_panel_wide(s, a);
     int tiles = 0;
     for (int i = 0; i < a.nseg; ++i) {
         const PnSeg& sg = a.seg[i];
@@ -435,6 +437,7 @@ hipError_t launch_lstm_panel(hipStream_t s, const LstmPnArgs& a) {
     if (!panel_supported(a.M) || a.D % 4 != 0 || a.npairs < 1 || a.npairs > 3) return hipErrorInvalidValue;
     for (int p = 0; p < a.npairs; ++p)
         if (a.p[p].K % 16 != 0 || a.p[p].lda % 4 != 0) return hipErrorInvalidValue;
+    if (lstm_panel_wide_supported(a)) return launch_lstm_panel_wide(s, a);
     int min_steps = 1 << 30, max_steps = 0;
     for (int p = 0; p < a.npairs; ++p) {
         const int st = a.p[p].K / 16;

@@ -5,6 +5,14 @@
 // of a launch, start skew, main-loop, reduction and epilogue durations (100 MHz wall clock) and the event time.
 #include "../video-description-with-spatial-temporal-attention_amd/csrc/panel.hip"
 
+namespace stattn {   // the wide-kernel entry points panel.hip links against (panelw.hip is not part of this probe: 64 rows never route there)
+bool panel_wide_supported(const PnArgs&) { return false; }
+bool lstm_panel_wide_supported(const LstmPnArgs&) { return false; }
+hipError_t launch_panel_wide(hipStream_t, const PnArgs&) { return hipErrorInvalidValue; }
+hipError_t launch_lstm_panel_wide(hipStream_t, const LstmPnArgs&) { return hipErrorInvalidValue; }
+int panel_wide_tile_cols() { return 32; }
+}
+
 #include <algorithm>
 #include <cstdlib>
 #include <cstdio>

@@ -162,6 +162,7 @@ void stattn_destroy(stattn_handle* h) {
     if (h->beam_gexec) (void)hipGraphExecDestroy(h->beam_gexec);
     if (h->beam_gexec8) (void)hipGraphExecDestroy(h->beam_gexec8);
     if (h->pin_io) (void)hipHostFree(h->pin_io);
+    if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_plan[0]) (void)hipHostFree(h->pin_plan[0]);
     if (h->pin_plan[1]) (void)hipHostFree(h->pin_plan[1]);
     for (hipEvent_t e : h->plan_ev) if (e) (void)hipEventDestroy(e);

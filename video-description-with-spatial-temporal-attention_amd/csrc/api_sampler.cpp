@@ -305,11 +305,14 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     float *hp, *cp, *ho, *co, *hd, *emb, *sproj, *preh, *dp, *al, *CL, *eg, *em, *elt, *plt, *ag, *am, *alt, *ctx, *a1, *lg, *pr,
           *score[2], *fin_score;
     CHK(getbuf_t(h, "bs_vid", (size_t)M, &vid));
-    CHK(getbuf_t(h, "bs_live", (size_t)nvid, &live_k)); CHK(getbuf_t(h, "bs_dead", (size_t)nvid, &dead_k));
-    CHK(getbuf_t(h, "bs_tok0", (size_t)M * L0, &tok[0])); CHK(getbuf_t(h, "bs_tok1", (size_t)M * L0, &tok[1]));
-    CHK(getbuf_t(h, "bs_fin_tok", (size_t)M * L0, &fin_tok)); CHK(getbuf_t(h, "bs_fin_len", (size_t)M, &fin_len));
-    CHK(getbuf_t(h, "bs_fin_score", (size_t)M, &fin_score));
-    CHK(getbuf_t(h, "bs_score0", (size_t)M, &score[0])); CHK(getbuf_t(h, "bs_score1", (size_t)M, &score[1]));
+    // everything the host reads back at the end lives in ONE block (one device -> host copy into pinned memory instead of seven
+    // pageable ones of ~20 us each): live_k, dead_k [nvid] | fin_len, fin_score, score0, score1 [M] | fin_tok, tok0, tok1 [M * L0]
+    const size_t res_words = (size_t)2 * nvid + (size_t)4 * M + (size_t)3 * M * L0;
+    int* res_blk;
+    CHK(getbuf_t(h, "bs_result", res_words, &res_blk));
+    live_k = res_blk; dead_k = live_k + nvid; fin_len = dead_k + nvid;
+    fin_score = reinterpret_cast<float*>(fin_len + M); score[0] = fin_score + M; score[1] = score[0] + M;
+    fin_tok = reinterpret_cast<int*>(score[1] + M); tok[0] = fin_tok + (size_t)M * L0; tok[1] = tok[0] + (size_t)M * L0;
     CHK(getbuf_t(h, "bs_next_w", (size_t)M, &next_w));
     int* d_step;
     CHK(getbuf_t(h, "bs_step", (size_t)1, &d_step));
@@ -331,24 +334,6 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     CHK(getbuf_t(h, "bs_ctx", (size_t)M * D, &ctx)); CHK(getbuf_t(h, "bs_a1", (size_t)M * E, &a1));
     CHK(getbuf_t(h, "bs_lg", (size_t)M * Vp, &lg)); CHK(getbuf_t(h, "bs_pr", (size_t)M * Vp, &pr));
 
-    // initial beam: one live hypothesis per video (row v*k), empty, score 0, next word -1 (:871-893)
-    {
-        std::vector<int> hv(M), one(nvid, 1);
-        std::vector<int64_t> nw(M, -1);
-        for (int i = 0; i < M; ++i) hv[i] = i / k;
-        HIPCHK(h, hipMemcpyAsync(vid, hv.data(), (size_t)M * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(live_k, one.data(), (size_t)nvid * 4, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipMemcpyAsync(next_w, nw.data(), (size_t)M * 8, hipMemcpyHostToDevice, s));
-        HIPCHK(h, hipStreamSynchronize(s));     // the host vectors go out of scope
-    }
-    HIPCHK(h, hipMemsetAsync(dead_k, 0, (size_t)nvid * 4, s));
-    HIPCHK(h, hipMemsetAsync(score[0], 0, (size_t)M * 4, s));
-    HIPCHK(h, hipMemsetAsync(hp, 0, (size_t)M * D * 4, s));
-    HIPCHK(h, hipMemsetAsync(cp, 0, (size_t)M * D * 4, s));
-    HIPCHK(h, hipMemcpy2DAsync(hp, (size_t)k * D * 4, h0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, hipMemcpy2DAsync(cp, (size_t)k * D * 4, c0, (size_t)D * 4, (size_t)D * 4, nvid, hipMemcpyDeviceToDevice, s));
-    HIPCHK(h, launch_fill(s, dp, 0.5f, (size_t)M * 3 * D));
-
     // one decoded word = a fixed sequence of 10 kernel launches whose arguments depend on the word index only through
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
     FwdPanels pn{};
@@ -360,9 +345,6 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         CHK(getbuf_t(h, "bs_hp_pk", packed_rows_floats(M, D), &hp_pk)); CHK(getbuf_t(h, "bs_ctx_pk", packed_rows_floats(M, D), &ctx_pk));
         CHK(getbuf_t(h, "bs_emb_pk", packed_rows_floats(M, E), &emb_pk)); CHK(getbuf_t(h, "bs_hd_pk", packed_rows_floats(M, D), &hd_pk));
         CHK(getbuf_t(h, "bs_a1_pk", packed_rows_floats(M, E), &a1_pk));
-        for (float* q : {ctx_pk, hd_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, D) * sizeof(float), s));
-        for (float* q : {emb_pk, a1_pk}) HIPCHK(h, hipMemsetAsync(q, 0, packed_rows_floats(M, E) * sizeof(float), s));
-        HIPCHK(h, launch_pack_rows(s, hp, D, M, D, hp_pk));          // initial states; later words: beam_update's gather
     }
     // Small batches (<= 16 rows: the reference's own evaluation decodes ONE video at a time, metrics.py:121-135) are
     // launch-latency bound -- each of the ten launches of a word costs 5-11 us however little it computes.  Their word is
@@ -410,7 +392,23 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     if (small) {
         CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
         CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
-        HIPCHK(h, hipMemsetAsync(ho_pk, 0, packed_rows_floats(M, D) * sizeof(float), s));
+    }
+    int* d_ticket;
+    CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
+    {   // the initial beam (one live, empty, zero-score hypothesis per video on row v * k, next word -1, :871-893), its states,
+        // the eval dropout multiplier, zeroed packed buffers, the zero embedding of the first word (:803-804), counters:
+        // ONE launch (beam.hip beam_init_kernel) instead of twenty memsets and small copies
+        BeamInitArgs bi{};
+        bi.nvid = nvid; bi.k = k; bi.D = D; bi.E = E;
+        bi.vid = vid; bi.live_k = live_k; bi.dead_k = dead_k; bi.next_w = next_w; bi.score0 = score[0];
+        bi.h0 = h0; bi.c0 = c0; bi.hp = hp; bi.cp = cp; bi.hp_pk = hp_pk; bi.dp = dp; bi.emb = emb;
+        bi.ticket = d_ticket; bi.step = d_step;
+        float* zs[5] = {ctx_pk, hd_pk, emb_pk, a1_pk, ho_pk};
+        const size_t zn[5] = {packed_rows_floats(M, D), packed_rows_floats(M, D), packed_rows_floats(M, E), packed_rows_floats(M, E), packed_rows_floats(M, D)};
+        for (int q = 0; q < 5; ++q) { bi.zero[q] = zs[q]; bi.zero_n[q] = zs[q] ? zn[q] : 0; }
+        HIPCHK(h, launch_beam_init(s, bi));
+    }
+    if (small) {
         // state projections of the first word from the initial states
         PnArgs a{};
         a.M = M; a.nseg = 2;
@@ -422,12 +420,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         }
         HIPCHK(h, launch_panel(s, a));
     }
-    // first word: no previous word, zero embedding (:803-804); afterwards beam_update writes the embedding of the
-    // word it selects (no lookup launch inside the loop)
-    HIPCHK(h, hipMemsetAsync(emb, 0, (size_t)M * E * sizeof(float), s));
-    int* d_ticket;
-    CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
-    HIPCHK(h, hipMemsetAsync(d_ticket, 0, sizeof(int), s));
+    // (first word: no previous word, zero embedding (:803-804), set by the init launch; afterwards beam_update writes the
+    // embedding of the word it selects -- no lookup launch inside the loop)
     auto enqueue_word = [&](int parity) -> int {
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
@@ -526,7 +520,6 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
-    HIPCHK(h, hipMemsetAsync(d_step, 0, sizeof(int), s));
 
     // The launch-bound inner loop is captured once as hipGraphs of EIGHT and of TWO words (even + odd parity alternate)
     // and replayed -- a replay costs 10-16 us of host / front-end time whatever it holds, so the long graph carries the
@@ -606,17 +599,21 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     if (rc_loop != STATTN_OK) return rc_loop;
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
-        std::vector<int> lv(nvid), dv(nvid), ftok((size_t)M * L0), flen(M), ltok((size_t)M * L0);
-        std::vector<float> fsc(M), lsc(M);
         const int fb = steps_run & 1;     // buffers written by the last executed step
-        HIPCHK(h, hipMemcpyAsync(lv.data(), live_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(dv.data(), dead_k, (size_t)nvid * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(ftok.data(), fin_tok, (size_t)M * L0 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(flen.data(), fin_len, (size_t)M * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(fsc.data(), fin_score, (size_t)M * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(ltok.data(), tok[fb], (size_t)M * L0 * 4, hipMemcpyDeviceToHost, s));
-        HIPCHK(h, hipMemcpyAsync(lsc.data(), score[fb], (size_t)M * 4, hipMemcpyDeviceToHost, s));
+        if (res_words * 4 > h->pin_res_bytes) {
+            if (h->pin_res) { (void)hipHostFree(h->pin_res); h->pin_res = nullptr; h->pin_res_bytes = 0; }
+            HIPCHK(h, hipHostMalloc(&h->pin_res, res_words * 4, hipHostMallocDefault));
+            h->pin_res_bytes = res_words * 4;
+        }
+        HIPCHK(h, hipMemcpyAsync(h->pin_res, res_blk, res_words * 4, hipMemcpyDeviceToHost, s));
         HIPCHK(h, hipStreamSynchronize(s));
+        const int* hr = static_cast<const int*>(h->pin_res);
+        std::vector<int> lv(hr, hr + nvid), dv(hr + nvid, hr + 2 * nvid);
+        const int* flen = hr + 2 * nvid;
+        const float* fsc = reinterpret_cast<const float*>(flen + M);
+        const float* lsc = fsc + M + (size_t)fb * M;
+        const int* ftok = reinterpret_cast<const int*>(fsc + 3 * (size_t)M);
+        const int* ltok = ftok + (size_t)(1 + fb) * M * L0;
         for (size_t i = 0; i < (size_t)M * L0; ++i) out_tokens[i] = -1;
         for (int v = 0; v < nvid; ++v) {
             int n = 0;

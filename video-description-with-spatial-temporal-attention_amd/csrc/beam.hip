@@ -368,6 +368,39 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     }
 }
 
+
+__global__ __launch_bounds__(256) void beam_init_kernel(const BeamInitArgs a) {
+    const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gsz = (size_t)gridDim.x * blockDim.x;
+    const int M = a.nvid * a.k, D = a.D;
+    if (gid < (size_t)M) {
+        const int i = (int)gid;
+        a.vid[i] = i / a.k;
+        a.next_w[i] = -1;
+        a.score0[i] = 0.f;
+    }
+    if (gid < (size_t)a.nvid) { a.live_k[gid] = 1; a.dead_k[gid] = 0; }
+    if (gid == 0) { *a.ticket = 0; *a.step = 0; }
+    for (size_t i = gid; i < (size_t)M * D; i += gsz) {
+        const int row = (int)(i / D), d = (int)(i - (size_t)row * D), v = row / a.k;
+        const bool first = row == v * a.k;
+        const float hv = first ? a.h0[(size_t)v * D + d] : 0.f, cv = first ? a.c0[(size_t)v * D + d] : 0.f;
+        a.hp[i] = hv; a.cp[i] = cv;
+        if (a.hp_pk) a.hp_pk[pn_pack_offset(row, d, D >> 4)] = hv;
+    }
+    if (a.hp_pk) {   // rows M .. roundup(M, 16) of the packed panel are read (and ignored) by the last m-tile: keep them finite
+        const int Mp = (M + 15) & ~15;
+        for (size_t i = gid; i < (size_t)(Mp - M) * D; i += gsz) {
+            const int row = M + (int)(i / D), d = (int)(i % D);
+            a.hp_pk[pn_pack_offset(row, d, D >> 4)] = 0.f;
+        }
+    }
+    for (size_t i = gid; i < (size_t)M * 3 * D; i += gsz) a.dp[i] = 0.5f;
+    if (a.emb) for (size_t i = gid; i < (size_t)M * a.E; i += gsz) a.emb[i] = 0.f;
+#pragma unroll
+    for (int q = 0; q < 6; ++q)
+        if (a.zero[q]) for (size_t i = gid; i < a.zero_n[q]; i += gsz) a.zero[q][i] = 0.f;
+}
+
 }  // namespace
 
 int beam_topk_splits(int nvid) {          // slices of the vocabulary per video: ~512 workgroups in all, <= 256 / KB
@@ -387,6 +420,17 @@ hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* par
     if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB || (a.stochastic && (a.k != 1 || a.tile_cols < 1)))) return hipErrorInvalidValue;
     if (a.proj_next && (!a.proj_step || a.nproj % 4)) return hipErrorInvalidValue;
     hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(a.stats ? 1024 : 256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
+    return hipGetLastError();
+}
+
+hipError_t launch_beam_init(hipStream_t s, const BeamInitArgs& a) {
+    if (a.nvid < 1 || a.k < 1 || !a.vid || !a.live_k || !a.dead_k || !a.next_w || !a.score0 || !a.h0 || !a.c0 || !a.hp || !a.cp || !a.dp ||
+        !a.ticket || !a.step) return hipErrorInvalidValue;
+    size_t n = (size_t)a.nvid * a.k * 3 * a.D;
+    for (int q = 0; q < 6; ++q) if (a.zero[q] && a.zero_n[q] > n) n = a.zero_n[q];
+    size_t blocks = (n + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(beam_init_kernel, dim3((unsigned)blocks), dim3(256), 0, s, a);
     return hipGetLastError();
 }
 

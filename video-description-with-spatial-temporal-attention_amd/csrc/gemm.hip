@@ -503,7 +503,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
             else if (ks > Kt / 512) ks = Kt / 512;
             // (a launch with an epilogue pays for it once more in the reduction: slices of at least 1024 -- measured on the
             // readout pair 1920 x 512 x 2048: 2 / 3 / 4 / 6 / 8 slices 55.5 / 55.9 / 57.4 / 58.9 / 61.9 us, unsplit 69.0)
-            if (epi && !fks && ks > Kt / 1024) ks = Kt / 1024;
+            // (a problem of a few dozen tiles -- one video's F -> D projection, 208 x 512 x 4096 -- is a latency chain per
+            // workgroup: slices of 512 there)
+            if (epi && !fks && ks > Kt / 1024 && t11 > 64) ks = Kt / 1024;
             if (ks > 32) ks = 32;
             while (ks > 1 && (size_t)ks * g.M * g.N > g.ws_floats) --ks;
             if (ks > 1 && (g.M * (size_t)g.N) % 4 == 0 && g.ldc % 4 == 0 && g.N % 4 == 0) {

@@ -123,6 +123,7 @@ struct stattn_handle {
     // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
     // ~15 us); sn_m / sn_dp / sn_vid remember that the constant step inputs (video index, eval dropout) are in place
     void* pin_io = nullptr; size_t pin_io_bytes = 0;
+    void* pin_res = nullptr; size_t pin_res_bytes = 0;      // pinned landing block of a beam search's results
     int sn_m = -1; const void* sn_dp = nullptr; const void* sn_vid = nullptr;
     uint64_t host_rng = 0x853c49e6748fea9bull;
     // batched beam search: raw features staged by stattn_beam_stage (or the last call that passed host features)

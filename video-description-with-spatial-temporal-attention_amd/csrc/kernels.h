@@ -410,6 +410,22 @@ hipError_t launch_adadelta(hipStream_t s, float* p, const float* g, float* rg2, 
 // ----------------------------------------------------------------------------
 // batched device-side beam search (beam.hip)
 // ----------------------------------------------------------------------------
+// Everything stattn_beam_search initialises before the first word, in ONE launch (it was ~20 memsets / small copies of
+// 4-5 us each plus the gaps between them: a quarter of a per-video decode call): the initial beam (one live, empty, zero-score
+// hypothesis per video on row v * k, next word -1, :871-893), its states (row v * k = h0 / c0 of the video, other rows 0), the
+// eval dropout multiplier 0.5, zeroed packed activation buffers, the packed initial states, the zero embedding of the first
+// word (:803-804), and the word counter / ticket.  Any pointer may be null (buffer not in use).
+struct BeamInitArgs {
+    int nvid, k, D, E;
+    int* vid; int* live_k; int* dead_k; int64_t* next_w; float* score0;
+    const float* h0; const float* c0; float* hp; float* cp; float* hp_pk;
+    float* dp;                                   // [M, 3D] <- 0.5
+    float* zero[6]; size_t zero_n[6];            // buffers to clear (floats)
+    float* emb;                                  // [M, E] <- 0
+    int* ticket; int* step;
+};
+hipError_t launch_beam_init(hipStream_t s, const BeamInitArgs& a);
+
 struct BeamArgs {
     const float* probs; int ldp;        // [nvid*k, ldp] next-word probabilities of this step
     int V, k, D, maxlen, nvid, suppress_eos;

@@ -125,21 +125,29 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         PN_STAMP(3);
         return;
     }
+    // the segment's fields, read once: `a.seg[si]` is indexed dynamically, and left inside the loop every field is an s_load
+    // from the kernel-argument segment per iteration whose s_waitcnt lgkmcnt(0) also drains the LDS reads (panelw.hip)
+    const float* const bias = sg.bias; const float* const bias2 = sg.bias2;
+    const float* const add = sg.add; const float* const mul = sg.mul;
+    float* const Cp = sg.C; float* const Cpk = sg.Cpk;
+    const int ldadd = sg.ldadd, ldmul = sg.ldmul, ldc = sg.ldc, act = sg.act, Spk = sg.N >> 4, M = a.M;
+    const float scale = sg.scale;
+    const size_t pstride = a.part_stride;
     for (int idx = tid; idx < RB * CB; idx += blockDim.x) {
         const int row = idx / CB, col = idx % CB;
-        if (row >= a.M) continue;
+        if (row >= M) continue;
         float v = 0.f;
         for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + col];
         const int n = n0 + col;
-        if (kz > 1) { sg.C[(size_t)blockIdx.y * a.part_stride + (size_t)row * sg.ldc + n] = v; continue; }
-        if (sg.bias) v += sg.bias[n];
-        if (sg.bias2) v += sg.bias2[n];
-        if (sg.add) v += sg.add[(size_t)row * sg.ldadd + n];
-        if (sg.act == 1) v = fast_tanh(v);
-        v *= sg.scale;
-        if (sg.mul) v *= sg.mul[(size_t)row * sg.ldmul + n];
-        sg.C[(size_t)row * sg.ldc + n] = v;
-        if (sg.Cpk) sg.Cpk[pn_pack_offset(row, n, sg.N >> 4)] = v;
+        if (kz > 1) { Cp[(size_t)blockIdx.y * pstride + (size_t)row * ldc + n] = v; continue; }
+        if (bias) v += bias[n];
+        if (bias2) v += bias2[n];
+        if (add) v += add[(size_t)row * ldadd + n];
+        if (act == 1) v = fast_tanh(v);
+        v *= scale;
+        if (mul) v *= mul[(size_t)row * ldmul + n];
+        Cp[(size_t)row * ldc + n] = v;
+        if (Cpk) Cpk[pn_pack_offset(row, n, Spk)] = v;
     }
     PN_STAMP(3);
 }

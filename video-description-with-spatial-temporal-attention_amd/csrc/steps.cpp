@@ -151,7 +151,22 @@ int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, c
         g.A = ctxg; g.lda = D; g.B = w.Wcg; g.ldb = D; g.C = c.PG; g.ldc = D; g.M = nv * T; g.N = D; g.K = D; g.bias = w.bg;
     }
     if (extra) g1[n1++] = *extra;
-    CHK(gemm_group(h, g1, n1));
+    // A handful of videos (per-video decode, metrics.py:121-135: ONE video = 208 region rows at configs[0]): the F -> D
+    // projections are a few dozen tiles with K = 4096 -- in the grouped launch 48 workgroups walk 128 k-tiles each (98 us, a
+    // fifth of the set-up of a decode call).  Cut along K instead: the split-K path of launch_gemm (partial tiles in a
+    // workspace, summed in a fixed order by the reduction that applies the bias / tanh epilogue).
+    const size_t region_rows = (size_t)nv * T * K;
+    if (region_rows <= 1024 && h->opt.precision == 0 && !extra) {
+        const size_t ws_floats = (size_t)8 * region_rows * D;
+        float* ws;
+        CHK(getbuf_t(h, "pc_ws", ws_floats, &ws));
+        for (int i = 0; i < n1; ++i) {
+            if (g1[i].K >= 2048) { g1[i].ws = ws; g1[i].ws_floats = ws_floats; }
+            HIPCHK(h, gemm_nn(h, g1[i]));
+        }
+    } else {
+        CHK(gemm_group(h, g1, n1));
+    }
     {   // pctxl_ (:324)
         GemmArgs& g = g2[n2++];
         gemm_defaults(g); g.split = h->opt.precision != 0;

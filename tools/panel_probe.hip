@@ -75,7 +75,7 @@ int main() {
     CK(launch_pack_rows(0, h, D, M, D, hpk)); CK(launch_pack_rows(0, ctx, D, M, D, ctxpk));
     const int apk = getenv("PN_UNPACKED_A") ? 0 : 1;
     PnArgs pa{};
-    pa.M = M; pa.nseg = 2;
+    pa.M = M; pa.nseg = getenv("PN_ONE_SEG") ? 1 : 2;     // 1: the product's launch since round 3 (h.U rides in the attention launch)
     pn_seg_defaults(pa.seg[0]); pa.seg[0].npairs = 1; pa.seg[0].p[0] = PnPair{apk ? hpk : h, D, pWd, D, apk}; pa.seg[0].C = sproj; pa.seg[0].ldc = 4 * D; pa.seg[0].N = 4 * D;
     pn_seg_defaults(pa.seg[1]); pa.seg[1].npairs = 1; pa.seg[1].p[0] = PnPair{apk ? hpk : h, D, pU, D, apk}; pa.seg[1].C = preh; pa.seg[1].ldc = 4 * D; pa.seg[1].N = 4 * D;
     pa.seg[1].add = xproj; pa.seg[1].ldadd = 4 * D;

@@ -167,6 +167,26 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         __shared__ float s_lse[KB];
         __shared__ float s_m[16][KB], s_s[16][KB];
         const int live = live0, nt = a.ntile, lane = tid & 63, w = tid >> 6;
+        // The first four candidates of every thread (all of them up to 4096: every greedy / beam-5 single-video step) are
+        // requested BEFORE the log-sum-exp pass: their addresses do not depend on it, only their cost does, so the two passes
+        // over the records are one memory round trip instead of two dependent ones.
+        const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
+        const int C = live * per;
+        float pv[4]; int pi[4], pj[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int e = u * NT + tid;
+            pv[u] = -INFINITY; pi[u] = 0x7fffffff; pj[u] = 0;
+            if (e < C) {
+                const int j = e / per, rem = e - j * per, t = rem / nsel, i = rem - t * nsel;
+                const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
+                pv[u] = rec[2 + i];                                            // (stochastic: the tile's best PERTURBED value)
+                pi[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i];
+                pj[u] = j;
+            }
+        }
+        __shared__ float s_hyp[KB];
+        if (tid < live) s_hyp[tid] = a.hyp_score[v * k + tid];
         // Rows in parallel when there are waves enough (1024 threads): wave w takes row w % live and every (nwv / live)-th group
         // of 64 tiles of it -- one load latency for all rows instead of one per row; else row after row over all threads.
         const int nwv_ = NT >> 6, wpr = nwv_ / live;              // waves per row (0: fewer waves than rows)
@@ -201,11 +221,12 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         float lc[KB]; int li[KB];
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
-        const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
-        // one flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they are
-        // inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
-        const int C = live * per;
-        for (int c0 = 0; c0 < C; c0 += 4 * NT) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+            if (pv[u] > -INFINITY) list_insert(lc, li, (a.stochastic ? 0.f : s_hyp[pj[u]] + s_lse[pj[u]]) - pv[u], pi[u]);
+        // the rest of the flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they
+        // are inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
+        for (int c0 = 4 * NT; c0 < C; c0 += 4 * NT) {
             float cv[4]; int ci[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
@@ -215,7 +236,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
                     const int j = e / per, rem = e - j * per, t = rem / nsel, i = rem - t * nsel;
                     const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
                     const float val = rec[2 + i];                              // (stochastic: the tile's best PERTURBED value)
-                    const float base = a.stochastic ? 0.f : a.hyp_score[v * k + j] + s_lse[j];
+                    const float base = a.stochastic ? 0.f : s_hyp[j] + s_lse[j];
                     if (val > -INFINITY) { cv[u] = base - val; ci[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i]; }
                 }
             }

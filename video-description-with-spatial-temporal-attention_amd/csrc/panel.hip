@@ -75,6 +75,17 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         const int nsteps = pr.K >> 4;
         const size_t tile_floats = (size_t)nsteps * 256;
         const float* Bp = pr.P + (size_t)tg * NT * tile_floats + 4 * lane;
+#if defined(STATTN_PROBES) && PN_VARIANT == 6
+        // tools/panel_probe.hip, VERDICT r03 item 3(a): what the main loop costs when the workgroup's weight slice is ALREADY in
+        // LDS (a persistent kernel would keep it there across the decoder steps): the slice is copied in before the timed part
+        {
+            float* wl = red + (size_t)KS * RB * CB;
+            for (size_t i = tid; i < tile_floats * NT / 4; i += blockDim.x) st4(wl + 4 * i, ld4(pr.P + (size_t)tg * NT * tile_floats + 4 * i));
+            __syncthreads();
+            PN_STAMP(0);
+            Bp = wl + 4 * lane;
+        }
+#endif
         pn_accumulate<MT, NT, R, ONESHOT>(acc, Ap, astep, Bp, tile_floats, nsteps, (int)blockIdx.y * KS + ks, KS * kz,
                                           pn_rotation((int)blockIdx.x, nsteps));
     }
@@ -414,7 +425,10 @@ hipError_t launch_panel(hipStream_t s, const PnArgs& a) {
     if (stats && (q.MG != 1 || kz != 1)) return hipErrorInvalidValue;      // every row in one row group, no K split over blocks
     for (int i = 0; i < a.nseg; ++i)
         if (a.seg[i].stats && (a.seg[i].stats_kb < 1 || a.seg[i].stats_kb > PN_STATS_KB)) return hipErrorInvalidValue;
-    const size_t lds = ((size_t)q.KS + (stats ? 1 : 0)) * q.MG * q.MT * 16 * CB * sizeof(float);
+    size_t lds = ((size_t)q.KS + (stats ? 1 : 0)) * q.MG * q.MT * 16 * CB * sizeof(float);
+#if defined(STATTN_PROBES) && PN_VARIANT == 6
+    lds += (size_t)max_steps * kz * 256 * (nt2 ? 2 : 1) * sizeof(float);       // the workgroup's weight slice (tools/panel_probe.hip)
+#endif
 #define STATTN_PN_LAUNCH1(MT_, NT_, MAXT_, R_, OS_)                                                         \
     do {                                                                                                    \
         hipError_t e_ = pn_allow_lds(panel_kernel<MT_, NT_, MAXT_, R_, OS_>, lds);                          \

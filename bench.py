@@ -240,14 +240,17 @@ def leg_decode_c1(args, local):
                 dec.beam_search(f["ctxg"][i:i + 1], f["mask_ctxg"][i:i + 1], f["ctxl"][i:i + 1], f["ctxm"][i:i + 1], k=k, maxlen=t, suppress_eos=True)
         one_pass()
         dec.sync()
-        reps = 5
-        t0 = time.perf_counter()
-        for _ in range(reps):
-            one_pass()
-        dec.sync()
-        dt = time.perf_counter() - t0
-        rs = c["B"] * (1 + k * (t - 1)) * reps
-        out["k%d" % k] = dict(value=rs / dt, ms_per_video=dt / reps / c["B"] * 1e3, graph_replays_per_video=dec.beam_graph_replays())
+        reps = 7
+        passes = []
+        for _ in range(reps):                 # every pass timed on its own (synchronised): the leg reports the MEDIAN pass, and the
+            t1 = time.perf_counter()          # mean and the slowest beside it -- one host hiccup (a garbage-collection pause that frees
+            one_pass()                        # another decoder's device buffers, 40 ms) otherwise decides a 36 ms measurement
+            dec.sync()
+            passes.append(time.perf_counter() - t1)
+        dt = float(np.median(passes))
+        rs = c["B"] * (1 + k * (t - 1))
+        out["k%d" % k] = dict(value=rs / dt, ms_per_video=dt / c["B"] * 1e3, graph_replays_per_video=dec.beam_graph_replays(),
+                              passes=reps, ms_per_video_mean=float(np.mean(passes)) / c["B"] * 1e3, ms_per_video_max=float(np.max(passes)) / c["B"] * 1e3)
     # the word loop alone, on one resident video, k = 1 and k = 5
     dec.beam_stage(f["ctxg"][:1], f["mask_ctxg"][:1], f["ctxl"][:1], f["ctxm"][:1])
     nslab = 3 if dec.lt_mode == 1 else 2
@@ -298,11 +301,13 @@ def leg_beam_c5(args, local, params):
     dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
     dec.sync()
     reps = 5
-    t0 = time.perf_counter()
-    for _ in range(reps):
+    calls = []
+    for _ in range(reps):                     # (median call, like decode_c1)
+        t1 = time.perf_counter()
         dec.beam_search(k=k, maxlen=t, suppress_eos=True, resident=True)
-    dec.sync()
-    dt = time.perf_counter() - t0
+        dec.sync()
+        calls.append(time.perf_counter() - t1)
+    dt = float(np.median(calls)) * reps
     replays = dec.beam_graph_replays()
     M = nv * k
     rs = nv * (1 + k * (t - 1))
@@ -327,7 +332,8 @@ def leg_beam_c5(args, local, params):
     rec_ms = kms["hproj"][0] + kms["lstm"][0]
     out = dict(workload="c5 beam: batched device beam search, %d videos x beam %d, maxlen %d, <eos> suppressed, T=%d K=%d feat=%d hidden=%d E=%d "
                         "vocab=%d, inputs resident in HBM, the F->D projections redone in every call" % (nv, k, t, T, K, F, D, E, c["V"]),
-               value=rs * reps / dt, unit="row-steps/s", ms_per_call=dt / reps * 1e3, graph_replays=replays, us_per_word=us,
+               value=rs * reps / dt, unit="row-steps/s", ms_per_call=dt / reps * 1e3, ms_per_call_mean=float(np.mean(calls)) * 1e3,
+               ms_per_call_max=float(np.max(calls)) * 1e3, graph_replays=replays, us_per_word=us,
                value_word_loop_only=M * 1e6 / us, projections_ms_per_call=kms["prologue"][0],
                roofline_hbm=hbm("spatial_shared_kernel<%d>" % k, sp_bytes, kms["spatial"][0]),
                recurrent_gemms=mfma("160-row state projections h.[Wd*|U] + LSTM [ctx|emb].[Wc|W] (2 launches per word)", rec_flops, rec_ms),
@@ -992,6 +998,8 @@ def main():
     legs = (train and args.config == "c2" and world == 1 and args.h2d == "none" and args.precision == "fp32" and not args.no_legs
             and not os.environ.get("STATTN_BENCH_CHILD"))
     if legs:
+        import gc
+        gc.collect()                      # (the split-precision decoder above and its buffers go now, not inside a leg's timed loop)
         # measured in the SAME run, never as `value`: the train step with the minibatch crossing PCIe on every step, the
         # reference's own per-video decode loop (configs[0]) and the long-context beam search (configs[4])
         core = dp.DataParallelStep(dec, global_batch=c["B"], alpha_c=0.70602, decay_c=1e-4, clip_c=10.0)

@@ -21,11 +21,12 @@ python bench.py --mode beam --config c1 --beam 1 --steps 50 --warmup 3 > $o/${r}
 python bench.py --mode beam --config c1 --beam 5 --steps 50 --warmup 3 > $o/${r}_bench_c1_beam5.json 2>> $o/${r}_bench.err
 python bench.py --mode decode --config c1 --steps 5 --warmup 1 > $o/${r}_bench_c1_decode.json 2>> $o/${r}_bench.err
 python bench.py --mode decode --config c1 --beam 5 --steps 5 --warmup 1 --no-cpu-baseline > $o/${r}_bench_c1_decode_beam5.json 2>> $o/${r}_bench.err
-tools/prof_trace.sh ${r}_trace_c2_train --steps 5 --warmup 1 --no-cpu-baseline --no-split
+tools/prof_trace.sh ${r}_trace_c2_train --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-legs
 tools/prof_trace.sh ${r}_trace_c5_beam --mode beam --config c5 --steps 3 --warmup 1
 tools/prof_trace.sh ${r}_trace_c1_beam1 --mode beam --config c1 --beam 1 --steps 20 --warmup 2
+tools/prof_trace.sh ${r}_trace_c1_decode --mode decode --config c1 --steps 5 --warmup 1 --no-cpu-baseline
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
-    tools/prof_pmc.sh ${r}_pmc_train $c python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split
+    tools/prof_pmc.sh ${r}_pmc_train $c python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-legs --no-live-pmc
 done
 tools/prof_pmc.sh ${r}_fetch_calibration FETCH_SIZE tools/bin/fetch_calib
 # stamp every collected file with the HEAD it was measured at

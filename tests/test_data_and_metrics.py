@@ -175,7 +175,7 @@ def test_train_keyword_surface_is_the_reference_s():
 
 
 @pytest.mark.gpu
-def test_train_from_scratch_with_the_reference_config_block(tmp_path):
+def test_train_from_scratch_with_the_reference_config_block(tmp_path, capsys):
     """train_model.py:82 -> model_attention.train_from_scratch(state, channel) -> Attention.train(**state.attention)
     (model_attention.py:1558-1562) with config.py's keys (dims shrunk) and an injected MemoryEngine."""
     from stattn import model_attention
@@ -190,17 +190,20 @@ def test_train_from_scratch_with_the_reference_config_block(tmp_path):
                      dim_word=64, ctxglm_dim=-1, ctxg_dim=-1, ctxl_dim=-1, ctxm_dim=-1, dim=128, n_layers_out=1, n_layers_init=0,
                      encoder_dim=300, prev2out=True, ctx2out=True, patience=20, max_epochs=4, decay_c=1e-4, alpha_entropy_r=0.,
                      alpha_c=0.70602, lrate=0.0002, selector=True, n_words=30, maxlen=30, optimizer='adadelta', clip_c=10.,
-                     batch_size=4, valid_batch_size=2, dispFreq=10, validFreq=2, saveFreq=-1, sampleFreq=500, metric='everything',
-                     use_dropout=True, K=4, OutOf=None, verbose=False, debug=False)               # config.py:13-52
+                     batch_size=4, valid_batch_size=2, dispFreq=4, validFreq=2, saveFreq=-1, sampleFreq=4, metric='everything',
+                     use_dropout=True, K=4, OutOf=None, verbose=True, debug=False)               # config.py:13-52
     state = {'attention': attention, 'engine': _train_engine()}
     train_err, valid_err, test_err = model_attention.train_from_scratch(state, Channel())
     assert all(np.isfinite([train_err, valid_err, test_err])) and valid_err > 0 and test_err > 0
-    for f in ('model_options.pkl', 'model_current.npz', 'model_best.npz', 'train_valid_test.txt'):
+    logged = capsys.readouterr().out
+    assert 'alphalt ratio' in logged and 'sampling from valid' in logged and logged.count('Truth ') >= 8 and 'Sample ( 0 )' in logged
+    for f in ('model_options.pkl', 'model_current.npz', 'model_best.npz', 'train_valid_test.txt', 'alphal_ratio.txt', 'alphalt_ratio.txt'):
         assert os.path.isfile(save_dir + f), f
     hist = np.loadtxt(save_dir + 'train_valid_test.txt')
     assert hist.shape == (4, 22) and list(hist[:, 1]) == [2, 4, 6, 8]           # 8 updates, validated every 2; 22 columns (:1462-1469)
     assert hist[-1, 2] < hist[0, 2]                                              # the train NLL went down
     assert Channel.saves == 4
+    assert np.loadtxt(save_dir + 'alphag_ratio.txt').shape == (4,)
     best = np.load(save_dir + 'model_best.npz')
     assert {'train_err', 'valid_err', 'test_err', 'history_errs', 'Wemb', 'decoder_U', 'ff_logit_W'} <= set(best.files)
     import pickle

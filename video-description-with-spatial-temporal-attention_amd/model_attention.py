@@ -290,8 +290,10 @@ class Attention(object):
         there); at the end the best parameters are put back (:1519-1520), valid / test errors recomputed and
         model_best.npz written (:1543-1546).  `debug=True` (the reference's default!) stops after ONE update and
         skips the error passes (:1504-1509, 1525).  `optimizer` must be 'adadelta' (the one the path implements;
-        `lrate` is ignored by it in the reference too, common.py:193).  sampleFreq printing and the caption metrics
-        are not reproduced.  `self.channel.save()` is called where the reference calls it."""
+        `lrate` is ignored by it in the reference too, common.py:193).  With `verbose`, every `dispFreq` updates the four
+        attention min / max ratios and regulariser values are printed (:1291-1306) and every `sampleFreq` updates beam-5 captions of
+        up to ten training and validation videos next to their ground truth (:1312-1368); every validation appends the ratios to
+        `alpha{l,g,m,lt}_ratio.txt` (:1372-1390).  The caption metrics (coco-caption) are not reproduced.  `self.channel.save()` is called where the reference calls it."""
         import os
         import pickle as pkl
         try:
@@ -325,12 +327,46 @@ class Attention(object):
         use_noise, inps, cost = rv[1], list(rv[2:10]), rv[14]
         self.f_init, self.f_next = self.build_sampler(tparams, model_options, use_noise, rv[0])
         f_log_probs = self.function(inps, -cost, tparams=tparams)
+        # f_alphal / f_alphag / f_alpham / f_alphalt (:1167-1188): [alphas, alpha_c * mean_{T(,K)} sum_b (1 - sum_t alpha)^2]
+        f_alphas = self.function(inps, [rv[10], rv[11], rv[12], rv[13]], tparams=tparams)
+
+        def alpha_ratios(batch):
+            """min / max attention-weight ratio and regulariser value per attention, as logged at :1291-1306 and :1372-1390"""
+            out = []
+            for al in f_alphas(*batch):
+                reg = alpha_c * float(((1. - al.sum(0)) ** 2).sum(0).mean()) if alpha_c > 0. else 0.
+                out.append((float(al.min(-1).mean() / al.max(-1).mean()), reg))
+            return out
+
+        def words(seq):                                              # ids up to the first <eos> (0), unknown ids as UNK
+            out = []
+            for w in seq:
+                if int(w) == 0:
+                    break
+                out.append(engine.word_idict.get(int(w), 'UNK'))
+            return ' '.join(out)
+
+        def sample_execute(from_which, batch):                      # :1312-1368
+            print('------------- sampling from %s ----------' % from_which)
+            if from_which == 'valid' and len(engine.kf_valid) > 2:
+                idx = engine.kf_valid[numpy.random.randint(1, len(engine.kf_valid) - 1)]
+                batch = data_engine.prepare_data(engine, [engine.valid[i] for i in idx])
+            x_s, _, g_s, gm_s, l_s, lm_s, m_s, mm_s = batch
+            for jj in range(min(10, x_s.shape[1])):
+                sample, score, _, _ = self.gen_sample(tparams, self.f_init, self.f_next, g_s[jj], gm_s[jj], l_s[jj], lm_s[jj], m_s[jj],
+                                                      mm_s[jj], model_options, trng=rv[0], k=5, maxlen=30, stochastic=False)
+                best = int(numpy.argmin(score))
+                print('cost', score[best])
+                print('Truth ', jj, ': ', words(x_s[:, jj]))
+                print('Sample ( 0 ) ', jj, ': ', words(sample[best]))
+
         f_grad_shared, f_update = self.build_train_functions(tparams, model_options, decay_c, alpha_c, clip_c)
         history_errs = []
         if reload_:
             history_errs = numpy.load(saved)['history_errs'].tolist()
         best_p, bad_counter, uidx, estop = None, 0, 0, False
         train_err = valid_err = test_err = -1
+        ratio_log = [[], [], [], []]
         for eidx in range(max_epochs):
             train_costs = []
             for idx in engine.kf_train:
@@ -347,7 +383,17 @@ class Attention(object):
                 train_costs.append(c)
                 if dispFreq and numpy.mod(uidx, dispFreq) == 0 and verbose:
                     print('Epoch ', eidx, 'Update ', uidx, 'Train cost', c)
+                    for name, (ratio, reg) in zip(('alphal', 'alphag', 'alpham', 'alphalt'), alpha_ratios(batch)):
+                        print('%s ratio %.3f, reg %.3f' % (name, ratio, reg))
+                if sampleFreq and sampleFreq > 0 and numpy.mod(uidx, sampleFreq) == 0 and verbose:
+                    use_noise.set_value(0.)
+                    sample_execute('train', batch)
+                    sample_execute('valid', batch)
                 if validFreq != -1 and numpy.mod(uidx, validFreq) == 0:
+                    use_noise.set_value(0.)
+                    for lst, name, (ratio, _) in zip(ratio_log, ('alphal', 'alphag', 'alpham', 'alphalt'), alpha_ratios(batch)):
+                        lst.append(ratio)                     # (:1372-1390; the reference appends alphag's ratio to alpham's log)
+                        numpy.savetxt(save_model_dir + '%s_ratio.txt' % name, lst)
                     numpy.savez(save_model_dir + 'model_current.npz', history_errs=history_errs, **common.unzip(tparams))
                     use_noise.set_value(0.)
                     train_err = train_perp = valid_err = valid_perp = test_err = test_perp = -1

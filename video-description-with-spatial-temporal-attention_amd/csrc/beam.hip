@@ -12,6 +12,14 @@
 
 namespace stattn {
 
+#ifdef STATTN_PROBES
+// timeline of beam_update_kernel (make PROBES=1; tools/beam_probe.py): workgroup 0, thread 0 stamps the 100 MHz wall clock
+__device__ long long* bm_probe = nullptr;
+#define BM_STAMP(i) do { if (bm_probe && threadIdx.x == 0 && blockIdx.x == 0) bm_probe[i] = __builtin_amdgcn_s_memrealtime(); } while (0)
+#else
+#define BM_STAMP(i) do {} while (0)
+#endif
+
 namespace {
 
 constexpr int KB = 8;   // maximum beam width
@@ -48,19 +56,33 @@ __device__ __forceinline__ void block_select(float (&lc)[KB], int (&li)[KB], int
     }
 }
 
+// (cost, flat index) as ONE 64-bit key whose unsigned order is cand_less's order: the cost's bits made monotone (sign flip),
+// the index below them -- a wave-wide arg-min is then a min over one value (two 32-bit shuffles per step instead of three, no
+// owner lane to carry: indices are unique, the winner is whoever holds the minimum)
+__device__ __forceinline__ unsigned long long cand_key(float c, int i) {
+    unsigned u = __float_as_uint(c);
+    u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+    return ((unsigned long long)u << 32) | (unsigned)i;
+}
+__device__ __forceinline__ float key_cost(unsigned long long key) {
+    unsigned u = (unsigned)(key >> 32);
+    u = (u & 0x80000000u) ? (u & 0x7fffffffu) : ~u;
+    return __uint_as_float(u);
+}
+__device__ __forceinline__ unsigned long long wave_min_key(unsigned long long k) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long other = __shfl_xor(k, o, 64); k = other < k ? other : k; }
+    return k;
+}
+
 // The same selection with ONE workgroup barrier instead of 2 n: every wave first selects its own n best (n rounds of a
 // wave-wide arg-min, no barrier), then wave 0 merges the <= 16 n wave winners.  s_c / s_i: [16 * KB] each.
 __device__ __forceinline__ void block_select2(float (&lc)[KB], int (&li)[KB], int n, float* s_c, int* s_i, float* res_c, int* res_i) {
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6, nwv = (int)blockDim.x >> 6;
     for (int r = 0; r < n; ++r) {
-        float c = lc[0]; int idx = li[0]; int owner = lane;
-#pragma unroll
-        for (int o = 32; o > 0; o >>= 1) {
-            const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
-            if (cand_less(oc, oi, c, idx)) { c = oc; idx = oi; owner = oo; }
-        }
-        if (lane == 0) { s_c[w * KB + r] = c; s_i[w * KB + r] = idx; }
-        if (lane == owner) {
+        const unsigned long long mine = cand_key(lc[0], li[0]), best = wave_min_key(mine);
+        if (lane == 0) { s_c[w * KB + r] = key_cost(best); s_i[w * KB + r] = (int)(unsigned)best; }
+        if (mine == best) {                                    // (several lanes only when every list is exhausted: sentinels)
 #pragma unroll
             for (int i = 0; i < KB - 1; ++i) { lc[i] = lc[i + 1]; li[i] = li[i + 1]; }
             lc[KB - 1] = INFINITY; li[KB - 1] = 0x7fffffff;
@@ -68,24 +90,18 @@ __device__ __forceinline__ void block_select2(float (&lc)[KB], int (&li)[KB], in
     }
     __syncthreads();
     if (w == 0) {
-        float mc[2]; int mi[2];
+        unsigned long long mk[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const int e = lane + 64 * u;                       // candidate e = (wave e / n, rank e % n)
             const bool in = e < nwv * n;
-            mc[u] = in ? s_c[(e / n) * KB + e % n] : INFINITY;
-            mi[u] = in ? s_i[(e / n) * KB + e % n] : 0x7fffffff;
+            mk[u] = in ? cand_key(s_c[(e / n) * KB + e % n], s_i[(e / n) * KB + e % n]) : cand_key(INFINITY, 0x7fffffff);
         }
-        if (cand_less(mc[1], mi[1], mc[0], mi[0])) { const float tc = mc[0]; mc[0] = mc[1]; mc[1] = tc; const int ti = mi[0]; mi[0] = mi[1]; mi[1] = ti; }
+        if (mk[1] < mk[0]) { const unsigned long long t = mk[0]; mk[0] = mk[1]; mk[1] = t; }
         for (int r = 0; r < n; ++r) {
-            float c = mc[0]; int idx = mi[0]; int owner = lane;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) {
-                const float oc = __shfl_xor(c, o, 64); const int oi = __shfl_xor(idx, o, 64); const int oo = __shfl_xor(owner, o, 64);
-                if (cand_less(oc, oi, c, idx)) { c = oc; idx = oi; owner = oo; }
-            }
-            if (lane == 0) { res_c[r] = c; res_i[r] = idx; }
-            if (lane == owner) { mc[0] = mc[1]; mi[0] = mi[1]; mc[1] = INFINITY; mi[1] = 0x7fffffff; }
+            const unsigned long long best = wave_min_key(mk[0]);
+            if (lane == 0) { res_c[r] = key_cost(best); res_i[r] = (int)(unsigned)best; }
+            if (mk[0] == best) { mk[0] = mk[1]; mk[1] = cand_key(INFINITY, 0x7fffffff); }
         }
     }
     __syncthreads();
@@ -157,9 +173,11 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     __shared__ float res_c[KB];
     __shared__ int res_i[KB];
     const int v = blockIdx.x, tid = threadIdx.x, NT = blockDim.x;
+    BM_STAMP(0);
     const int k = a.k, D = a.D, L = a.maxlen, V = a.V, step = *a.step;
     const int live0 = a.live_k[v], dead0 = a.dead_k[v];
     const int nsel = live0 > 0 ? k - dead0 : 0;                // how many candidates survive (:923)
+    BM_STAMP(1);
     if (nsel > 0 && a.stats) {
         // Small-batch decode: no probabilities were materialised.  The logits launch left, per (row, vocabulary tile),
         // the tile max, sum exp(v - max) and its best values; here: log-sum-exp per live row, then
@@ -218,6 +236,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
             s_lse[tid] = m + logf(ssum);
         }
         __syncthreads();
+        BM_STAMP(2);
         float lc[KB]; int li[KB];
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
@@ -244,7 +263,9 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
             for (int u = 0; u < 4; ++u)
                 if (ci[u] != 0x7fffffff) list_insert(lc, li, cv[u], ci[u]);
         }
+        BM_STAMP(3);
         block_select2(lc, li, nsel, s_c2, s_i2, res_c, res_i);
+        BM_STAMP(4);
         if (a.stochastic && tid == 0 && res_i[0] != 0x7fffffff) {
             // the draw is word res_i[0]; gen_sample's stochastic "score" is the running SUM of the drawn words'
             // probabilities (model_attention.py:916): p = exp(v - lse) with v the unperturbed logit kept by the tile
@@ -299,6 +320,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         }
     }
     __syncthreads();
+    BM_STAMP(5);
     const int n = s_n;
     // Copies of the n surviving candidates: tokens, then -- for the ones that stay live -- the parent's state, the next
     // step's state projections, the packed h and the embedding of the chosen word.  One flat index space per field over ALL
@@ -380,13 +402,19 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         const size_t base = (size_t)v * k * D;
         for (int i = tid; i < s_rows * D; i += NT) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
     }
+    BM_STAMP(6);
     // Advance the word counter.  Every workgroup read *a.step when it started; the LAST one to get here (a ticket)
     // knows all of them did, so it may write step + 1 for the next word's kernels (was a one-thread launch of its own).
     __syncthreads();
     if (tid == 0) {
-        __threadfence();
-        if (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) { *a.ticket = 0; *a.step = step + 1; }
+        if (gridDim.x == 1) {                      // one video: this workgroup is the last by construction
+            *a.step = step + 1;
+        } else {
+            __threadfence();
+            if (atomicAdd(a.ticket, 1) == (int)gridDim.x - 1) { *a.ticket = 0; *a.step = step + 1; }
+        }
     }
+    BM_STAMP(7);
 }
 
 
@@ -456,3 +484,16 @@ hipError_t launch_beam_init(hipStream_t s, const BeamInitArgs& a) {
 }
 
 }  // namespace stattn
+
+#ifdef STATTN_PROBES
+extern "C" int stattn_probe_beam(long long* out8) {      // first call (out8 = null): arm; later: read the eight stamps
+    static long long* d = nullptr;
+    if (!d) {
+        if (hipMalloc(&d, 8 * sizeof(long long)) != hipSuccess) return -1;
+        (void)hipMemset(d, 0, 8 * sizeof(long long));
+        if (hipMemcpyToSymbol(HIP_SYMBOL(stattn::bm_probe), &d, sizeof d) != hipSuccess) return -2;
+    }
+    if (out8) { (void)hipDeviceSynchronize(); if (hipMemcpy(out8, d, 8 * sizeof(long long), hipMemcpyDeviceToHost) != hipSuccess) return -3; }
+    return 0;
+}
+#endif

@@ -379,6 +379,11 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     if (vocab_stats) {
         // the logits launch (same arguments for every word)
         lgargs.M = M; lgargs.nseg = 1;
+        // Small-batch decode re-reads the same ~45 MB of weights every word; per XCD that is 5.5 MB through a 4 MB L2, so nothing
+        // survives from word to word.  The vocabulary matrix is more than half of it: loaded with the non-temporal policy it no
+        // longer displaces the rest, which then hits L2 in the other launches of the next word (configs[0]: 48.0 -> 45.5 us per
+        // word).  STATTN_LOGITS_NT=0: default policy (A/B).  (Non-temporal loads on EVERY weight stream were slower: DESIGN.md.)
+        { static const char* ntl = getenv("STATTN_LOGITS_NT"); lgargs.stream_b = (small && !(ntl && ntl[0] == '0')) ? 1 : 0; }
         PnSeg& so = lgargs.seg[0];
         pn_seg_defaults(so);
         so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};

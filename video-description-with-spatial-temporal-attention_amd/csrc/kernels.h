@@ -186,6 +186,7 @@ constexpr int PN_STATS_REC = 2 + 2 * PN_STATS_KB;
 struct PnArgs {
     PnSeg seg[6]; int nseg; int M;
     int kz; size_t part_stride;        // K split over gridDim.y: raw partial tiles to C + z * part_stride, no epilogue
+    int stream_b;                      // weights loaded with the non-temporal policy (a matrix that should not displace the others in L2)
 };
 void pn_seg_defaults(PnSeg& s);
 bool panel_supported(int M);

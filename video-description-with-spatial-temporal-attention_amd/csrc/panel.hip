@@ -87,7 +87,7 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         }
 #endif
         pn_accumulate<MT, NT, R, ONESHOT>(acc, Ap, astep, Bp, tile_floats, nsteps, (int)blockIdx.y * KS + ks, KS * kz,
-                                          pn_rotation((int)blockIdx.x, nsteps));
+                                          pn_rotation((int)blockIdx.x, nsteps), a.stream_b != 0);
     }
     PN_STAMP(1);
     pn_spill<MT, NT>(red, RB, ks, mg, acc, j, g);

@@ -24,12 +24,18 @@ struct PnOps { float4 a[MT]; float4 b[NT]; };
 // s = logical k-step; the physical one is rotated by `rot` (see pn_rotation)
 template <int MT, int NT>
 __device__ __forceinline__ void pn_load(PnOps<MT, NT>& o, const float* const (&Ap)[MT], int astep, const float* __restrict__ Bp,
-                                        size_t tile_floats, int s, int rot, int nsteps) {
+                                        size_t tile_floats, int s, int rot, int nsteps, bool stream_b = false) {
     s += rot;
     s = s >= nsteps ? s - nsteps : s;
 #if !(defined(STATTN_PROBES) && (PN_VARIANT == 4 || PN_VARIANT == 5))
 #pragma unroll
-    for (int i = 0; i < NT; ++i) o.b[i] = ld4(Bp + (size_t)i * tile_floats + (size_t)s * 256);
+    for (int i = 0; i < NT; ++i) {
+        if (stream_b) {
+            typedef float v4f __attribute__((ext_vector_type(4)));
+            const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(Bp + (size_t)i * tile_floats + (size_t)s * 256));
+            o.b[i] = make_float4(t.x, t.y, t.z, t.w);
+        } else o.b[i] = ld4(Bp + (size_t)i * tile_floats + (size_t)s * 256);
+    }
 #endif
 #if defined(STATTN_PROBES) && (PN_VARIANT == 3 || PN_VARIANT == 5)
     return;
@@ -66,13 +72,14 @@ __device__ __forceinline__ void pn_mfma(f32x4 (&acc)[MT][NT], const PnOps<MT, NT
 // steps) compiles the refills out.
 template <int MT, int NT, int R, bool ONESHOT>
 __device__ __forceinline__ void pn_accumulate(f32x4 (&acc)[MT][NT], const float* const (&Ap)[MT], int astep,
-                                              const float* __restrict__ Bp, size_t tile_floats, int nsteps, int s0, int stride, int rot) {
+                                              const float* __restrict__ Bp, size_t tile_floats, int nsteps, int s0, int stride, int rot,
+                                              bool stream_b = false) {
     if (s0 >= nsteps) return;
     const int n = (nsteps - s0 + stride - 1) / stride;         // steps of this wave
     const int last = s0 + (n - 1) * stride;
     PnOps<MT, NT> ring[R];
 #pragma unroll
-    for (int u = 0; u < R; ++u) pn_load(ring[u], Ap, astep, Bp, tile_floats, min(s0 + u * stride, last), rot, nsteps);
+    for (int u = 0; u < R; ++u) pn_load(ring[u], Ap, astep, Bp, tile_floats, min(s0 + u * stride, last), rot, nsteps, stream_b);
     int base = 0;
     if (!ONESHOT) {
         for (; base + 2 * R <= n; base += R) {   // groups whose refills are all real; no branch between loads and MFMAs
@@ -82,7 +89,7 @@ __device__ __forceinline__ void pn_accumulate(f32x4 (&acc)[MT][NT], const float*
                 __builtin_amdgcn_sched_barrier(0);
                 pn_mfma(acc, ring[u]);
                 __builtin_amdgcn_sched_barrier(0);
-                pn_load(ring[u], Ap, astep, Bp, tile_floats, sb + (u + R) * stride, rot, nsteps);
+                pn_load(ring[u], Ap, astep, Bp, tile_floats, sb + (u + R) * stride, rot, nsteps, stream_b);
             }
         }
         if (base + R < n) {                      // one more refilling group when a partial group follows (clamped refills)
@@ -92,7 +99,7 @@ __device__ __forceinline__ void pn_accumulate(f32x4 (&acc)[MT][NT], const float*
                 __builtin_amdgcn_sched_barrier(0);
                 pn_mfma(acc, ring[u]);
                 __builtin_amdgcn_sched_barrier(0);
-                pn_load(ring[u], Ap, astep, Bp, tile_floats, min(sb + (u + R) * stride, last), rot, nsteps);
+                pn_load(ring[u], Ap, astep, Bp, tile_floats, min(sb + (u + R) * stride, last), rot, nsteps, stream_b);
             }
             base += R;
         }

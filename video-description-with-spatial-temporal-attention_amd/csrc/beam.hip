@@ -24,6 +24,17 @@ namespace {
 
 constexpr int KB = 8;   // maximum beam width
 
+// n / d for 0 <= n < 2^22 and a workgroup-uniform d >= 1, through the float reciprocal (rd = 1.0f / d) and one correction step:
+// exact, six instructions instead of the ~40 of an integer division.  beam_update is ONE workgroup per video -- its 16 waves share
+// the issue slots of a single CU, so its time is its instruction count (tools/beam_probe.py), and the flat (row, tile, rank) /
+// (row, column) index splits were most of it.
+__device__ __forceinline__ int fdiv(int n, int d, float rd) {
+    int q = (int)((float)n * rd);
+    q -= (q * d > n);
+    q += ((q + 1) * d <= n);
+    return q;
+}
+
 // ordering of candidates: cost ascending, ties by the lower flat index (what a stable argsort of the flat cost
 // array yields, :921-923)
 __device__ __forceinline__ bool cand_less(float c0, int i0, float c1, int i1) { return c0 < c1 || (c0 == c1 && i0 < i1); }
@@ -190,13 +201,14 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         // over the records are one memory round trip instead of two dependent ones.
         const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
         const int C = live * per;
+        const float r_per = 1.0f / (float)per, r_nsel = 1.0f / (float)nsel;
         float pv[4]; int pi[4], pj[4];
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             const int e = u * NT + tid;
             pv[u] = -INFINITY; pi[u] = 0x7fffffff; pj[u] = 0;
             if (e < C) {
-                const int j = e / per, rem = e - j * per, t = rem / nsel, i = rem - t * nsel;
+                const int j = fdiv(e, per, r_per), rem = e - j * per, t = fdiv(rem, nsel, r_nsel), i = rem - t * nsel;
                 const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
                 pv[u] = rec[2 + i];                                            // (stochastic: the tile's best PERTURBED value)
                 pi[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i];
@@ -252,7 +264,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
                 const int e = c0 + u * NT + tid;
                 cv[u] = INFINITY; ci[u] = 0x7fffffff;
                 if (e < C) {
-                    const int j = e / per, rem = e - j * per, t = rem / nsel, i = rem - t * nsel;
+                    const int j = fdiv(e, per, r_per), rem = e - j * per, t = fdiv(rem, nsel, r_nsel), i = rem - t * nsel;
                     const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
                     const float val = rec[2 + i];                              // (stochastic: the tile's best PERTURBED value)
                     const float base = a.stochastic ? 0.f : s_hyp[j] + s_lse[j];
@@ -326,8 +338,9 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     // step's state projections, the packed h and the embedding of the chosen word.  One flat index space per field over ALL
     // candidates: the loads of every row are in flight together.  (A loop over the candidates around per-row loops was a
     // chain of n x 5 dependent read -> write round trips: 50 us of a 93 us word at k = 5.)
+    const float r_step = 1.0f / (float)(step > 0 ? step : 1), r_D = 1.0f / (float)D;
     for (int i = tid; i < n * step; i += NT) {
-        const int r = i / step, j = i - r * step;
+        const int r = fdiv(i, step, r_step), j = i - r * step;
         const int* __restrict__ src = a.tok_in + (size_t)(v * k + s_ti[r]) * L;
         int* __restrict__ dst = (s_fin[r] ? a.fin_tok : a.tok_out) + (size_t)(v * k + s_slot[r]) * L;
         dst[j] = src[j];
@@ -340,7 +353,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         for (int u = 0; u < 4; ++u) {
             const int i = i0 + u * NT;
             on[u] = i < n * D;
-            const int r = on[u] ? i / D : 0, d = on[u] ? i - r * D : 0;
+            const int r = on[u] ? fdiv(i, D, r_D) : 0, d = on[u] ? i - r * D : 0;
             on[u] = on[u] && !s_fin[r];
             rr[u] = r; dd[u] = d;
             const size_t so = (size_t)(v * k + s_ti[r]) * D + d;
@@ -356,6 +369,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     }
     if (a.proj_next) {   // the next step's state projections travel with the hypothesis (linear in h: gathered, not recomputed)
         const int np4 = a.nproj >> 2;
+        const float r_np4 = 1.0f / (float)np4;
         for (int i0 = tid; i0 < n * np4; i0 += 4 * NT) {
             float4 pv[4]; float4* dst[4];
 #pragma unroll
@@ -363,7 +377,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
                 const int i = i0 + u * NT;
                 dst[u] = nullptr;
                 if (i < n * np4) {
-                    const int r = i / np4, d4 = i - r * np4;
+                    const int r = fdiv(i, np4, r_np4), d4 = i - r * np4;
                     if (!s_fin[r]) {
                         pv[u] = reinterpret_cast<const float4*>(a.proj_step + (size_t)(v * k + s_ti[r]) * a.nproj)[d4];
                         dst[u] = reinterpret_cast<float4*>(a.proj_next + (size_t)(v * k + s_slot[r]) * a.nproj) + d4;
@@ -377,13 +391,14 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     // the embedding of the word just chosen = the input of the hypothesis' next step (:803-804): written here, so the
     // word loop needs no separate lookup launch
     if (a.emb_next) {
+        const float r_E = 1.0f / (float)a.E;
         for (int i0 = tid; i0 < n * a.E; i0 += 4 * NT) {
             float xv[4]; int rr[4], ee[4]; bool on[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int i = i0 + u * NT;
                 on[u] = i < n * a.E;
-                const int r = on[u] ? i / a.E : 0, e = on[u] ? i - r * a.E : 0;
+                const int r = on[u] ? fdiv(i, a.E, r_E) : 0, e = on[u] ? i - r * a.E : 0;
                 on[u] = on[u] && !s_fin[r];
                 rr[u] = r; ee[u] = e;
                 xv[u] = on[u] ? a.Wemb[(size_t)s_wi[r] * a.E + e] : 0.f;

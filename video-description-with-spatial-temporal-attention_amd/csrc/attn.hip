@@ -455,7 +455,7 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         for (int d4 = lane; d4 < nd4; d4 += 64) {
             float4 x[8];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) x[kk] = ld4(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
+            for (int kk = 0; kk < 8; ++kk) x[kk] = ld4_nt(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
             const float4 u4 = ld4(a.Ul + 4 * d4);
             usum += (u4.x + u4.y) + (u4.z + u4.w);
             const float4 m2u = make_float4(-2.f * u4.x, -2.f * u4.y, -2.f * u4.z, -2.f * u4.w);
@@ -525,8 +525,8 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
 #pragma unroll
             for (int kk = 0; kk < RG; ++kk) {
                 const int k = min(k0 + kk, K - 1);
-                l[kk] = ld4(L + (size_t)k * D + 4 * d4);
-                q[kk] = LW ? ld4(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                l[kk] = ld4_nt(L + (size_t)k * D + 4 * d4);
+                q[kk] = LW ? ld4_nt(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         };
         rows(l4, q4, 0);

@@ -47,6 +47,12 @@ __device__ __forceinline__ int xcd_rows(int n, int rows, int per_row) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ void st4(float* p, float4 v) { *reinterpret_cast<float4*>(p) = v; }
+// a stream that must not displace what other kernels re-read from the caches (non-temporal policy)
+__device__ __forceinline__ float4 ld4_nt(const float* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t = __builtin_nontemporal_load(reinterpret_cast<const v4f*>(p));
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 
 // counter-based generator (splitmix64 finaliser): u in (0, 1) from (seed, a, b), and the Gumbel(0, 1) variate -log(-log u)
 __device__ __forceinline__ unsigned long long mix64_dev(unsigned long long z) {

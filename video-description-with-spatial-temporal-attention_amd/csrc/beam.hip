@@ -238,23 +238,30 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
             if (wpr && lane == 0)                      // the other rows' slots of this wave: neutral elements
                 for (int o = 0; o < live; ++o) if (o != j) { s_m[w][o] = -INFINITY; s_s[w][o] = 0.f; }
         }
-        __syncthreads();
-        if (tid < live) {
+        // One live row: its log-sum-exp shifts every candidate's cost by the same amount, so the selection does not wait for it --
+        // the waves' partials are combined after the selection (whose barriers publish them) and added to the winners' costs.
+        const bool one = live == 1;
+        const float hyp0 = a.hyp_score[v * k];
+        auto row_lse = [&](int j) {
             const int nwv = NT >> 6;
             float m = -INFINITY;
-            for (int q = 0; q < nwv; ++q) m = fmaxf(m, s_m[q][tid]);
+            for (int q = 0; q < nwv; ++q) m = fmaxf(m, s_m[q][j]);
             float ssum = 0.f;
-            for (int q = 0; q < nwv; ++q) if (s_m[q][tid] > -INFINITY) ssum += s_s[q][tid] * __expf(s_m[q][tid] - m);
-            s_lse[tid] = m + logf(ssum);
+            for (int q = 0; q < nwv; ++q) if (s_m[q][j] > -INFINITY) ssum += s_s[q][j] * __expf(s_m[q][j] - m);
+            return m + logf(ssum);
+        };
+        if (!one) {
+            __syncthreads();
+            if (tid < live) s_lse[tid] = row_lse(tid);
+            __syncthreads();
         }
-        __syncthreads();
         BM_STAMP(2);
         float lc[KB]; int li[KB];
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
 #pragma unroll
         for (int u = 0; u < 4; ++u)
-            if (pv[u] > -INFINITY) list_insert(lc, li, (a.stochastic ? 0.f : s_hyp[pj[u]] + s_lse[pj[u]]) - pv[u], pi[u]);
+            if (pv[u] > -INFINITY) list_insert(lc, li, (a.stochastic ? 0.f : (one ? hyp0 : s_hyp[pj[u]] + s_lse[pj[u]])) - pv[u], pi[u]);
         // the rest of the flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they
         // are inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
         for (int c0 = 4 * NT; c0 < C; c0 += 4 * NT) {
@@ -267,7 +274,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
                     const int j = fdiv(e, per, r_per), rem = e - j * per, t = fdiv(rem, nsel, r_nsel), i = rem - t * nsel;
                     const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
                     const float val = rec[2 + i];                              // (stochastic: the tile's best PERTURBED value)
-                    const float base = a.stochastic ? 0.f : s_hyp[j] + s_lse[j];
+                    const float base = a.stochastic ? 0.f : (one ? hyp0 : s_hyp[j] + s_lse[j]);
                     if (val > -INFINITY) { cv[u] = base - val; ci[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i]; }
                 }
             }
@@ -277,6 +284,12 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         }
         BM_STAMP(3);
         block_select2(lc, li, nsel, s_c2, s_i2, res_c, res_i);
+        if (one && tid == 0) {
+            const float lse = row_lse(0);
+            s_lse[0] = lse;
+            if (!a.stochastic)
+                for (int r = 0; r < nsel; ++r) if (res_i[r] != 0x7fffffff) res_c[r] += lse;
+        }
         BM_STAMP(4);
         if (a.stochastic && tid == 0 && res_i[0] != 0x7fffffff) {
             // the draw is word res_i[0]; gen_sample's stochastic "score" is the running SUM of the drawn words'
@@ -347,6 +360,7 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
     }
     if (tid < n) ((s_fin[tid] ? a.fin_tok : a.tok_out) + (size_t)(v * k + s_slot[tid]) * L)[step] = s_wi[tid];
     // (every gather below: four independent loads per thread in flight, then their stores)
+    if (a.h_step != a.h_next)                                  // (one hypothesis per video: the LSTM wrote the states in place)
     for (int i0 = tid; i0 < n * D; i0 += 4 * NT) {             // gather the state of the parent hypothesis (:943-945)
         float hv[4], cv[4]; size_t dO[4]; int rr[4], dd[4]; bool on[4];
 #pragma unroll

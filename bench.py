@@ -36,6 +36,9 @@ if ROOT not in sys.path:
 CONFIGS = {
     # configs[1] with twice the rows: the region tensors (328 MB) exceed the 256 MB Infinity Cache -- HBM vs cache probe
     "c2b128": dict(B=128, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    # rows between the 64-row panel kernels and the wide ones (where each row-panel kernel takes over: csrc/panelw.hip)
+    "c2b80": dict(B=80, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    "c2b96": dict(B=96, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
     # configs[1] with the reference's real vocabulary (config.py:35)
     "c2v20k": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=20000, t=30),
     # BASELINE.json configs[1] "Single MI355X" / configs[2] per-GPU shard

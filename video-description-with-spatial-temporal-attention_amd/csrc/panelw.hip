@@ -387,7 +387,9 @@ bool panel_wide_supported(const PnArgs& a) {
     return true;
 }
 bool lstm_panel_wide_supported(const LstmPnArgs& a) {
-    if (!panel_wide_enabled() || a.M <= 64 || a.D % 8 != 0) return false;
+    // (measured at D = 1024 against panel.hip's LSTM kernel: 80 / 96 / 128 rows 31 vs 20.5 / 32 vs 20.5 / 32 vs 24 us, 160 rows 33 vs 37:
+    // this kernel's time barely depends on the row count, the 16-column kernel's grows with it -- it takes over from 144 rows)
+    if (!panel_wide_enabled() || a.M < 144 || a.D % 8 != 0) return false;
     for (int p = 0; p < a.npairs; ++p)
         if (a.p[p].K % 32 != 0) return false;
     return true;

@@ -417,6 +417,16 @@ hipError_t launch_panel_wide(hipStream_t s, const PnArgs& a) {
         hipLaunchKernelGGL((panelw_kernel<MB_, R_, KS_>), grid, block, lds, s, a);           \
     } while (0)
     // ring depth: (waves per SIMD) x R x MB x 256 MFMA cycles of operands in flight >= ~6000 cycles (2.5 us)
+#ifdef STATTN_PROBES
+    if (const char* rr = getenv("STATTN_PW_R")) {          // tools/panelw_probe.hip: ring depth sweep
+        const int R_ = atoi(rr);
+#define STATTN_PW_SWEEP(MB_, KS_) \
+        if (MB == MB_) { if (R_ == 3) STATTN_PW(MB_, 3, KS_); else if (R_ == 4) STATTN_PW(MB_, 4, KS_); else if (R_ == 5) STATTN_PW(MB_, 5, KS_); \
+                         else if (R_ == 6) STATTN_PW(MB_, 6, KS_); else STATTN_PW(MB_, 8, KS_); return hipGetLastError(); }
+        STATTN_PW_SWEEP(1, 16) STATTN_PW_SWEEP(5, 4)
+#undef STATTN_PW_SWEEP
+    }
+#endif
     switch (MB) {
         case 1: STATTN_PW(1, 6, 16); break;
         case 2: STATTN_PW(2, 6, 8); break;
@@ -442,10 +452,21 @@ hipError_t launch_lstm_panel_wide(hipStream_t s, const LstmPnArgs& a) {
         if (e_ != hipSuccess) return e_;                                                     \
         hipLaunchKernelGGL((lstm_panelw_kernel<MB_, R_>), grid, block, lds, s, a);           \
     } while (0)
+#ifdef STATTN_PROBES
+    if (const char* rr = getenv("STATTN_PW_R")) {
+        const int R_ = atoi(rr);
+#define STATTN_LPW_SWEEP(MB_) \
+        if (MB == MB_) { if (R_ == 3) STATTN_LPW(MB_, 3); else if (R_ == 4) STATTN_LPW(MB_, 4); else if (R_ == 5) STATTN_LPW(MB_, 5); \
+                         else if (R_ == 6) STATTN_LPW(MB_, 6); else STATTN_LPW(MB_, 8); return hipGetLastError(); }
+        STATTN_LPW_SWEEP(2) STATTN_LPW_SWEEP(3)
+#undef STATTN_LPW_SWEEP
+    }
+#endif
     switch (MB) {
-        case 1: STATTN_LPW(1, 16); break;
-        case 2: STATTN_LPW(2, 12); break;
-        case 3: STATTN_LPW(3, 8); break;
+        case 1: STATTN_LPW(1, 8); break;      // (rings deeper than ~8 steps are slower: 12 steps at two row blocks, 36 KB per wave in
+                                              // flight, doubled the launch time: tools/panelw_probe.hip, STATTN_PW_R)
+        case 2: STATTN_LPW(2, 6); break;
+        case 3: STATTN_LPW(3, 6); break;
         case 4: STATTN_LPW(4, 6); break;
         case 5: STATTN_LPW(5, 5); break;
         case 6: STATTN_LPW(6, 4); break;

@@ -432,7 +432,7 @@ hipError_t launch_panel_wide(hipStream_t s, const PnArgs& a) {
         case 2: STATTN_PW(2, 6, 8); break;
         case 3: STATTN_PW(3, 8, 4); break;
         case 4: STATTN_PW(4, 6, 4); break;
-        case 5: STATTN_PW(5, 4, 4); break;
+        case 5: STATTN_PW(5, 6, 4); break;
         case 6: STATTN_PW(6, 4, 4); break;
         default: STATTN_PW(8, 3, 4); break;
     }

@@ -15,6 +15,7 @@
 //     three softmaxes over T (unmasked, Appendix C.5), selector gate, and
 //     ctx[b,:] = sel_b * sum_t (ag_t G[v,t,:] + am_t M[v,t,:] + alt_t CL[b,t,:])
 #include "kernels.h"
+
 #include "devmath.h"
 #include "panel_inl.h"
 
@@ -51,6 +52,7 @@ __global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
     __shared__ float s_red[4 * 10];
     __shared__ float s_e[KMAX];
     const int T = a.T, K = a.K, D = a.D;
+    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int bt = blockIdx.x, b = bt / T, t = bt % T;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
@@ -80,9 +82,9 @@ __global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
             }
         }
         block_sum<10>(p, s_red, tid);
-        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
-        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
-        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + cl0;
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + cg0;
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + cm0;
     }
     __syncthreads();
 
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
     }
     if (LW) {
         block_sum<1>(pe, s_red, tid);
-        if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+        if (tid == 0) a.elt[bt] = pe[0] + clt0;
     }
 }
 
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
         return;
     }
     const int T = a.T, K = a.K, D = a.D;
+    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, t = bt % T;   // a row's frames on one XCD (shared sproj row)
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
@@ -208,9 +211,9 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
             }
         }
         block_sum_w<10, NW>(p, s_red, tid);
-        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
-        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
-        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + cl0;
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + cg0;
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + cm0;
     }
     __syncthreads();
     float mx = -INFINITY;
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
     }
     if (LW) {
         block_sum_w<1, NW>(pe, s_red, tid);
-        if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+        if (tid == 0) a.elt[bt] = pe[0] + clt0;
     }
 }
 
@@ -260,6 +263,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
 __global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a) {
     __shared__ float s_red[4 * 10];
     const int T = a.T, K = a.K, D = a.D;
+    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int bt = blockIdx.x, b = bt / T, t = bt % T;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x, nw = blockDim.x >> 6;
@@ -292,11 +296,11 @@ __global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a)
 #pragma unroll
         for (int i = 0; i < 10; ++i) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q * 10 + i]; p[i] = r; }
     }
-    if (tid == 0) { a.eg[bt] = p[8] + a.cg[0]; a.em[bt] = p[9] + a.cm[0]; }
+    if (tid == 0) { a.eg[bt] = p[8] + cg0; a.em[bt] = p[9] + cm0; }
     // softmax over the K regions (every lane redundantly, from registers)
     float mx = -INFINITY;
 #pragma unroll
-    for (int kk = 0; kk < 8; ++kk) { p[kk] += a.cl[0]; if (kk < K) mx = fmaxf(mx, p[kk]); }
+    for (int kk = 0; kk < 8; ++kk) { p[kk] += cl0; if (kk < K) mx = fmaxf(mx, p[kk]); }
     float sum = 0.f;
 #pragma unroll
     for (int kk = 0; kk < 8; ++kk) { p[kk] = kk < K ? __expf(p[kk] - mx) : 0.f; sum += p[kk]; }
@@ -319,7 +323,7 @@ __global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a)
         __syncthreads();                       // (s_red is being re-used)
         if (lane == 0) s_red[w] = pe;
         __syncthreads();
-        if (tid == 0) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q]; a.elt[bt] = r + a.clt[0]; }
+        if (tid == 0) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q]; a.elt[bt] = r + clt0; }
     }
 }
 
@@ -335,6 +339,7 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
         return;
     }
     const int T = a.T, K = a.K, D = a.D;
+    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, t = bt % T;
     const int v = a.vid ? a.vid[b] : b;
     const int tid = threadIdx.x;
@@ -371,9 +376,9 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
             }
         }
         block_sum_w<10, NW>(p, s_red, tid);
-        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + a.cl[0];
-        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + a.cg[0];
-        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + a.cm[0];
+        if (tid < 8 && k0 + tid < K) s_e[k0 + tid] = p[tid] + cl0;
+        if (k0 == 0 && tid == 8) a.eg[bt] = p[8] + cg0;
+        if (k0 == 0 && tid == 9) a.em[bt] = p[9] + cm0;
     }
     __syncthreads();
 
@@ -411,7 +416,7 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
                  dot4_tanh(make_float4(w[4] + b1.x, w[5] + b1.y, w[6] + b1.z, w[7] + b1.w), ld4(sl + 3 * D + 8 * d8 + 4), ld4(a.Ult + 8 * d8 + 4));
     }
     block_sum_w<1, NW>(pe, s_red, tid);
-    if (tid == 0) a.elt[bt] = pe[0] + a.clt[0];
+    if (tid == 0) a.elt[bt] = pe[0] + clt0;
 }
 
 // ---- beam-search variant: the H hypotheses of a video (rows v*H .. v*H+H-1) attend to the SAME region tensors, so
@@ -423,10 +428,17 @@ template <int H>
 #ifndef STATTN_SHARED_RG
 #define STATTN_SHARED_RG 4
 #endif
+#ifndef STATTN_SH_ABL
+#define STATTN_SH_ABL 0       // probe builds: 1 = score phase without its arithmetic, 2 = without its slab loads
+#endif
+#ifndef STATTN_SH_PHASE
+#define STATTN_SH_PHASE 0     // 1 / 2: probe builds that run one phase only
+#endif
 __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArgs a) {
     __shared__ float s_red[4 * 2 * H];
     __shared__ float s_e[H][KMAX];
     const int T = a.T, K = a.K, D = a.D;
+    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int vt = blockIdx.x, v = vt / T, t = vt % T;
     const int tid = threadIdx.x;
     const size_t slab = ((size_t)v * T + t) * K * D;
@@ -436,10 +448,15 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
     const int b0 = v * H;                                   // first row (hypothesis) of this video
     const int nd4 = D >> 2;
 
+#if STATTN_SH_PHASE == 2     // probe builds only (tools/shared_probe.sh): the weighted-sum phase alone, uniform weights
+    if (tid < H * KMAX) (&s_e[0][0])[tid] = 1.f / K;
+    __syncthreads();
+#else
     // ---- region scores of all hypotheses.  Wave w owns regions 8w .. 8w+7 (+32, ...) over the WHOLE of D (a row of a
     // slab is 64 lanes x 16 B x D/256 fully coalesced loads), so a wave_sum finishes its scores: no cross-wave reduction
     const int lane = tid & 63, w = tid >> 6;
-    for (int k0 = 8 * w; k0 < K; k0 += 32) {
+    constexpr int RP = 8;     // regions in flight per wave and pass (wave w owns regions RP w .. RP w + RP - 1, then + 4 RP)
+    for (int k0 = RP * w; k0 < K; k0 += 4 * RP) {
         // This phase is VALU-bound at configs[4] (H K D = 164 k tanh per workgroup, 419 M per word: as long as the
         // 1 GB of slabs takes to stream), so the tanh is split along its sum:
         //     tanh(x + s) = 1 - 2 / (1 + e^{2x} e^{2s})
@@ -448,25 +465,42 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         // FMA remain -- ONE transcendental instead of two.  U . 1 is added once at the end (the "1 -" of every term).
         // Exponents are clamped to +-80 (|x|, |s| <= 40: e^{80} e^{80} = inf -> tanh = 1, e^{-80} e^{-80} = 0 -> -1, never
         // 0 x inf); inside that domain the result equals the direct form to 1e-7.
-        float p[8 * H];          // p[h * 8 + kk] = sum_d (-2 U_d) / (1 + e^{2x} e^{2s})
+        float p[RP * H];         // p[h * RP + kk] = sum_d (-2 U_d) / (1 + e^{2x} e^{2s})
         float usum = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8 * H; ++i) p[i] = 0.f;
+        for (int i = 0; i < RP * H; ++i) p[i] = 0.f;
         for (int d4 = lane; d4 < nd4; d4 += 64) {
-            float4 x[8];
+            float4 x[RP];
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) x[kk] = ld4_nt(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
+#if STATTN_SH_ABL == 2
+            for (int kk = 0; kk < RP; ++kk) x[kk] = make_float4(1e-3f * (lane + kk), 1e-3f * d4, 0.1f, 0.2f);
+#else
+            for (int kk = 0; kk < RP; ++kk) x[kk] = ld4_nt(PL + (size_t)min(k0 + kk, K - 1) * D + 4 * d4);
+#endif
+            // the H state-projection rows are requested HERE, with the slab rows: loaded inside the per-hypothesis blocks below
+            // (which a sched_barrier keeps apart) each was an exposed L2 round trip, five per column group
+            float4 sp[H];
+#pragma unroll
+            for (int h = 0; h < H; ++h) sp[h] = ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4);
             const float4 u4 = ld4(a.Ul + 4 * d4);
             usum += (u4.x + u4.y) + (u4.z + u4.w);
             const float4 m2u = make_float4(-2.f * u4.x, -2.f * u4.y, -2.f * u4.z, -2.f * u4.w);
+#if STATTN_SH_ABL == 1
 #pragma unroll
-            for (int kk = 0; kk < 8; ++kk) x[kk] = exp2x4(x[kk]);
+            for (int kk = 0; kk < RP; ++kk) p[kk] += (x[kk].x + x[kk].y) + (x[kk].z + x[kk].w) + sp[kk % H].x;
+            if (false)
+#endif
+#pragma unroll
+            for (int kk = 0; kk < RP; ++kk) x[kk] = exp2x4(x[kk]);
+#if STATTN_SH_ABL == 1
+            if (false)
+#endif
 #pragma unroll
             for (int h = 0; h < H; ++h) {
-                const float4 es = exp2x4(ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4));
+                const float4 es = exp2x4(sp[h]);
 #pragma unroll
-                for (int kk = 0; kk < 8; ++kk) {
-                    p[h * 8 + kk] += m2u.x * fast_rcp(1.f + x[kk].x * es.x) + m2u.y * fast_rcp(1.f + x[kk].y * es.y) +
+                for (int kk = 0; kk < RP; ++kk) {
+                    p[h * RP + kk] += m2u.x * fast_rcp(1.f + x[kk].x * es.x) + m2u.y * fast_rcp(1.f + x[kk].y * es.y) +
                                      m2u.z * fast_rcp(1.f + x[kk].z * es.z) + m2u.w * fast_rcp(1.f + x[kk].w * es.w);
                 }
                 __builtin_amdgcn_sched_barrier(0);     // one hypothesis at a time: interleaving all 8 H chains spills
@@ -474,9 +508,9 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         }
         usum = wave_sum(usum);
 #pragma unroll
-        for (int i = 0; i < 8 * H; ++i) {
+        for (int i = 0; i < RP * H; ++i) {
             const float r = wave_sum(p[i]);
-            if (lane == 0 && k0 + (i & 7) < K) s_e[i >> 3][k0 + (i & 7)] = r + usum + a.cl[0];
+            if (lane == 0 && k0 + (i % RP) < K) s_e[i / RP][k0 + (i % RP)] = r + usum + cl0;
         }
     }
     // ---- the two frame scores per hypothesis (PG / PM rows are shared by the hypotheses as well)
@@ -497,7 +531,7 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         block_sum<2 * H>(q, s_red, tid);
 #pragma unroll
         for (int h = 0; h < H; ++h)
-            if (tid == h) { a.eg[(size_t)(b0 + h) * T + t] = q[2 * h] + a.cg[0]; a.em[(size_t)(b0 + h) * T + t] = q[2 * h + 1] + a.cm[0]; }
+            if (tid == h) { a.eg[(size_t)(b0 + h) * T + t] = q[2 * h] + cg0; a.em[(size_t)(b0 + h) * T + t] = q[2 * h + 1] + cm0; }
     }
     __syncthreads();
     // ---- softmax over the regions, one wave-lane group per hypothesis (K <= 64: one lane per region)
@@ -509,6 +543,8 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         if (lane < K) { s_e[h][lane] = al; a.alphal[((size_t)(b0 + h) * T + t) * K + lane] = al; }
     }
     __syncthreads();
+#endif
+#if STATTN_SH_PHASE != 1
     // ---- attended local feature (and the local-temporal score) per hypothesis: L / LW streamed once
     float pe[H];
 #pragma unroll
@@ -561,8 +597,9 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
         block_sum<H>(pe, s_red, tid);
 #pragma unroll
         for (int h = 0; h < H; ++h)
-            if (tid == h) a.elt[(size_t)(b0 + h) * T + t] = pe[h] + a.clt[0];
+            if (tid == h) a.elt[(size_t)(b0 + h) * T + t] = pe[h] + clt0;
     }
+#endif
 }
 
 

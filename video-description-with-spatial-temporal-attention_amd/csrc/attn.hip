@@ -107,14 +107,23 @@ __global__ __launch_bounds__(256) void spatial_kernel(const SpatialArgs a) {
     const float* __restrict__ LW = a.LW ? a.LW + slab : nullptr;
     for (int d4 = tid; d4 < nd4; d4 += 256) {
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the loop is written once per case: with `if (LW)` around the second load inside it, hipcc kept the branch and put
+        // a full wait behind every LW row -- K dependent round trips per item)
+        if (LW) {
 #pragma unroll 8
-        for (int k = 0; k < K; ++k) {
-            const float al = s_e[k];
-            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
-            c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
-            if (LW) {
+            for (int k = 0; k < K; ++k) {
+                const float al = s_e[k];
+                const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
                 const float4 q4 = ld4(LW + (size_t)k * D + 4 * d4);
+                c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
                 w4.x += al * q4.x; w4.y += al * q4.y; w4.z += al * q4.z; w4.w += al * q4.w;
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) {
+                const float al = s_e[k];
+                const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
+                c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
             }
         }
         st4(a.CL + (size_t)bt * D + 4 * d4, c4);
@@ -233,14 +242,23 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
     const float* __restrict__ LW = a.LW ? a.LW + slab : nullptr;
     for (int d4 = tid; d4 < nd4; d4 += NT) {
         float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        // (the loop is written once per case: with `if (LW)` around the second load inside it, hipcc kept the branch and put
+        // a full wait behind every LW row -- K dependent round trips per item)
+        if (LW) {
 #pragma unroll 8
-        for (int k = 0; k < K; ++k) {
-            const float al = s_e[k];
-            const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
-            c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
-            if (LW) {
+            for (int k = 0; k < K; ++k) {
+                const float al = s_e[k];
+                const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
                 const float4 q4 = ld4(LW + (size_t)k * D + 4 * d4);
+                c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
                 w4.x += al * q4.x; w4.y += al * q4.y; w4.z += al * q4.z; w4.w += al * q4.w;
+            }
+        } else {
+#pragma unroll 8
+            for (int k = 0; k < K; ++k) {
+                const float al = s_e[k];
+                const float4 l4 = ld4(L + (size_t)k * D + 4 * d4);
+                c4.x += al * l4.x; c4.y += al * l4.y; c4.z += al * l4.z; c4.w += al * l4.w;
             }
         }
         st4(a.CL + (size_t)bt * D + 4 * d4, c4);

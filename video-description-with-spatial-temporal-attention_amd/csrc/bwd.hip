@@ -207,8 +207,9 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
     auto form_dcs = [&](int d4) {          // dcsum[b, 4 d4 ..] = sel * (readout term + partials of dpre.Wc^T)
         const size_t ob = (size_t)b * D + 4 * d4;
         float4 dc = a.dctx_r ? ld4(a.dctx_r + ob) : make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q = 0; q < a.nP; ++q) add4(dc, ld4(a.dctxP + (size_t)q * MD + ob));
-        return dc;
+#pragma unroll 4
+        for (int q = 0; q < a.nP; ++q) add4(dc, ld4(a.dctxP + (size_t)q * MD + ob));      // (four partials in flight together: not unrolled,
+        return dc;                                                                          //  every partial was a round trip of its own)
     };
     // dcsum of the row is needed again by the spatial part: parked in LDS (D <= 2048), else re-formed from the partials
     constexpr int DCS_LDS = 2048;
@@ -220,17 +221,20 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
         for (int i = 0; i < 8; ++i) q[i] = 0.f;
         for (int d4 = tid; d4 < nd4; d4 += 256) {
             const size_t ob = (size_t)b * D + 4 * d4, o = (size_t)bt * D + 4 * d4;
+            // every operand of the seven dot products is requested before dcsum is formed (one round trip, not four)
+            const float4 xc = ld4(a.csum + ob), xg = ld4(a.G + o), xm = ld4(a.Mo + o), xl = ld4(a.CL + o);
+            const float4 x0 = ld4(a.cparts + ob), x1 = ld4(a.cparts + MD + ob), x2 = ld4(a.cparts + 2 * MD + ob);
             const float4 dc = form_dcs(d4);
-            q[6] += dot4(dc, ld4(a.csum + ob));
+            q[6] += dot4(dc, xc);
             const float4 dcs = scale4(dc, sel);
             if (dcs_lds) st4(&s_dcs[4 * d4], dcs);
             if (tf == 0) st4(a.dcsum + ob, dcs);
-            q[0] += dot4(dcs, ld4(a.G + o));
-            q[1] += dot4(dcs, ld4(a.Mo + o));
-            q[2] += dot4(dcs, ld4(a.CL + o));
-            q[3] += dot4(dcs, ld4(a.cparts + ob));
-            q[4] += dot4(dcs, ld4(a.cparts + MD + ob));
-            q[5] += dot4(dcs, ld4(a.cparts + 2 * MD + ob));
+            q[0] += dot4(dcs, xg);
+            q[1] += dot4(dcs, xm);
+            q[2] += dot4(dcs, xl);
+            q[3] += dot4(dcs, x0);
+            q[4] += dot4(dcs, x1);
+            q[5] += dot4(dcs, x2);
         }
         block_sum<8>(q, s_red, tid, 4);
         // softmax backward of the three temporal attentions for this frame (wave 0..2; the T-long <alpha, r> only with

@@ -663,30 +663,42 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     }
 
     if (w < 3) {          // three softmaxes over T, one wave each
+        // the lane's scores are read ONCE, all of them in flight together (three passes over e[] were three dependent round trips)
         const float* e = (w == 0 ? a.eg : (w == 1 ? a.em : a.elt)) + (size_t)b * T;
+        constexpr int NE = (TMAX + 63) / 64;
+        float ev[NE];
+#pragma unroll
+        for (int i = 0; i < NE; ++i) ev[i] = e[min(lane + 64 * i, T - 1)];
         float mx = -INFINITY;
-        for (int t = lane; t < T; t += 64) mx = fmaxf(mx, e[t]);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) if (lane + 64 * i < T) mx = fmaxf(mx, ev[i]);
         mx = wave_max(mx);
         float sum = 0.f;
-        for (int t = lane; t < T; t += 64) sum += __expf(e[t] - mx);
+#pragma unroll
+        for (int i = 0; i < NE; ++i) { ev[i] = lane + 64 * i < T ? __expf(ev[i] - mx) : 0.f; sum += ev[i]; }
         sum = wave_sum(sum);
         const float inv = 1.0f / sum;
         float* out = (w == 0 ? a.alphag : (w == 1 ? a.alpham : a.alphalt)) + (size_t)b * T;
-        for (int t = lane; t < T; t += 64) {
-            const float al = __expf(e[t] - mx) * inv;
-            s_al[w][t] = al;
-            if (chunk == 0) out[t] = al;
+#pragma unroll
+        for (int i = 0; i < NE; ++i) {
+            const int t = lane + 64 * i;
+            if (t < T) {
+                const float al = ev[i] * inv;
+                s_al[w][t] = al;
+                if (chunk == 0) out[t] = al;
+            }
         }
     } else {              // selector gate sigma(h_prev . W_sel + b_sel)   (:433)
         float sel = 1.f;
         if (a.W_sel) {
+            const float bsel = a.b_sel[0];
             float s = 0.f;
             for (int d4 = lane; d4 < (D >> 2); d4 += 64) {
                 const float4 h4 = ld4(a.h_prev + (size_t)b * D + 4 * d4), w4 = ld4(a.W_sel + 4 * d4);
                 s += h4.x * w4.x + h4.y * w4.y + h4.z * w4.z + h4.w * w4.w;
             }
             s = wave_sum(s);
-            sel = fast_sigmoid(s + a.b_sel[0]);
+            sel = fast_sigmoid(s + bsel);
         }
         if (lane == 0) {
             s_sel = sel;

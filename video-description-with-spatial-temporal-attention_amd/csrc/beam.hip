@@ -265,17 +265,25 @@ __global__ __launch_bounds__(1024) void beam_update_kernel(const BeamArgs a, int
         // the rest of the flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they
         // are inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
         for (int c0 = 4 * NT; c0 < C; c0 += 4 * NT) {
-            float cv[4]; int ci[4];
+            // (value AND index of the four candidates requested together, unconditionally -- the last candidate is re-read past the
+            // end: with the index load inside `if (val > -inf)` the four were eight dependent round trips)
+            float cv[4], val[4]; int ci[4], ix[4], jj[4];
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
-                const int e = c0 + u * NT + tid;
+                const int e = min(c0 + u * NT + tid, C - 1);
+                const int j = fdiv(e, per, r_per), rem = e - j * per, t = fdiv(rem, nsel, r_nsel), i = rem - t * nsel;
+                const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
+                val[u] = rec[2 + i];                                           // (stochastic: the tile's best PERTURBED value)
+                ix[u] = reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i];
+                jj[u] = j;
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
                 cv[u] = INFINITY; ci[u] = 0x7fffffff;
-                if (e < C) {
-                    const int j = fdiv(e, per, r_per), rem = e - j * per, t = fdiv(rem, nsel, r_nsel), i = rem - t * nsel;
-                    const float* rec = a.stats + ((size_t)(v * k + j) * nt + t) * PN_STATS_REC;
-                    const float val = rec[2 + i];                              // (stochastic: the tile's best PERTURBED value)
+                if (c0 + u * NT + tid < C && val[u] > -INFINITY) {
+                    const int j = jj[u];
                     const float base = a.stochastic ? 0.f : (one ? hyp0 : s_hyp[j] + s_lse[j]);
-                    if (val > -INFINITY) { cv[u] = base - val; ci[u] = j * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i]; }
+                    cv[u] = base - val[u]; ci[u] = j * V + ix[u];
                 }
             }
 #pragma unroll

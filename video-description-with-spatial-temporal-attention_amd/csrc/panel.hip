@@ -38,6 +38,11 @@ __device__ long long* pn_probe = nullptr;
 
 namespace {
 
+// Optional epilogue operands are read through a pointer that is ALWAYS valid (the operand, or one of these with a zero stride):
+// a load inside `if (bias)` keeps its branch and hipcc puts a full s_waitcnt behind it -- every optional operand was a dependent
+// L2 round trip of its own, in the tail (or, for the LSTM kernel's "early" requests, in front) of a 5 - 12 us launch.
+__device__ const float pn_zero = 0.f, pn_one = 1.f;
+
 // ---- general grouped GEMM with fused epilogue ------------------------------------------------------------
 template <int MT, int NT, int MAXT, int R, bool ONESHOT>
 __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int MG, const int KS) {
@@ -55,6 +60,26 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     const int kz = a.kz > 1 ? a.kz : 1;
 
     PN_STAMP(0);
+    // the segment's fields, read once: `a.seg[si]` is indexed dynamically, and left inside the loop every field is an s_load
+    // from the kernel-argument segment per iteration whose s_waitcnt lgkmcnt(0) also drains the LDS reads (panelw.hip)
+    const int n0 = tg * CB;
+    const float* const bias = sg.bias ? sg.bias : &pn_zero; const int sbias = sg.bias ? 1 : 0;
+    const float* const bias2 = sg.bias2 ? sg.bias2 : &pn_zero; const int sbias2 = sg.bias2 ? 1 : 0;
+    const float* const add = sg.add ? sg.add : &pn_zero; const int sadd = sg.add ? 1 : 0;
+    const float* const mul = sg.mul ? sg.mul : &pn_one; const int smul = sg.mul ? 1 : 0;
+    const int ldadd = sg.ldadd, ldmul = sg.ldmul, M = a.M;
+    // The epilogue's operands do not depend on the GEMM: those of the thread's first (row, column) item -- its only one unless
+    // the block has fewer threads than the tile has elements -- are requested before it (four loads in flight behind the main
+    // loop instead of up to four dependent round trips after it).
+    struct Epi { float b, b2, ad, ml; };
+    auto epi_load = [&](int idx) {
+        const int row = min(idx / CB, M - 1), n = n0 + idx % CB;
+        Epi e;
+        e.b = bias[n * sbias]; e.b2 = bias2[n * sbias2];
+        e.ad = add[((size_t)row * ldadd + n) * sadd]; e.ml = mul[((size_t)row * ldmul + n) * smul];
+        return e;
+    };
+    const Epi e0 = epi_load(min(tid, RB * CB - 1));
     f32x4 acc[MT][NT];
 #pragma unroll
     for (int i = 0; i < MT; ++i)
@@ -94,7 +119,6 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     __syncthreads();
     PN_STAMP(2);
 
-    const int n0 = tg * CB;
     if (sg.stats) {   // vocabulary statistics of this column tile (small-batch decode: the logits are never stored)
         // final biased values -> the extra RB x CB block behind the K-slice partials (launch_panel sizes it in)
         float* fin = red + (size_t)KS * RB * CB;
@@ -103,7 +127,7 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
             float v = 0.f;
             for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + col];
             const int n = n0 + col;
-            if (sg.bias) v += sg.bias[n];
+            v += idx == tid ? e0.b : bias[n * sbias];
             if (n >= sg.stats_V || (sg.stats_skip0 && n == 0)) v = -INFINITY;
             fin[idx] = v;
         }
@@ -136,12 +160,8 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         PN_STAMP(3);
         return;
     }
-    // the segment's fields, read once: `a.seg[si]` is indexed dynamically, and left inside the loop every field is an s_load
-    // from the kernel-argument segment per iteration whose s_waitcnt lgkmcnt(0) also drains the LDS reads (panelw.hip)
-    const float* const bias = sg.bias; const float* const bias2 = sg.bias2;
-    const float* const add = sg.add; const float* const mul = sg.mul;
     float* const Cp = sg.C; float* const Cpk = sg.Cpk;
-    const int ldadd = sg.ldadd, ldmul = sg.ldmul, ldc = sg.ldc, act = sg.act, Spk = sg.N >> 4, M = a.M;
+    const int ldc = sg.ldc, act = sg.act, Spk = sg.N >> 4;
     const float scale = sg.scale;
     const size_t pstride = a.part_stride;
     for (int idx = tid; idx < RB * CB; idx += blockDim.x) {
@@ -151,12 +171,13 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + col];
         const int n = n0 + col;
         if (kz > 1) { Cp[(size_t)blockIdx.y * pstride + (size_t)row * ldc + n] = v; continue; }
-        if (bias) v += bias[n];
-        if (bias2) v += bias2[n];
-        if (add) v += add[(size_t)row * ldadd + n];
+        const Epi e = idx == tid ? e0 : epi_load(idx);
+        v += e.b;
+        v += e.b2;
+        v += e.ad;
         if (act == 1) v = fast_tanh(v);
         v *= scale;
-        if (mul) v *= mul[(size_t)row * ldmul + n];
+        v *= e.ml;
         Cp[(size_t)row * ldc + n] = v;
         if (Cpk) Cpk[pn_pack_offset(row, n, Spk)] = v;
     }
@@ -183,22 +204,28 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
     // The epilogue's operands do not depend on the GEMM: those of the thread's first (row, unit) item -- its only one
     // unless the block has fewer K-slice waves than m-tiles -- are requested before it, so that the cell update at the
     // end is arithmetic only (it was a chain of ten dependent global loads: 4.4 us of a 17 us launch).
-    struct EpiIn { float pre[4], dp[3], cp, hp, m, d1; };
+    // (Every load unconditional, through pointers that are always valid, and no arithmetic on the loaded values here: with
+    // `a.bias ? ... : 0` / `if (a.bias) v += ...` hipcc kept the branches and waited for each load where it stood -- the
+    // "early requests" were four to six dependent round trips IN FRONT of the main loop.)
+    struct EpiIn { float add[4], bias[4], dp[3], cp, hp, m, d1; };
+    const float* const padd = a.pre_add ? a.pre_add : &pn_zero; const int sadd = a.pre_add ? 1 : 0;
+    const float* const pbias = a.bias ? a.bias : &pn_zero; const int sbias = a.bias ? 1 : 0;
+    const float* const pmask = a.mask ? a.mask : &pn_one; const int smask = a.mask ? 1 : 0;
+    const float* const pd1 = a.d1 ? a.d1 : &pn_one; const int sd1 = a.d1 ? 1 : 0;
     auto epi_load = [&](int idx) {
         EpiIn e;
         const int row = min(idx >> 2, a.M - 1), d = 4 * c + (idx & 3);
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
-            float v = a.pre_add ? a.pre_add[(size_t)row * a.ldpre + gate * D + d] : 0.f;
-            if (a.bias) v += a.bias[gate * D + d];
-            e.pre[gate] = v;
+            e.add[gate] = padd[((size_t)row * a.ldpre + gate * D + d) * sadd];
+            e.bias[gate] = pbias[(gate * D + d) * sbias];
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) e.dp[q] = a.dp[(size_t)row * a.lddp + q * D + d];
         e.cp = a.c_prev[(size_t)row * D + d];
         e.hp = a.h_prev[(size_t)row * D + d];
-        e.m = a.mask ? a.mask[row] : 1.f;
-        e.d1 = a.d1 ? a.d1[(size_t)row * a.ldd1 + d] : a.d1_scalar;
+        e.m = pmask[row * smask];
+        e.d1 = pd1[((size_t)row * a.ldd1 + d) * sd1];
         return e;
     };
     const EpiIn e0 = epi_load(min(tid, RB * 4 - 1));
@@ -237,7 +264,7 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
         for (int gate = 0; gate < 4; ++gate) {
             float v = 0.f;
             for (int k = 0; k < KS; ++k) v += red[((size_t)k * RB + row) * CB + gate * 4 + u];
-            pre[gate] = v + e.pre[gate];
+            pre[gate] = v + (e.add[gate] + e.bias[gate]);
         }
         // dropout multiplies the i/f/o PRE-activations (:444-447); g gets none
         const float gi = fast_sigmoid(pre[0] * e.dp[0]);
@@ -255,8 +282,9 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
             float* gt = a.gates + (size_t)row * 4 * D + d;
             gt[0] = gi; gt[D] = gf; gt[2 * D] = go; gt[3 * D] = gg;
         }
-        if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * e.d1;
-        if (a.hd_pk) a.hd_pk[pn_pack_offset(row, d, D >> 4)] = hn * e.d1;
+        const float d1 = a.d1 ? e.d1 : a.d1_scalar;
+        if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * d1;
+        if (a.hd_pk) a.hd_pk[pn_pack_offset(row, d, D >> 4)] = hn * d1;
     }
     PN_STAMP(3);
 }

@@ -161,6 +161,11 @@ __device__ __forceinline__ void pw_reduce(float* red, f32x16 (&acc)[MB], int w, 
 }
 
 // ---- general grouped GEMM with the fused epilogue of panel_kernel --------------------------------------------------
+// optional epilogue operands are read through pointers that are always valid (panel.hip: a load inside `if (add)` keeps its
+// branch and a full wait -- add and mul were two dependent round trips per output row of a thread)
+__device__ __attribute__((aligned(16))) const float pw_zero4[4] = {0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) const float pw_one4[4] = {1.f, 1.f, 1.f, 1.f};
+
 template <int MB, int R, int KS>
 __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
     constexpr int NTH = 64 * KS, FPITCH = WCB + 1;
@@ -194,14 +199,26 @@ __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
     // each field is an s_load from the kernel-argument segment per iteration, its s_waitcnt lgkmcnt(0) also draining the LDS
     // reads (measured: 5.4 us of epilogue for 20 stores per thread).  A thread owns four consecutive columns (float4 LDS
     // reads, 16-byte global accesses) of every (NTH / 8)-th row.
-    const float* const bias = sg.bias; const float* const bias2 = sg.bias2;
-    const float* const add = sg.add; const float* const mul = sg.mul;
+    const float* const bias = sg.bias ? sg.bias : pw_zero4; const int sbias = sg.bias ? 1 : 0;
+    const float* const bias2 = sg.bias2 ? sg.bias2 : pw_zero4; const int sbias2 = sg.bias2 ? 1 : 0;
+    const float* const add = sg.add ? sg.add : pw_zero4; const int sadd = sg.add ? 1 : 0;
+    const float* const mul = sg.mul ? sg.mul : pw_one4; const int smul = sg.mul ? 1 : 0;
     float* const Cp = sg.C; float* const Cpk = sg.Cpk; float* const stats = sg.stats;
     const int ldadd = sg.ldadd, ldmul = sg.ldmul, ldc = sg.ldc, act = sg.act, Spk = sg.N >> 4;
     const float scale = sg.scale;
     const int c4 = (tid & 7) * 4, n = n0 + c4;
-    float4 b4 = bias ? ld4(bias + n) : make_float4(0.f, 0.f, 0.f, 0.f);
-    if (bias2) { const float4 q = ld4(bias2 + n); b4.x += q.x; b4.y += q.y; b4.z += q.z; b4.w += q.w; }
+    // every global operand of this thread's epilogue in ONE burst: both biases and add / mul of all its rows
+    constexpr int NR = (RB * 8 + NTH - 1) / NTH;            // rows per thread
+    float4 b4 = ld4(bias + n * sbias);
+    const float4 b2 = ld4(bias2 + n * sbias2);
+    float4 ad[NR], ml[NR];
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int row = min(row0 + (tid >> 3) + q * (NTH / 8), a.M - 1);
+        ad[q] = ld4(add + ((size_t)row * ldadd + n) * sadd);
+        ml[q] = ld4(mul + ((size_t)row * ldmul + n) * smul);
+    }
+    b4.x += b2.x; b4.y += b2.y; b4.z += b2.z; b4.w += b2.w;
     if (stats) {   // vocabulary statistics of this column block (the logits are never stored): see panel_kernel
         const int stats_V = sg.stats_V, stats_kb = sg.stats_kb, skip0 = sg.stats_skip0, ntile = sg.N / WCB;
         float* fin = red + (KS / 2 > 2 ? KS / 2 : 2) * BUF;  // [RB][33] final biased values
@@ -252,15 +269,16 @@ __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
         PW_STAMP(3);
         return;
     }
-    for (int rr = tid >> 3; rr < RB; rr += NTH / 8) {
-        const int row = row0 + rr;
-        if (row >= a.M) break;                             // (rows ascend with rr)
+#pragma unroll
+    for (int q = 0; q < NR; ++q) {
+        const int rr = (tid >> 3) + q * (NTH / 8), row = row0 + rr;
+        if (rr >= RB || row >= a.M) break;                 // (rows ascend with q)
         const float4 p0 = ld4(red + rr * WPITCH + c4), p1 = ld4(red + BUF + rr * WPITCH + c4);
         float4 v = make_float4(p0.x + p1.x + b4.x, p0.y + p1.y + b4.y, p0.z + p1.z + b4.z, p0.w + p1.w + b4.w);
-        if (add) { const float4 q = ld4(add + (size_t)row * ldadd + n); v.x += q.x; v.y += q.y; v.z += q.z; v.w += q.w; }
+        v.x += ad[q].x; v.y += ad[q].y; v.z += ad[q].z; v.w += ad[q].w;
         if (act == 1) v = make_float4(fast_tanh(v.x), fast_tanh(v.y), fast_tanh(v.z), fast_tanh(v.w));
         v.x *= scale; v.y *= scale; v.z *= scale; v.w *= scale;
-        if (mul) { const float4 q = ld4(mul + (size_t)row * ldmul + n); v.x *= q.x; v.y *= q.y; v.z *= q.z; v.w *= q.w; }
+        v.x *= ml[q].x; v.y *= ml[q].y; v.z *= ml[q].z; v.w *= ml[q].w;
         if (Cp) st4(Cp + (size_t)row * ldc + n, v);
         if (Cpk) st4(Cpk + pn_pack_offset(row, n, Spk), v);
     }
@@ -279,22 +297,28 @@ __global__ __launch_bounds__(256) void lstm_panelw_kernel(const LstmPnArgs a) {
     const int rb0 = (int)blockIdx.y * MB, row0 = rb0 * 32;
 
     // the epilogue's operands do not depend on the GEMM: requested before it (panel.hip lstm_panel_kernel)
-    struct EpiIn { float pre[4], dp[3], cp, hp, m, d1; };
+    // (every load unconditional, through pointers that are always valid, and no arithmetic on the loaded values before the
+    // main loop: with `a.bias ? ... : 0` hipcc kept the branches and waited for each load where it stood -- the early requests
+    // were four dependent round trips per item IN FRONT of the GEMM.)  The bias depends on the unit only: once per thread.
+    struct EpiIn { float add[4], dp[3], cp, hp, m, d1; };
+    const float* const padd = a.pre_add ? a.pre_add : pw_zero4; const int sadd = a.pre_add ? 1 : 0;
+    const float* const pbias = a.bias ? a.bias : pw_zero4; const int sbias = a.bias ? 1 : 0;
+    const float* const pmask = a.mask ? a.mask : pw_one4; const int smask = a.mask ? 1 : 0;
+    const float* const pd1 = a.d1 ? a.d1 : pw_one4; const int sd1 = a.d1 ? 1 : 0;
+    float gbias[4];
+#pragma unroll
+    for (int gate = 0; gate < 4; ++gate) gbias[gate] = pbias[(gate * D + 8 * cb + (tid & 7)) * sbias];
     auto epi_load = [&](int idx) {
         EpiIn e;
         const int row = min(row0 + (idx >> 3), a.M - 1), d = 8 * cb + (idx & 7);
 #pragma unroll
-        for (int gate = 0; gate < 4; ++gate) {
-            float v = a.pre_add ? a.pre_add[(size_t)row * a.ldpre + gate * D + d] : 0.f;
-            if (a.bias) v += a.bias[gate * D + d];
-            e.pre[gate] = v;
-        }
+        for (int gate = 0; gate < 4; ++gate) e.add[gate] = padd[((size_t)row * a.ldpre + gate * D + d) * sadd];
 #pragma unroll
         for (int q = 0; q < 3; ++q) e.dp[q] = a.dp[(size_t)row * a.lddp + q * D + d];
         e.cp = a.c_prev[(size_t)row * D + d];
         e.hp = a.h_prev[(size_t)row * D + d];
-        e.m = a.mask ? a.mask[row] : 1.f;
-        e.d1 = a.d1 ? a.d1[(size_t)row * a.ldd1 + d] : a.d1_scalar;
+        e.m = pmask[row * smask];
+        e.d1 = pd1[((size_t)row * a.ldd1 + d) * sd1];
         return e;
     };
     PW_STAMP(0);
@@ -329,7 +353,7 @@ __global__ __launch_bounds__(256) void lstm_panelw_kernel(const LstmPnArgs a) {
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
             const int col = (u8 >> 2) * 16 + gate * 4 + (u8 & 3);
-            pv[gate] = red[rr * WPITCH + col] + red[BUF + rr * WPITCH + col] + e.pre[gate];
+            pv[gate] = red[rr * WPITCH + col] + red[BUF + rr * WPITCH + col] + (e.add[gate] + gbias[gate]);
         }
         // dropout multiplies the i/f/o PRE-activations (:444-447); g gets none
         const float gi = fast_sigmoid(pv[0] * e.dp[0]);
@@ -347,8 +371,9 @@ __global__ __launch_bounds__(256) void lstm_panelw_kernel(const LstmPnArgs a) {
             float* gt = a.gates + (size_t)row * 4 * D + d;
             gt[0] = gi; gt[D] = gf; gt[2 * D] = go; gt[3 * D] = gg;
         }
-        if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * e.d1;
-        if (a.hd_pk) a.hd_pk[pn_pack_offset(row, d, D >> 4)] = hn * e.d1;
+        const float d1 = a.d1 ? e.d1 : a.d1_scalar;
+        if (a.hd_out) a.hd_out[(size_t)row * D + d] = hn * d1;
+        if (a.hd_pk) a.hd_pk[pn_pack_offset(row, d, D >> 4)] = hn * d1;
     }
     PW_STAMP(3);
 }

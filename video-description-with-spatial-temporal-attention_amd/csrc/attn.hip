@@ -16,6 +16,8 @@
 //     ctx[b,:] = sel_b * sum_t (ag_t G[v,t,:] + am_t M[v,t,:] + alt_t CL[b,t,:])
 #include "kernels.h"
 
+#include <type_traits>
+
 #include "devmath.h"
 #include "panel_inl.h"
 
@@ -567,50 +569,56 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
     float pe[H];
 #pragma unroll
     for (int h = 0; h < H; ++h) pe[h] = 0.f;
-    for (int d4 = tid; d4 < nd4; d4 += 256) {
-        float4 c4[H], w4[H];
-#pragma unroll
-        for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
-        // RG regions per round, the NEXT round's rows requested before this round's FMAs (the rounds used to be a chain of
-        // K / RG exposed load latencies: this phase alone was 174 us at configs[4] for 0.67 GB)
-        constexpr int RG = STATTN_SHARED_RG;
-        float4 l4[RG], q4[RG], ln[RG], qn[RG];
-        auto rows = [&](float4 (&l)[RG], float4 (&q)[RG], int k0) {
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-                const int k = min(k0 + kk, K - 1);
-                l[kk] = ld4_nt(L + (size_t)k * D + 4 * d4);
-                q[kk] = LW ? ld4_nt(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    // (written once per lt_mode: with `LW ? load : 0` inside, hipcc kept a branch around every LW load and put a full wait behind
+    // each of the first four -- the phase began with four dependent HBM round trips)
+    auto sums = [&](auto has_lw) {
+        constexpr bool HAS_LW = decltype(has_lw)::value;
+        for (int d4 = tid; d4 < nd4; d4 += 256) {
+            float4 c4[H], w4[H];
+    #pragma unroll
+            for (int h = 0; h < H; ++h) { c4[h] = make_float4(0.f, 0.f, 0.f, 0.f); w4[h] = c4[h]; }
+            // RG regions per round, the NEXT round's rows requested before this round's FMAs (the rounds used to be a chain of
+            // K / RG exposed load latencies: this phase alone was 174 us at configs[4] for 0.67 GB)
+            constexpr int RG = STATTN_SHARED_RG;
+            float4 l4[RG], q4[RG], ln[RG], qn[RG];
+            auto rows = [&](float4 (&l)[RG], float4 (&q)[RG], int k0) {
+    #pragma unroll
+                for (int kk = 0; kk < RG; ++kk) {
+                    const int k = min(k0 + kk, K - 1);
+                    l[kk] = ld4_nt(L + (size_t)k * D + 4 * d4);
+                    q[kk] = HAS_LW ? ld4_nt(LW + (size_t)k * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            };
+            rows(l4, q4, 0);
+            for (int k0 = 0; k0 < K; k0 += RG) {
+                rows(ln, qn, min(k0 + RG, K - 1));
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int kk = 0; kk < RG; ++kk) {
+    #pragma unroll
+                    for (int h = 0; h < H; ++h) {
+                        const float al = k0 + kk < K ? s_e[h][k0 + kk] : 0.f;
+                        c4[h].x += al * l4[kk].x; c4[h].y += al * l4[kk].y; c4[h].z += al * l4[kk].z; c4[h].w += al * l4[kk].w;
+                        w4[h].x += al * q4[kk].x; w4[h].y += al * q4[kk].y; w4[h].z += al * q4[kk].z; w4[h].w += al * q4[kk].w;
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+    #pragma unroll
+                for (int kk = 0; kk < RG; ++kk) { l4[kk] = ln[kk]; q4[kk] = qn[kk]; }
             }
-        };
-        rows(l4, q4, 0);
-        for (int k0 = 0; k0 < K; k0 += RG) {
-            rows(ln, qn, min(k0 + RG, K - 1));
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) {
-#pragma unroll
-                for (int h = 0; h < H; ++h) {
-                    const float al = k0 + kk < K ? s_e[h][k0 + kk] : 0.f;
-                    c4[h].x += al * l4[kk].x; c4[h].y += al * l4[kk].y; c4[h].z += al * l4[kk].z; c4[h].w += al * l4[kk].w;
-                    w4[h].x += al * q4[kk].x; w4[h].y += al * q4[kk].y; w4[h].z += al * q4[kk].z; w4[h].w += al * q4[kk].w;
+            const float4 bl = HAS_LW ? ld4(a.blt + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    #pragma unroll
+            for (int h = 0; h < H; ++h) {
+                st4(a.CL + ((size_t)(b0 + h) * T + t) * D + 4 * d4, c4[h]);
+                if (HAS_LW) {
+                    float4 z = w4[h];
+                    z.x += bl.x; z.y += bl.y; z.z += bl.z; z.w += bl.w;
+                    pe[h] += dot4_tanh(z, ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 3 * D + 4 * d4), ld4(a.Ult + 4 * d4));
                 }
             }
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int kk = 0; kk < RG; ++kk) { l4[kk] = ln[kk]; q4[kk] = qn[kk]; }
         }
-        const float4 bl = LW ? ld4(a.blt + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            st4(a.CL + ((size_t)(b0 + h) * T + t) * D + 4 * d4, c4[h]);
-            if (LW) {
-                float4 z = w4[h];
-                z.x += bl.x; z.y += bl.y; z.z += bl.z; z.w += bl.w;
-                pe[h] += dot4_tanh(z, ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 3 * D + 4 * d4), ld4(a.Ult + 4 * d4));
-            }
-        }
-    }
+    };
+    if (LW) sums(std::true_type{}); else sums(std::false_type{});
     if (LW) {
         block_sum<H>(pe, s_red, tid);
 #pragma unroll

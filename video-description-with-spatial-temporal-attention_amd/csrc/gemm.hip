@@ -184,7 +184,20 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     };
     frags(0, sA, sB, 0);
 
-    // one tile; `RS` = register set that holds tile kt+1 on entry and receives tile kt+3's... (see call sites)
+    // One tile.  The non-MFMA instructions of every k-block are dealt out ONE BY ONE between its MFMAs
+    // (sched_group_barrier pipelines: a compile-time interleave), so each of them issues in the 64-clock shadow of the
+    // wave's own previous MFMA.  Issued as blocks ("all fragment reads, then 16 MFMAs, then 8 LDS writes + 8 global loads
+    // + their address arithmetic, ...", round 1-3) the wave offers the matrix pipe nothing for the length of a block,
+    // and its SIMD partner -- the wave of the co-resident workgroup, same code, same phase -- is in the same block at the
+    // same time: MfmaUtil 76-80 %.  Measured (tools/gemm_ab.sh, 128 x 128 tile): 4096^3 128.6 -> 137.7 TFLOP/s, TN
+    // 4096 x 1024 x 13312 128.0 -> 138.5; 64 x 64 tile + 2-5 %.  (Starting the co-resident workgroups out of phase with
+    // an s_sleep instead: no change.)  Quotas per MFMA: what the k-block has to place, divided by its MFMAs.
+    constexpr int NM = 4 * TM * TN;                                        // MFMAs of a k-block
+    constexpr int Q_DSR = (TM + 4 * TN + NM - 1) / NM;                     // fragment reads (b128 / 4 x b32 per fragment)
+    constexpr int Q_DSW = (4 * (TM + TN) + NM - 1) / NM;                   // LDS writes of the next tile (b128, at worst split in two)
+    constexpr int Q_VM = (2 * (TM + TN) + NM - 1) / NM;                    // global loads of tile kt + 3
+    constexpr int Q_VALU = (24 * (TM + TN) + NM - 1) / NM;                 // their address arithmetic (VALU + SALU)
+#define SGB(mask, n) __builtin_amdgcn_sched_group_barrier(mask, n, 0)
 #define STATTN_GEMM2_TILE(KT, RA_NEXT, RB_NEXT, RA_FAR, RB_FAR)                                              \
     {                                                                                                         \
         const int st = (KT) & 1;                                                                              \
@@ -192,31 +205,30 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
         const float* cB = sB + st * TB::ELEMS;                                                                \
         float* nA = sA + (st ^ 1) * TA::ELEMS;                                                                \
         float* nB = sB + (st ^ 1) * TB::ELEMS;                                                                \
-        /* k-block 0 */                                                                                       \
+        /* k-block 0 (fragments of k-block 1 requested under it) */                                           \
         frags(1, cA, cB, 1);                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(0);                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { SGB(0x8, 1); SGB(0x100, Q_DSR); }                 \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
-        /* k-block 1, then tile KT+1 (already in registers) goes to the other stage */                        \
+        /* k-block 1; tile KT+1 (already in registers: fetched two tiles ahead) goes to the other stage */    \
         frags(0, cA, cB, 2);                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(1);                                                                                             \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         TA::sstore(RA_NEXT, nA, tid);                                                                         \
         TB::sstore(RB_NEXT, nB, tid);                                                                         \
-        /* the freed register set starts fetching tile KT+3?  no: tile KT+2 lives in the FAR set; refill NEXT */\
+        _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { SGB(0x8, 1); SGB(0x100, Q_DSR); SGB(0x200, Q_DSW); } \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        /* k-block 2; the freed register set starts fetching tile KT+3 (tile KT+2 lives in the FAR set) */    \
         loadA(RA_NEXT, (KT) + 3);                                                                             \
         loadB(RB_NEXT, (KT) + 3);                                                                             \
-        /* k-block 2 (its fragments for k-block 3 are fetched BEFORE the barrier) */                          \
         frags(1, cA, cB, 3);                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(0);                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { SGB(0x8, 1); SGB(0x100, Q_DSR); SGB(0x6, Q_VALU); SGB(0x20, Q_VM); } \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         __syncthreads();                                                                                      \
-        /* k-block 3, with the first fragments of tile KT+1 already on their way */                           \
+        /* k-block 3, with the first fragments of tile KT+1 requested under it */                             \
         frags(0, nA, nB, 0);                                                                                  \
-        __builtin_amdgcn_sched_barrier(0);                                                                    \
         mfmas(1);                                                                                             \
+        _Pragma("unroll") for (int i_ = 0; i_ < NM; ++i_) { SGB(0x8, 1); SGB(0x100, Q_DSR); }                 \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
     }
 
@@ -233,6 +245,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     }
     if (kt < nk) STATTN_GEMM2_TILE(kt, ra1, rb1, ra0, rb0)
 #undef STATTN_GEMM2_TILE
+#undef SGB
 #ifdef STATTN_PROBES
     if (g.clk && lin == 0 && ky == 0 && tid == 0) {
         g.clk[2] = __builtin_readcyclecounter(); g.clk[3] = __builtin_amdgcn_s_memrealtime();

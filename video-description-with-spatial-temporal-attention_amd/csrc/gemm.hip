@@ -26,6 +26,8 @@ namespace {
 
 using namespace gemm_common;
 
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
 constexpr int BK = 32;
 constexpr int KPAD = BK + 4;
 
@@ -35,30 +37,49 @@ struct Tile {
     static constexpr int ELEMS = KC ? BR * KPAD : BK * BR;
     static constexpr int NF4 = BR * BK / 4 / 256;
 
-    // rows_total: extent of the "rows" dimension (M or N); K: extent of k.
-    // EDGE = false: K is a multiple of BK and a row-contiguous operand has no partial tile -> no predicates, no
-    // exec-mask branches around the loads (those make hipcc serialise the prefetch with vmcnt(0)).
-    template <bool EDGE = true>
-    __device__ static __forceinline__ void gload(float4 (&r)[NF4], const float* __restrict__ X, int ld,
-                                                 int r0, int rows_total, int k0, int K, int tid) {
+    // Addressing: per thread and 16-byte piece a LOOP-INVARIANT 32-bit byte offset from the tile's first row (offsets()),
+    // and per k-tile one wave-uniform base pointer, handed to a buffer load as its resource (scalar registers): no 64-bit
+    // vector arithmetic in the loop (it was ~60 VALU instructions per k-tile: half of the issue slots the 64 x 64 tile's
+    // four MFMAs of a k-block leave).  The resource is rebuilt per k-tile from the 64-bit base, so operands of any size
+    // work; only a tile's own extent (128 rows x ld x 4 bytes) has to stay below 4 GB.  Rows beyond rows_total are clamped to the last row (edge rows are never stored).
+    __device__ static __forceinline__ void offsets(unsigned (&off)[NF4], int ld, int r0, int rows_total, int tid) {
 #pragma unroll
         for (int i = 0; i < NF4; ++i) {
             const int idx = tid + i * 256;
             if constexpr (KC) {
                 const int rr = idx >> 3, kc = idx & 7;
                 int row = r0 + rr;
-                row = row < rows_total ? row : rows_total - 1;   // clamp: edge rows are never stored
-                const int k = k0 + 4 * kc;
-                if constexpr (EDGE) r[i] = (k < K) ? ld4(X + (size_t)row * ld + k) : make_float4(0.f, 0.f, 0.f, 0.f);
-                else r[i] = ld4(X + (size_t)row * ld + k);
+                row = row < rows_total ? row : rows_total - 1;
+                off[i] = ((unsigned)(row - r0) * (unsigned)ld + 4u * kc) * 4u;   // bytes
             } else {
                 constexpr int RCW = BR / 4;
                 const int k = idx / RCW, rc = idx % RCW;
-                const int gk = k0 + k, gr = r0 + 4 * rc;
-                if constexpr (EDGE) r[i] = (gk < K && gr < rows_total) ? ld4(X + (size_t)gk * ld + gr)
-                                                                       : make_float4(0.f, 0.f, 0.f, 0.f);
-                else r[i] = ld4(X + (size_t)gk * ld + gr);
+                off[i] = ((unsigned)k * (unsigned)ld + 4u * rc) * 4u;
             }
+        }
+    }
+    // uniform base of k-tile k0: KC rows start at X + r0 * ld + k0, RC rows at X + k0 * ld + r0
+    __device__ static __forceinline__ const float* tile_base(const float* X, int ld, int r0, int k0) {
+        if constexpr (KC) return X + (size_t)r0 * ld + k0;
+        else return X + (size_t)k0 * ld + r0;
+    }
+    // EDGE = false: K is a multiple of BK and a row-contiguous operand has no partial tile -> no predicates, no
+    // exec-mask branches around the loads (those make hipcc serialise the prefetch with vmcnt(0)).
+    template <bool EDGE = true>
+    __device__ static __forceinline__ void gload(float4 (&r)[NF4], const float* __restrict__ Xt, const unsigned (&off)[NF4],
+                                                 int r0, int rows_total, int k0, int K, int tid) {
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(Xt), 0, -1, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < NF4; ++i) {
+            bool ok = true;
+            if constexpr (EDGE) {
+                const int idx = tid + i * 256;
+                if constexpr (KC) ok = k0 + 4 * (idx & 7) < K;
+                else { constexpr int RCW = BR / 4; ok = k0 + idx / RCW < K && r0 + 4 * (idx % RCW) < rows_total; }
+            }
+            u32x4 v = u32x4{0u, 0u, 0u, 0u};
+            if (ok) v = __builtin_amdgcn_raw_buffer_load_b128(rs, off[i], 0, 0);
+            r[i] = make_float4(__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3]));
         }
     }
     __device__ static __forceinline__ void sstore(const float4 (&r)[NF4], float* s, int tid) {
@@ -147,16 +168,36 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     // counted vmcnt waits); the redundant tail loads hit L2
     auto ktile = [&](int t) { return kb + (t < nk ? t : (nk > 0 ? nk - 1 : 0)) * BK; };
 
-    // tile t of A / B into a register set; with a second operand pair the tiles at k >= K come from it (a uniform select)
+    // tile t of A / B into a register set; with a second operand pair the tiles at k >= K come from it (uniform selects)
+    unsigned offA[TA::NF4], offB[TB::NF4], offA2[TA::NF4], offB2[TB::NF4];
+    TA::offsets(offA, g.lda, m0, g.M, tid);
+    TB::offsets(offB, g.ldb, n0, g.N, tid);
+    if (g.A2) { TA::offsets(offA2, g.lda2, m0, g.M, tid); TB::offsets(offB2, g.ldb2, n0, g.N, tid); }
+    else {
+#pragma unroll
+        for (int i = 0; i < TA::NF4; ++i) offA2[i] = offA[i];
+#pragma unroll
+        for (int i = 0; i < TB::NF4; ++i) offB2[i] = offB[i];
+    }
     auto loadA = [&](float4 (&r)[TA::NF4], int t) {
         const int k = ktile(t);
         const bool second = g.A2 && k >= g.K;
-        TA::template gload<EDGE>(r, second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, g.M, second ? k - g.K : k, second ? ke - g.K : ke, tid);
+        const int kk = second ? k - g.K : k;
+        const float* Xt = TA::tile_base(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, kk);
+        unsigned off[TA::NF4];
+#pragma unroll
+        for (int i = 0; i < TA::NF4; ++i) off[i] = second ? offA2[i] : offA[i];
+        TA::template gload<EDGE>(r, Xt, off, m0, g.M, kk, second ? ke - g.K : ke, tid);
     };
     auto loadB = [&](float4 (&r)[TB::NF4], int t) {
         const int k = ktile(t);
         const bool second = g.A2 && k >= g.K;
-        TB::template gload<EDGE>(r, second ? g.B2 : g.B, second ? g.ldb2 : g.ldb, n0, g.N, second ? k - g.K : k, second ? ke - g.K : ke, tid);
+        const int kk = second ? k - g.K : k;
+        const float* Xt = TB::tile_base(second ? g.B2 : g.B, second ? g.ldb2 : g.ldb, n0, kk);
+        unsigned off[TB::NF4];
+#pragma unroll
+        for (int i = 0; i < TB::NF4; ++i) off[i] = second ? offB2[i] : offB[i];
+        TB::template gload<EDGE>(r, Xt, off, n0, g.N, kk, second ? ke - g.K : ke, tid);
     };
     loadA(ra0, 0);
     loadB(rb0, 0);

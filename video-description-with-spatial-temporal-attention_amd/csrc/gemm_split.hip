@@ -265,6 +265,21 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
     // eight waves of a CU serialised on the LDS right after each barrier: 374 -> 285 TFLOP/s on the MFMA-only loop):
     // regions 0-3 each fetch one of the four operand rows/columns of the NEXT tile (3 reads) and split + store one
     // piece of tile kt + 2 (3 writes); regions 4-5 carry the global loads of tile kt + 4.
+// the side work of a region dealt out between its MFMAs instead of issued in front of them (sched_group_barrier pipeline,
+// as in gemm.hip; here + 1-3 %: dW_local 203.9 -> 208, dWo 159 -> 164, CL.Wclt 94 -> 101 TFLOP/s -- this kernel is bound by its LDS
+// store path and the clock it can hold, section 12 of DESIGN.md).  -DGS_SGB=0 is the A/B build (tools/build_gemm_var.sh).
+#ifndef GS_SGB
+#define GS_SGB 1
+#define GS_SGB_VALU 6
+#endif
+#if GS_SGB
+#define STATTN_GEMM3_DEAL _Pragma("unroll") for (int i_ = 0; i_ < MT * NT; ++i_) {                                \
+        __builtin_amdgcn_sched_group_barrier(0x8, 1, 0); __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);   \
+        __builtin_amdgcn_sched_group_barrier(0x2, GS_SGB_VALU, 0); __builtin_amdgcn_sched_group_barrier(0x200, 1, 0); \
+        __builtin_amdgcn_sched_group_barrier(0x20, 2, 0); }
+#else
+#define STATTN_GEMM3_DEAL
+#endif
 #define STATTN_GEMM3_TILE(KT, FA, FB, FA_NEXT, FB_NEXT, RA, RB)                                               \
     {                                                                                                         \
         const unsigned char* cA = smem + rd * STAGE;                                                          \
@@ -276,26 +291,32 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
         if constexpr (LD) TA::frag(FA_NEXT[0], cA, wm * 32 * MT + l31, kh);                                   \
         if constexpr (ST) TA::template sstore_part<0>(RA, wA, tid);                                           \
         STATTN_GEMM3_MFMAS(FA, FB, 0, 1)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (LD && MT > 1) TA::frag(FA_NEXT[MT - 1], cA, wm * 32 * MT + (MT - 1) * 32 + l31, kh);    \
         if constexpr (ST) TA::template sstore_part<1>(RA, wA, tid);                                           \
         STATTN_GEMM3_MFMAS(FA, FB, 1, 2)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (LD) TB::frag(FB_NEXT[0], cB, wn * 32 * NT + l31, kh);                                   \
         if constexpr (ST) TB::template sstore_part<0>(RB, wB, tid);                                           \
         STATTN_GEMM3_MFMAS(FA, FB, 2, 3)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (LD && NT > 1) TB::frag(FB_NEXT[NT - 1], cB, wn * 32 * NT + (NT - 1) * 32 + l31, kh);    \
         if constexpr (ST) TB::template sstore_part<1>(RB, wB, tid);                                           \
         STATTN_GEMM3_MFMAS(FA, FB, 3, 4)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (GL) TA::template gload<EDGE>(RA, rsA, offA, g.lda, m0, g.M, ktile((KT) + 4), ke, tid);        \
         if constexpr (GS_VARIANT == 8) { _Pragma("unroll") for (int q = 0; q < TA::NR; ++q) RA[q] *= 1.0001f; }       \
         STATTN_GEMM3_MFMAS(FA, FB, 4, 5)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         if constexpr (GL) TB::template gload<EDGE>(RB, rsB, offB, g.ldb, n0, g.N, ktile((KT) + 4), ke, tid);        \
         if constexpr (GS_VARIANT == 8) { _Pragma("unroll") for (int q = 0; q < TB::NR; ++q) RB[q] *= 1.0001f; }       \
         STATTN_GEMM3_MFMAS(FA, FB, 5, 6)                                                                      \
+        STATTN_GEMM3_DEAL                                                                                     \
         __builtin_amdgcn_sched_barrier(0);                                                                    \
         rd = rd == 2 ? 0 : rd + 1;                                                                            \
         wr = wr == 2 ? 0 : wr + 1;                                                                            \
@@ -309,6 +330,7 @@ __device__ __forceinline__ void gemm3_body(const GemmArgs& g, const int lin, con
         STATTN_GEMM3_TILE(kt + 1, a1, b1, a0, b0, ra1, rb1)
     }
 #undef STATTN_GEMM3_TILE
+#undef STATTN_GEMM3_DEAL
 #undef STATTN_GEMM3_MFMAS
 #ifdef STATTN_PROBES
     if (g.clk && lin == 0 && ky == 0 && tid == 0) {

@@ -508,8 +508,8 @@ def beam_bench(args, c, options, params, dec, batch, rank, world, dist):
         dist.destroy_process_group()
 
 
-TRAFFIC_KERNELS = {"gemm_nn": ("gemm2_group_kernel<1, 1, false, false, false>", "gemm2_group_kernel<2, 2, false, false, false>",
-                               "gemm2_kernel<1, 1, false, false, false>", "gemm2_kernel<2, 2, false, false, false>",
+TRAFFIC_KERNELS = {"gemm_nn": ("gemm2_group_kernel<1, 1, false, false, false", "gemm2_group_kernel<2, 2, false, false, false",
+                               "gemm2_kernel<1, 1, false, false, false", "gemm2_kernel<2, 2, false, false, false",
                                "gemm3_group_kernel", "gemm3_kernel"),
                    "spatial": ("spatial2_kernel<128>", "spatial_kernel", "spatial_bf16_kernel"),
                    "spatial_bwd": ("spatial_bwd_kernel",), "temporal": ("temporal_kernel",), "ctxgrad": ("ctxgrad_kernel",)}

@@ -35,8 +35,8 @@ def bench_traffic(fetch_csv, write_csv, out_json, keys):
     A class may span several kernel symbols (the plain forward GEMM launches are gemm2_group_kernel and gemm2_kernel
     instances): launch-weighted mean over all of them."""
     import json
-    pats = {"gemm_nn": ["gemm2_group_kernel<1, 1, false, false, false>", "gemm2_group_kernel<2, 2, false, false, false>",
-                        "gemm2_kernel<1, 1, false, false, false>"],
+    pats = {"gemm_nn": ["gemm2_group_kernel<1, 1, false, false, false", "gemm2_group_kernel<2, 2, false, false, false",
+                        "gemm2_kernel<1, 1, false, false, false"],
             "spatial": ["spatial2_kernel<128>"], "temporal": ["temporal_kernel"]}
 
     def total(path, plist, idx):

@@ -121,7 +121,8 @@ struct Tile {
 // before that barrier (their k-block-3 fragments are fetched during k-block 2); stage s^1 is read (k-block 3)
 // only after barrier(kt), which follows every wave's write.
 // `lin`: linear tile index of this workgroup within the problem (after the XCD remap); `ky`: its K slice (split-K).
-template <int TM, int TN, bool AT, bool BT, bool EDGE>
+// PAIR: the launch carries a second operand pair (C = A.B + A2.B2, K-concatenated); without it the selects between the pairs are compiled out
+template <int TM, int TN, bool AT, bool BT, bool EDGE, bool PAIR>
 __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, const int ky) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = Tile<BM, !AT>;
@@ -150,7 +151,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int Kt = g.K + (g.A2 ? g.K2 : 0);          // K-concatenated second operand pair (NN only)
+    const int Kt = g.K + (PAIR && g.A2 ? g.K2 : 0);  // K-concatenated second operand pair (NN / NT)
     int kb = 0, ke = Kt;
     float* Cout = g.C;
     int ldc = g.ldc;
@@ -172,7 +173,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     unsigned offA[TA::NF4], offB[TB::NF4], offA2[TA::NF4], offB2[TB::NF4];
     TA::offsets(offA, g.lda, m0, g.M, tid);
     TB::offsets(offB, g.ldb, n0, g.N, tid);
-    if (g.A2) { TA::offsets(offA2, g.lda2, m0, g.M, tid); TB::offsets(offB2, g.ldb2, n0, g.N, tid); }
+    if (PAIR && g.A2) { TA::offsets(offA2, g.lda2, m0, g.M, tid); TB::offsets(offB2, g.ldb2, n0, g.N, tid); }
     else {
 #pragma unroll
         for (int i = 0; i < TA::NF4; ++i) offA2[i] = offA[i];
@@ -181,7 +182,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     }
     auto loadA = [&](float4 (&r)[TA::NF4], int t) {
         const int k = ktile(t);
-        const bool second = g.A2 && k >= g.K;
+        const bool second = PAIR && g.A2 && k >= g.K;
         const int kk = second ? k - g.K : k;
         const float* Xt = TA::tile_base(second ? g.A2 : g.A, second ? g.lda2 : g.lda, m0, kk);
         unsigned off[TA::NF4];
@@ -191,7 +192,7 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     };
     auto loadB = [&](float4 (&r)[TB::NF4], int t) {
         const int k = ktile(t);
-        const bool second = g.A2 && k >= g.K;
+        const bool second = PAIR && g.A2 && k >= g.K;
         const int kk = second ? k - g.K : k;
         const float* Xt = TB::tile_base(second ? g.B2 : g.B, second ? g.ldb2 : g.ldb, n0, kk);
         unsigned off[TB::NF4];
@@ -296,9 +297,9 @@ __device__ __forceinline__ void gemm2_body(const GemmArgs& g, const int lin, con
     epilogue<TM, TN>(g, acc, m0, n0, wm, wn, l31, kh, Cout, ldc);
 }
 
-template <int TM, int TN, bool AT, bool BT, bool EDGE>
+template <int TM, int TN, bool AT, bool BT, bool EDGE, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
-    gemm2_body<TM, TN, AT, BT, EDGE>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
+    gemm2_body<TM, TN, AT, BT, EDGE, PAIR>(g, xcd_linear(blockIdx.x, gridDim.x, g.xcd_remap), blockIdx.y);
 }
 
 // Several independent problems in one launch (same transposes, no split-K): the tiles of the small ones fill the
@@ -308,11 +309,11 @@ __global__ __launch_bounds__(256, 2) void gemm2_kernel(const GemmArgs g) {
 // its share of problem 0, then of problem 1, ...), so each XCD gets the same mix of long-K and short-K tiles and the
 // short ones fill its tail.  (One contiguous run of the concatenated tile list per XCD left the XCDs that drew the
 // K = 4096 tiles working 40 % longer than the others.)
-template <int TM, int TN, bool AT, bool BT, bool EDGE>
+template <int TM, int TN, bool AT, bool BT, bool EDGE, bool PAIR>
 __global__ __launch_bounds__(256, 2) void gemm2_group_kernel(const GemmGroup G) {
     int p, lin;
     if (!group_locate(G, blockIdx.x, p, lin)) return;                // padding block of this XCD
-    gemm2_body<TM, TN, AT, BT, EDGE>(G.g[p], lin, 0);
+    gemm2_body<TM, TN, AT, BT, EDGE, PAIR>(G.g[p], lin, 0);
 }
 
 // C[i] (+)= alpha * sum_z ws[z][i]   (fixed summation order: deterministic)
@@ -375,14 +376,14 @@ hipError_t launch_cfg(hipStream_t s, const GemmArgs& g, bool tA, bool tB) {
         const bool edge = (Kt % BK != 0) || (g.kslices > 1 && (size_t)per * (g.kslices - 1) >= (size_t)Kt) ||
                           (tA && g.M % BM != 0);
         if (edge) {
-            if (!tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, true>), grid, block, 0, s, g);
-            else if (!tA && tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, true>), grid, block, 0, s, g);
-            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, true>), grid, block, 0, s, g);
+            if (!tA && !tB) { if (g.A2) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, true, true>), grid, block, 0, s, g); else hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, true, false>), grid, block, 0, s, g); }
+            else if (!tA && tB) { if (g.A2) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, true, true>), grid, block, 0, s, g); else hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, true, false>), grid, block, 0, s, g); }
+            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, true, false>), grid, block, 0, s, g);
             else return hipErrorInvalidValue;
         } else {
-            if (!tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, false>), grid, block, 0, s, g);
-            else if (!tA && tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, false>), grid, block, 0, s, g);
-            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, false>), grid, block, 0, s, g);
+            if (!tA && !tB) { if (g.A2) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, false, true>), grid, block, 0, s, g); else hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, false, false, false>), grid, block, 0, s, g); }
+            else if (!tA && tB) { if (g.A2) hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, false, true>), grid, block, 0, s, g); else hipLaunchKernelGGL((gemm2_kernel<TM, TN, false, true, false, false>), grid, block, 0, s, g); }
+            else if (tA && !tB) hipLaunchKernelGGL((gemm2_kernel<TM, TN, true, false, false, false>), grid, block, 0, s, g);
             else return hipErrorInvalidValue;
         }
     }
@@ -444,7 +445,7 @@ hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, b
     constexpr int BM = 64 * TM, BN = 64 * TN;
     GemmGroup G{};
     static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
-    bool edge = false;
+    bool edge = false, pair = false;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
         GemmArgs g = gs[i];
@@ -452,6 +453,7 @@ hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, b
         if (g.A2 && (tA || g.K % BK != 0 || g.K2 % BK != 0 || g.K2 <= 0)) return hipErrorInvalidValue;   // second operand pair: NN / NT, whole k-tiles
         g.kslices = 1; g.ws = nullptr; g.xcd_remap = noremap ? 0 : 1; g.clk = nullptr;
         edge = edge || g.K % BK != 0 || (tA && g.M % BM != 0);
+        pair = pair || g.A2 != nullptr;
         G.g[i] = g;
         G.tile_start[i] = tiles;
         tiles += ((g.M + BM - 1) / BM) * (g.N / BN);
@@ -461,14 +463,14 @@ hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, b
     for (int i = 0; i < n; ++i) per_xcd += (G.tile_start[i + 1] - G.tile_start[i] + NXCD - 1) / NXCD;
     const dim3 grid(per_xcd * NXCD);
     if (tA) {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, false>), grid, dim3(256), 0, s, G);
+        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, true, false>), grid, dim3(256), 0, s, G);
+        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, true, false, false, false>), grid, dim3(256), 0, s, G);
     } else if (tB) {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, false>), grid, dim3(256), 0, s, G);
+        if (edge) { if (pair) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, true, true>), grid, dim3(256), 0, s, G); else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, true, false>), grid, dim3(256), 0, s, G); }
+        else { if (pair) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, false, true>), grid, dim3(256), 0, s, G); else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, true, false, false>), grid, dim3(256), 0, s, G); }
     } else {
-        if (edge) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, true>), grid, dim3(256), 0, s, G);
-        else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, false>), grid, dim3(256), 0, s, G);
+        if (edge) { if (pair) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, true, true>), grid, dim3(256), 0, s, G); else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, true, false>), grid, dim3(256), 0, s, G); }
+        else { if (pair) hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, false, true>), grid, dim3(256), 0, s, G); else hipLaunchKernelGGL((gemm2_group_kernel<TM, TN, false, false, false, false>), grid, dim3(256), 0, s, G); }
     }
     return hipGetLastError();
 }

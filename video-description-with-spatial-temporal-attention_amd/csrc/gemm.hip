@@ -554,6 +554,11 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
         }
         if (t11 < 768 && Kt >= 1024) {
             int ks = (1024 + t11 - 1) / t11;
+            // 1024 workgroups are resident at once (four per CU): a slice count whose grid overshoots that by a fraction runs
+            // a nearly empty second round (da = dlogit.Wo^T, 240 tiles: 5 slices = 1200 workgroups) -- round down when that
+            // still fills the chip
+            static const char* ceil_rule = getenv("STATTN_SPLITK_CEIL");   // A/B switch for tools: the rule of rounds 1-3
+            if (!ceil_rule && ks * t11 > 1024 && (ks - 1) >= 2 && (ks - 1) * t11 >= 832) --ks;
             static const char* fks = getenv("STATTN_FWD_KS");            // tools: slice count of epilogue-carrying split-K launches
             if (epi && fks) ks = atoi(fks);
             else if (ks > Kt / 512) ks = Kt / 512;

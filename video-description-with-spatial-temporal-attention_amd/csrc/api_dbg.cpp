@@ -1,4 +1,5 @@
 // Development entry points (csrc/stattn_dbg.h): kernels run and timed in isolation by tests/ and tools/.
+#include <cstdlib>
 #include "steps.h"
 #include "stattn_dbg.h"
 
@@ -121,12 +122,28 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     for (int i = 0; i < 2; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
     hipEvent_t a, b;
     HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
-    HIPCHK(h, hipEventRecord(a, s));
-    for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
-    HIPCHK(h, hipEventRecord(b, s));
-    HIPCHK(h, hipEventSynchronize(b));
     float ms = 0.f;
-    HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    static const char* cold = getenv("STATTN_DBG_COLD");   // tools: every timed launch behind a 1 GB fill (operands out of L2 and the Infinity Cache, dirty lines in both)
+    if (cold) {
+        float* scr;
+        CHK(getbuf_t(h, "dbg_cold", (size_t)256 << 20, &scr));
+        for (int i = 0; i < iters; ++i) {
+            HIPCHK(h, launch_uniform(s, scr, (size_t)256 << 20, 11, 3 + i));
+            HIPCHK(h, hipEventRecord(a, s));
+            HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+            HIPCHK(h, hipEventRecord(b, s));
+            HIPCHK(h, hipEventSynchronize(b));
+            float t = 0.f;
+            HIPCHK(h, hipEventElapsedTime(&t, a, b));
+            ms += t;
+        }
+    } else {
+        HIPCHK(h, hipEventRecord(a, s));
+        for (int i = 0; i < iters; ++i) HIPCHK(h, launch_gemm(s, g, transA != 0, transB != 0));
+        HIPCHK(h, hipEventRecord(b, s));
+        HIPCHK(h, hipEventSynchronize(b));
+        HIPCHK(h, hipEventElapsedTime(&ms, a, b));
+    }
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
     *ms_per_launch = ms / iters;
     return STATTN_OK;

@@ -39,6 +39,9 @@ CONFIGS = {
     # rows between the 64-row panel kernels and the wide ones (where each row-panel kernel takes over: csrc/panelw.hip)
     "c2b80": dict(B=80, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
     "c2b96": dict(B=96, T=26, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    # (row, frame) items of the attention kernels against their resident workgroups: 1024 / 2048 items instead of 1664
+    "c2t16": dict(B=64, T=16, K=8, F=4096, D=1024, E=512, V=12000, t=30),
+    "c2t32": dict(B=64, T=32, K=8, F=4096, D=1024, E=512, V=12000, t=30),
     # configs[1] with the reference's real vocabulary (config.py:35)
     "c2v20k": dict(B=64, T=26, K=8, F=4096, D=1024, E=512, V=20000, t=30),
     # BASELINE.json configs[1] "Single MI355X" / configs[2] per-GPU shard

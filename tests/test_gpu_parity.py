@@ -590,6 +590,64 @@ def test_c1_greedy_gen_sample_full_vocabulary(stattn_mod, O):
         assert res[v][0] == s2
 
 
+def test_one_hypothesis_update_rides_in_the_next_attention_launch(stattn_mod, O, monkeypatch):
+    """One-hypothesis decode (k = 1, greedy and ancestral sampling): the bookkeeping of word w runs as an extra workgroup of the
+    attention launch of word w + 1 (five launches per word).  Same captions, scores and final states, bit for bit, as the six-launch
+    word (STATTN_NO_UPDATE_RIDER=1), with and without <eos> deaths, one video and several; the path counter shows which one ran."""
+    dims = dict(dim=128, dim_word=64, n_words=500, ctxg_dim=128, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=128)
+    opt = O.default_options(**dims)
+    for seed, eos_shift in ((3, -10.0), (4, 3.0)):
+        P = O.random_params(opt, seed=seed, dtype=np.float32)
+        P['ff_logit_b'] = (P['ff_logit_b'] + 0.5 * np.random.RandomState(seed).standard_normal(500)).astype(np.float32)
+        P['ff_logit_b'][0] += eos_shift              # second round: captions end early, at different words per video
+        b = O.synthetic_batch(opt, B=5, T=7, K=4, t=3, seed=60 + seed)
+        model = stattn_mod.Attention()
+        tparams = model.init_tparams(P)
+        f_init, f_next = model.build_sampler(tparams, opt, None, None)
+        dec = f_next.decoder
+        out = {}
+        for ride in (True, False):
+            if ride:
+                monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+            else:
+                monkeypatch.setenv('STATTN_NO_UPDATE_RIDER', '1')
+            res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=1, maxlen=12)
+            n_b = dec.path_counts()['upd_rider']
+            v = 2
+            args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+            one = model.gen_sample(tparams, f_init, f_next, *args, opt, None, 1, maxlen=12)
+            n_1 = dec.path_counts()['upd_rider']
+            assert (n_b > 0 and n_1 > 0) if ride else (n_b == 0 and n_1 == 0)
+            out[ride] = (res, one)
+        (ra, oa), (rb, ob) = out[True], out[False]
+        assert [r[0] for r in ra] == [r[0] for r in rb]
+        for x, y in zip(ra, rb):
+            assert np.array_equal(np.asarray(x[1], np.float32), np.asarray(y[1], np.float32))
+        assert oa[0] == ob[0] and oa[0] == ra[2][0]
+        assert np.array_equal(np.asarray(oa[1], np.float32), np.asarray(ob[1], np.float32))
+        for x, y in zip(oa[2] + oa[3], ob[2] + ob[3]):
+            assert np.array_equal(x, y)
+        if eos_shift > 0:
+            assert min(len(r[0][0]) for r in ra) < 12
+    # ancestral sampling on the device: same draws (the seed sequence of a handle is its call count)
+    P = O.random_params(opt, seed=9, dtype=np.float32)
+    draws = {}
+    for ride in (True, False):
+        if ride:
+            monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+        else:
+            monkeypatch.setenv('STATTN_NO_UPDATE_RIDER', '1')
+        model = stattn_mod.Attention()
+        tparams = model.init_tparams(P)
+        f_init, f_next = model.build_sampler(tparams, opt, None, None)
+        v = 1
+        args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+        draws[ride] = [model.gen_sample(tparams, f_init, f_next, *args, opt, None, 1, maxlen=10, stochastic=True) for _ in range(3)]
+        assert (f_next.decoder.path_counts()['upd_rider'] > 0) == ride
+    for x, y in zip(draws[True], draws[False]):
+        assert x[0] == y[0] and np.array_equal(np.asarray(x[1], np.float32), np.asarray(y[1], np.float32))
+
+
 # ------------------------------------------------------------------ robustness
 def test_changing_batch_shapes_and_relu_like_features(stattn_mod, O):
     """Consecutive minibatches of different (t, m, T, K) on one handle (device buffers grow and are re-used), and

@@ -190,6 +190,7 @@ long stattn_dbg_counter(const stattn_handle* h, int which) {
     if (which == 2) return h->path_fwd_panel;
     if (which == 3) return h->path_bwd_rider;
     if (which == 4) return h->path_bwd_panel;
+    if (which == 5) return h->path_upd_rider;
     return -1;
 }
 

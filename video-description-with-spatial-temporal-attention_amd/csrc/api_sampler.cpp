@@ -432,7 +432,19 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // and the readout launch writes the next word's state projections where the attention kernel will read them: beam_update has
     // no state / projection rows to move (its gathers were 2.9 of its 9.6 us at configs[0]).
     const bool direct = small && k == 1;
-    auto enqueue_word = [&](int parity) -> int {
+    // ... and the update itself leaves the critical path: the attention of word w + 1 reads the projections the readout launch of word w
+    // wrote, never the chosen word, so the bookkeeping of word w runs as one more workgroup of THAT launch (attn.hip
+    // spatial_small_update_kernel) and the word loop is  T L R G [S(w + 1) | U(w)]  behind one S(0): five launches per word.
+    // The attention behind the last word is computed for nothing.  STATTN_NO_UPDATE_RIDER=1: the six-launch word (A/B, tests).
+    bool ride = false;
+    if (direct) {
+        const char* noride = getenv("STATTN_NO_UPDATE_RIDER");        // (read on every call: tests switch it inside one process)
+        SpatialArgs probe{};
+        probe.M = M; probe.T = T; probe.K = K; probe.D = D; probe.group = k;
+        ride = !noride && spatial_update_supported(probe);
+    }
+    h->path_upd_rider = 0;
+    auto step_io = [&]() {
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
         io.h_prev = hp; io.c_prev = cp; io.sproj = sproj; io.preh = preh; io.xproj = nullptr; io.emb = emb;
@@ -445,6 +457,11 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         if (small) {       // projections of this word are in `proj` ([sproj | preh] per row); the LSTM also packs the new h
             io.skip_hproj = true; io.sproj = proj; io.preh = proj + (size_t)4 * D; io.ldproj = 8 * D; io.h_out_pk = ho_pk;
         }
+        return io;
+    };
+    auto enqueue_word = [&](int parity) -> int {
+        StepIO io = step_io();
+        io.phase = ride ? 2 : 0;
         CHK(run_step(h, io));
         std::unique_ptr<Prof> pro(new Prof(h, KC_READOUT));        // readout + vocabulary launch (+ softmax) of this word
         if (small) {       // readout layer 1 + the next word's state projections (before the beam is re-ordered), then logits -> statistics
@@ -527,9 +544,19 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         }
+        if (ride) {        // the next word's attention launch carries this word's update
+            io.phase = 1; io.upd = &ba;
+            CHK(run_step(h, io));
+            return STATTN_OK;
+        }
         HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
+    if (ride) {            // attention of the first word
+        StepIO io = step_io();
+        io.phase = 1;
+        CHK(run_step(h, io));
+    }
 
     // The launch-bound inner loop is captured once as hipGraphs of EIGHT and of TWO words (even + odd parity alternate)
     // and replayed -- a replay costs 10-16 us of host / front-end time whatever it holds, so the long graph carries the
@@ -539,7 +566,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
     h->beam_graph_replays = 0;
     // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
-    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed,
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride,
                                   (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
     for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
                           (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,
@@ -607,6 +634,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         }
     }
     if (rc_loop != STATTN_OK) return rc_loop;
+    h->path_upd_rider = ride ? steps_run : 0;      // (replayed graphs included)
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
         const int fb = steps_run & 1;     // buffers written by the last executed step

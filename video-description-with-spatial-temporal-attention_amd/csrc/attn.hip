@@ -20,6 +20,7 @@
 
 #include "devmath.h"
 #include "panel_inl.h"
+#include "beam_inl.h"
 
 #include <cstdlib>
 
@@ -280,7 +281,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
 // a lane requests EVERYTHING it will ever need -- its column of PL, L and LW for all K <= 8 regions, 24 float4 -- in one
 // burst and the kernel is a single memory round trip (the kernels above wait for the softmax before they ask for L / LW).
 // One float4 column per lane: D <= 4 * blockDim.
-__global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a) {
+__device__ __forceinline__ void spatial_small_body(const SpatialArgs& a) {
     __shared__ float s_red[4 * 10];
     const int T = a.T, K = a.K, D = a.D;
     const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
@@ -345,6 +346,18 @@ __global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a)
         __syncthreads();
         if (tid == 0) { float r = 0.f; for (int q = 0; q < nw; ++q) r += s_red[q]; a.elt[bt] = r + clt0; }
     }
+}
+
+__global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a) { spatial_small_body(a); }
+
+// One-hypothesis decode (greedy, ancestral sampling): the same kernel, plus u.nvid extra workgroups that run the beam bookkeeping
+// of the PREVIOUS word (beam_inl.h: arg-max / draw over the vocabulary statistics, log-sum-exp, token, score, <eos>, the chosen
+// word's embedding for this word's LSTM launch).  The attention of a word reads the state projections the readout launch left,
+// never the chosen word: as a launch of its own the update was 8.9 of the 42.5 us of a configs[0] word.
+__global__ __launch_bounds__(256) void spatial_small_update_kernel(const SpatialArgs a, const BeamArgs u) {
+    const int items = a.M * a.T;
+    if ((int)blockIdx.x >= items) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x - items, u.nvid); return; }
+    spatial_small_body(a);
 }
 
 template <int NT>
@@ -771,7 +784,21 @@ bool spatial_rider_supported(const SpatialArgs& a) {
     return !norider && (a.bf16 || !spatial_shared_path(a)) && a.D % 1024 == 0 && !v1;
 }
 
-hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
+static bool spatial_small_path(const SpatialArgs& a) {
+    static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
+    return !nosm && !a.bf16 && !spatial_shared_path(a) && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024;
+}
+bool spatial_update_supported(const SpatialArgs& a) { return a.M > 0 && a.K >= 1 && a.D % 4 == 0 && spatial_small_path(a); }
+
+hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* upd) {
+    if (upd) {
+        if (!spatial_update_supported(a) || !upd->stats || !upd->ticket || upd->nvid < 1 || upd->ntile < 1 || upd->k > PN_STATS_KB ||
+            (upd->stochastic && (upd->k != 1 || upd->tile_cols < 1)) || (upd->proj_next && (!upd->proj_step || upd->nproj % 4)))
+            return hipErrorInvalidValue;
+        const int nt = ((a.D / 4 + 63) / 64) * 64;
+        hipLaunchKernelGGL(spatial_small_update_kernel, dim3(a.M * a.T + upd->nvid), dim3(nt), 0, s, a, *upd);
+        return hipGetLastError();
+    }
     if (a.M <= 0) return hipSuccess;
     if (a.K > KMAX || a.K < 1 || a.D % 4 != 0) return hipErrorInvalidValue;
     if (a.rider.nblocks && (!spatial_rider_supported(a) || !rider_shape_ok(a.rider))) return hipErrorInvalidValue;
@@ -797,10 +824,9 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a) {
         return hipGetLastError();
     }
     // a grid that does not fill the chip (decode with a handful of rows): the single-round-trip kernel
-    static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
     // (on a grid that fills the chip it loses: 38 us against 33 at configs[1] -- three resident workgroups per CU with one
     // round trip each move fewer bytes than eight with three)
-    if (!nosm && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024) {
+    if (spatial_small_path(a)) {
         const int nt = ((a.D / 4 + 63) / 64) * 64;
         hipLaunchKernelGGL(spatial_small_kernel, dim3(a.M * a.T), dim3(nt), 0, s, a);
         return hipGetLastError();

@@ -252,7 +252,12 @@ struct SpatialArgs {
     int M, T, K, D;
     RiderArgs rider;   // optional GEMM computed by extra workgroups of this launch (fp32 per-row kernels only)
 };
-hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a);
+struct BeamArgs;
+// upd (optional; one-hypothesis decode on the single-round-trip kernel only, spatial_update_supported): the beam bookkeeping of the
+// PREVIOUS word runs as upd->nvid extra workgroups of this launch -- the attention of a word needs the new state projections but
+// neither the chosen word nor its embedding, so the update leaves the critical path of the word loop
+hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* upd = nullptr);
+bool spatial_update_supported(const SpatialArgs& a);
 bool spatial_rider_supported(const SpatialArgs& a);   // would launch_spatial pick a kernel that can carry a rider?
 
 // elt[r] = dot(P[r,:], U) + c   (lt_mode 0, after the CL.Wclt GEMM with fused tanh)

@@ -22,7 +22,8 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
 /* Debug counters.  which = 0: hipGraph replays (two decoded words each) in the last stattn_beam_search
  * -- 0 means the word sequence was launched eagerly (capture refused, profiling on, STATTN_BEAM_NOGRAPH).
  * which = 1 / 2: decoder steps since the last stattn_forward_train began whose attention launch carried the h.U rider /
- * that ran on the row-panel kernels; which = 3 / 4: the same for the reverse steps of the last stattn_backward (dhU rider). */
+ * that ran on the row-panel kernels; which = 3 / 4: the same for the reverse steps of the last stattn_backward (dhU rider);
+ * which = 5: words of the last stattn_beam_search / stattn_sample_search whose bookkeeping rode in the next word's attention launch. */
 long stattn_dbg_counter(const stattn_handle* h, int which);
 /* The bf16-MFMA kernel (stattn_dbg_gemm kind=2 checks it: operands are rounded to bf16 on the device,
  * fp32 accumulation) on device-resident random data, bf16 output.  tile: 0 = the launcher's choice,

@@ -285,8 +285,9 @@ int run_step(stattn_handle* h, const StepIO& io) {
     sa.M = io.M; sa.T = io.T; sa.K = io.K; sa.D = D;
     const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && !io.skip_hproj && spatial_rider_supported(sa);
     const int ldp = io.ldproj ? io.ldproj : 4 * D;
-    h->path_fwd_rider += rider; h->path_fwd_panel += io.pn != nullptr;
-    if (io.skip_hproj) {
+    if (io.phase != 2) { h->path_fwd_rider += rider; h->path_fwd_panel += io.pn != nullptr; }
+    if (io.upd && (io.phase != 1 || !io.skip_hproj)) return fail(h, STATTN_EINVAL, "run_step: an update rider needs phase 1 of a step with its projections in place");
+    if (io.phase == 2 || io.skip_hproj) {
     } else if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
         Prof pr(h, KC_HPROJ);
         PnArgs a{};
@@ -320,7 +321,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         if (io.xproj) { s.add = io.xproj; s.ldadd = 4 * D; }
         HIPCHK(h, launch_skinny(h->stream, a));
     }
-    {   // spatial attention + frame scores (:371-383, 389-397, 402-410, and 415-424 in lt_mode 1)
+    if (io.phase != 2) {   // spatial attention + frame scores (:371-383, 389-397, 402-410, and 415-424 in lt_mode 1)
         Prof pr(h, KC_SPATIAL);
         SpatialArgs a{};
         a.PL = io.c.PL; a.L = io.c.L; a.LW = h->opt.lt_mode == 1 ? io.c.LW : nullptr;
@@ -338,8 +339,10 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.Ult = w.Ult; a.clt = w.clt; a.blt = w.blt;
         a.alphal = io.alphal; a.CL = io.CL; a.eg = io.eg; a.em = io.em; a.elt = io.elt;
         a.M = io.M; a.T = io.T; a.K = io.K; a.D = D;
-        HIPCHK(h, launch_spatial(h->stream, a));
+        if (io.upd && !spatial_update_supported(a)) return fail(h, STATTN_EINVAL, "run_step: this attention launch cannot carry the update");
+        HIPCHK(h, launch_spatial(h->stream, a, io.upd));
     }
+    if (io.phase == 1) return STATTN_OK;
     if (h->opt.lt_mode == 0) {   // pctxlt = CL.Wclt + blt + pstatelt, tanh, . Ult  (:416-422) as one MFMA GEMM
         Prof pr(h, KC_LTGEMM);
         GemmArgs g;

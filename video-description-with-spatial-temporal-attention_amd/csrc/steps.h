@@ -69,6 +69,9 @@ struct StepIO {
     float *h_out_pk, *ctx_pk;        // with pn: packed copies written by the LSTM / temporal kernels (or null)
     const float* emb_pk;             // with pn, sampling: emb in the packed A layout (or null)
     float* hd_pk;                    // with pn, sampling: packed copy of hd for the readout (or null)
+    int phase;                       // 0: the whole step; 1: state projections + attention launch only; 2: temporal fuse + LSTM only
+                                     // (one-hypothesis decode runs the attention of word w + 1 in the last launch of word w)
+    const stattn::BeamArgs* upd;     // phase 1 only: beam bookkeeping of the previous word, extra workgroups of the attention launch
 };
 
 int run_step(stattn_handle* h, const StepIO& io);

@@ -347,7 +347,8 @@ def leg_beam_c5(args, local, params):
                             lstm=mfma("[ctx|emb].[Wc|W] + gates %dx%dx%d" % (M, 4 * D, D + E), 2.0 * M * (D + E) * 4 * D, kms["lstm"][0]),
                             readout_logits_softmax=mfma("readout %dx%dx%d + logits %dx%dx%d (+ softmax), scope" % (M, E, 2 * D, M, Vp, E), ro_flops, kms["readout"][0]),
                             temporal=hbm("temporal_kernel", M * T * D * 4.0 * 3, kms["temporal"][0]),
-                            select=dict(kernel="beam_topk_part + merge + beam_update (scope)", bound="latency", ms_per_launch=kms["select"][0])),
+                            select=dict(kernel="beam_update: first %d workgroups of the attention launch of the next word (no launch of its own)" % nv
+                                        if kms["select"][1] == 0 else "beam_topk_part + merge + beam_update (scope)", bound="latency", ms_per_launch=kms["select"][0])),
                word_us_by_events=sum(kms[x][0] for x in ("hproj", "spatial", "temporal", "lstm", "readout", "select")) * 1e3)
     out["roofline"] = out["roofline_hbm"]
     if not args.no_cpu_baseline:

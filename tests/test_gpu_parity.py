@@ -503,7 +503,7 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k, nvid):
 
 
 # ------------------------------------------------------------------ BASELINE.json configs[4] / configs[0] at full size
-def test_c5_full_size_device_beam_search(stattn_mod, O):
+def test_c5_full_size_device_beam_search(stattn_mod, O, monkeypatch):
     """BASELINE.json configs[4] as written: 32 videos x beam 5 = 160 rows, T=80, K=32, hidden 1024, through the
     device-side beam search with its hipGraph-captured per-word sequence (stattn_beam_search).  Videos 0 and 1 are
     checked against the oracle's gen_sample, the others against the product's host-driven gen_sample loop.  feat is
@@ -529,6 +529,22 @@ def test_c5_full_size_device_beam_search(stattn_mod, O):
     for (s1, c1), (s2, c2) in zip(res, res_r):
         assert s1 == s2
         np.testing.assert_array_equal(c1, c2)
+    # the update of every word rode in the next word's attention launch (which ran on the hypotheses before the re-ordering, the
+    # temporal kernel reading its parent's rows); the seven-launch word gives the same beams
+    assert dec.path_counts()['upd_rider'] > 0
+    fs_r = dec.beam_final_state()
+    monkeypatch.setenv('STATTN_NO_UPDATE_RIDER', '1')
+    res_n = dec.beam_search(k=k, maxlen=maxlen, resident=True)
+    assert dec.path_counts()['upd_rider'] == 0
+    fs_n = dec.beam_final_state()
+    monkeypatch.delenv('STATTN_NO_UPDATE_RIDER')
+    for (s1, c1), (s2, c2) in zip(res_r, res_n):       # (scores to an ulp or two: the riding update sums the log-sum-exp partials
+        assert s1 == s2                                 #  over the 256 threads of the attention launch, the launch of its own over 1024)
+        np.testing.assert_allclose(c1, c2, rtol=1e-6, atol=0)
+    # (states to a few ulps: a child's attention is now its PARENT's, computed in the parent's hypothesis slot of the shared-slab
+    #  kernel, whose per-slot code differs in the last bit -- tools/update_rider_ab.py: only children in another slot than their parent differ)
+    for (h1, c1), (h2, c2) in zip(fs_r, fs_n):
+        np.testing.assert_allclose(h1, h2, rtol=0, atol=1e-6); np.testing.assert_allclose(c1, c2, rtol=0, atol=1e-6)
     for v in range(nvid):
         args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
         bs, bsc = res[v]

@@ -398,6 +398,28 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
         CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
     }
+    // Larger beams whose attention launch streams the slabs once per video (spatial_shared_kernel) and whose vocabulary launch leaves
+    // statistics: the attention of word w + 1 does not depend on the words chosen at word w, only on the states -- it runs on the
+    // hypotheses as they stand BEFORE the re-ordering, right behind the state projections of the new h, and carries the whole update
+    // of word w (selection, log-sum-exp, gathers: one workgroup per video, 26 us per configs[4] word as a launch of its own) in its
+    // first workgroups.  The temporal kernel reads its parent's scores / region contexts through `rowmap`; h.U travels with the beam.
+    bool pre = false;
+    int* rowmap = nullptr;
+    float* preh_step = nullptr;
+    // On the small path (at most 16 rows) the readout launch already leaves the projections of the new h before the re-ordering
+    // (`proj_step`): the same order of launches, the attention reading them there.
+    if (panels && vocab_stats && !stochastic && k > 1) {
+        const char* noride = getenv("STATTN_NO_UPDATE_RIDER");
+        SpatialArgs probe{};
+        probe.M = M; probe.T = T; probe.K = K; probe.D = D; probe.group = k;
+        const bool hu_rider = !small && M <= 64 && spatial_rider_supported(probe);       // (run_step would let the attention launch carry h.U instead)
+        pre = !noride && !hu_rider && spatial_update_supported(probe);
+        if (pre) CHK(getbuf_t(h, "bs_rowmap", (size_t)M, &rowmap));
+        if (pre && !small) {
+            CHK(getbuf_t(h, "bs_preh_step", (size_t)M * 4 * D, &preh_step));
+            CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
+        }
+    }
     int* d_ticket;
     CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
     {   // the initial beam (one live, empty, zero-score hypothesis per video on row v * k, next word -1, :871-893), its states,
@@ -407,7 +429,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         bi.nvid = nvid; bi.k = k; bi.D = D; bi.E = E;
         bi.vid = vid; bi.live_k = live_k; bi.dead_k = dead_k; bi.next_w = next_w; bi.score0 = score[0];
         bi.h0 = h0; bi.c0 = c0; bi.hp = hp; bi.cp = cp; bi.hp_pk = hp_pk; bi.dp = dp; bi.emb = emb;
-        bi.ticket = d_ticket; bi.step = d_step;
+        bi.ticket = d_ticket; bi.step = d_step; bi.rowmap = rowmap;
         float* zs[5] = {ctx_pk, hd_pk, emb_pk, a1_pk, ho_pk};
         const size_t zn[5] = {packed_rows_floats(M, D), packed_rows_floats(M, D), packed_rows_floats(M, E), packed_rows_floats(M, E), packed_rows_floats(M, D)};
         for (int q = 0; q < 5; ++q) { bi.zero[q] = zs[q]; bi.zero_n[q] = zs[q] ? zn[q] : 0; }
@@ -436,7 +458,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // wrote, never the chosen word, so the bookkeeping of word w runs as one more workgroup of THAT launch (attn.hip
     // spatial_small_update_kernel) and the word loop is  T L R G [S(w + 1) | U(w)]  behind one S(0): five launches per word.
     // The attention behind the last word is computed for nothing.  STATTN_NO_UPDATE_RIDER=1: the six-launch word (A/B, tests).
-    bool ride = false;
+    bool ride = pre;
     if (direct) {
         const char* noride = getenv("STATTN_NO_UPDATE_RIDER");        // (read on every call: tests switch it inside one process)
         SpatialArgs probe{};
@@ -462,6 +484,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     auto enqueue_word = [&](int parity) -> int {
         StepIO io = step_io();
         io.phase = ride ? 2 : 0;
+        if (pre) { io.rowmap = rowmap; io.h_out_pk = ho_pk; }
         CHK(run_step(h, io));
         std::unique_ptr<Prof> pro(new Prof(h, KC_READOUT));        // readout + vocabulary launch (+ softmax) of this word
         if (small) {       // readout layer 1 + the next word's state projections (before the beam is re-ordered), then logits -> statistics
@@ -528,7 +551,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             HIPCHK(h, launch_softmax_nll(s, lg, Vp, pr, Vp, nullptr, nullptr, nullptr, M, V));
         }
         pro.reset();
-        Prof prs(h, KC_SELECT);                    // candidate selection + beam update of this word
+        std::unique_ptr<Prof> prs(new Prof(h, KC_SELECT, !ride));   // candidate selection + beam update of this word (riding: inside the attention launch's scope)
         BeamArgs ba{};
         ba.probs = pr; ba.ldp = Vp; ba.V = V; ba.k = k; ba.D = D; ba.maxlen = L0; ba.nvid = nvid; ba.step = d_step;
         ba.suppress_eos = suppress_eos;
@@ -541,20 +564,24 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         if (vocab_stats) {
             ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile; ba.tile_cols = Vp / vtile; ba.stochastic = stochastic;
             if (small && !direct) { ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D; }
+            if (pre) { ba.rowmap = rowmap; ba.h_next_pk = nullptr; }          // (the packed h of the re-ordered beam has no reader any more)
+            if (pre && !small) { ba.proj_step = preh_step; ba.proj_next = preh; ba.nproj = 4 * D; }
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         }
         if (ride) {        // the next word's attention launch carries this word's update
-            io.phase = 1; io.upd = &ba;
+            io.phase = 1; io.upd = &ba; io.rowmap = nullptr;
+            if (pre && small) io.sproj = proj_step;                                      // where the readout launch of this word left them
+            else if (pre) { io.h_prev = ho; io.h_prev_pk = ho_pk; io.preh = preh_step; }     // state projections of the new h, before the re-ordering
             CHK(run_step(h, io));
             return STATTN_OK;
         }
         HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
-    if (ride) {            // attention of the first word
+    if (ride) {            // attention of the first word (with `pre`: behind the state projections of the initial states)
         StepIO io = step_io();
-        io.phase = 1;
+        io.phase = 1;            // (h.U of the initial states goes straight to `preh`: nothing re-orders the beam before the first LSTM launch)
         CHK(run_step(h, io));
     }
 
@@ -566,7 +593,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
     h->beam_graph_replays = 0;
     // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
-    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride,
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride, (uintptr_t)pre, (uintptr_t)rowmap, (uintptr_t)preh_step,
                                   (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
     for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
                           (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,

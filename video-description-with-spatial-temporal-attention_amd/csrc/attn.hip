@@ -282,7 +282,7 @@ __global__ __launch_bounds__(NT) void spatial2_kernel(const SpatialArgs a) {
 // burst and the kernel is a single memory round trip (the kernels above wait for the softmax before they ask for L / LW).
 // One float4 column per lane: D <= 4 * blockDim.
 __device__ __forceinline__ void spatial_small_body(const SpatialArgs& a) {
-    __shared__ float s_red[4 * 10];
+    __shared__ float s_red[16 * 10];       // (up to sixteen waves: spatial_small_update_wide_kernel)
     const int T = a.T, K = a.K, D = a.D;
     const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
     const int bt = blockIdx.x, b = bt / T, t = bt % T;
@@ -355,6 +355,15 @@ __global__ __launch_bounds__(256) void spatial_small_kernel(const SpatialArgs a)
 // word's embedding for this word's LSTM launch).  The attention of a word reads the state projections the readout launch left,
 // never the chosen word: as a launch of its own the update was 8.9 of the 42.5 us of a configs[0] word.
 __global__ __launch_bounds__(256) void spatial_small_update_kernel(const SpatialArgs a, const BeamArgs u) {
+    const int items = a.M * a.T;
+    if ((int)blockIdx.x >= items) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x - items, u.nvid); return; }
+    spatial_small_body(a);
+}
+
+// Beams of 2 .. 8 hypotheses on the small path: the update of such a beam is a 1024-thread job (k * k * tiles candidates to scan), so
+// the launch runs 1024-thread workgroups; an attention item only uses its first D / 4 lanes (the others load clamped addresses and
+// contribute zeros), and what the 128-register budget of sixteen waves costs it disappears under the update beside it.
+__global__ __launch_bounds__(1024) void spatial_small_update_wide_kernel(const SpatialArgs a, const BeamArgs u) {
     const int items = a.M * a.T;
     if ((int)blockIdx.x >= items) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x - items, u.nvid); return; }
     spatial_small_body(a);
@@ -467,12 +476,12 @@ template <int H>
 #ifndef STATTN_SH_PHASE
 #define STATTN_SH_PHASE 0     // 1 / 2: probe builds that run one phase only
 #endif
-__global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArgs a) {
+__device__ __forceinline__ void spatial_shared_body(const SpatialArgs& a, const int vt) {
     __shared__ float s_red[4 * 2 * H];
     __shared__ float s_e[H][KMAX];
     const int T = a.T, K = a.K, D = a.D;
     const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;   // scalar loads up front, not inside the one-lane branches that use them
-    const int vt = blockIdx.x, v = vt / T, t = vt % T;
+    const int v = vt / T, t = vt % T;
     const int tid = threadIdx.x;
     const size_t slab = ((size_t)v * T + t) * K * D;
     const float* __restrict__ PL = a.PL + slab;
@@ -641,6 +650,20 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArg
 #endif
 }
 
+template <int H>
+__global__ __launch_bounds__(256, 3) void spatial_shared_kernel(const SpatialArgs a) { spatial_shared_body<H>(a, (int)blockIdx.x); }
+
+// Beam search: the same launch with the bookkeeping of the PREVIOUS word in its first u.nvid workgroups (beam_inl.h).  The attention
+// of word w + 1 is computed for the hypotheses as they stand BEFORE the beam is re-ordered -- it depends on a hypothesis' state only,
+// not on the word chosen for it -- and the temporal kernel picks the parent's scores / region contexts through BeamArgs::rowmap:
+// selection, log-sum-exp and the gathers (26 us per configs[4] word as a launch of their own, one workgroup per video) run under
+// this HBM-bound launch.
+template <int H>
+__global__ __launch_bounds__(256, 3) void spatial_shared_update_kernel(const SpatialArgs a, const BeamArgs u) {
+    if ((int)blockIdx.x < u.nvid) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x, u.nvid); return; }
+    spatial_shared_body<H>(a, (int)blockIdx.x - u.nvid);
+}
+
 
 
 // one wave per row: out[r] = dot(P[r,:], U) + c
@@ -675,7 +698,10 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
     const bool on = d < D;
     const float* __restrict__ G = a.G + (size_t)v * T * D + (on ? d : 0);
     const float* __restrict__ Mo = a.Mo + (size_t)v * T * D + (on ? d : 0);
-    const float* __restrict__ CL = a.CL + (size_t)b * T * D + (on ? d : 0);
+    // beam search with the update riding in the attention launch: scores and region contexts were computed for the hypotheses
+    // BEFORE the re-ordering -- row b takes its parent's
+    const int bs = a.rowmap ? a.rowmap[b] : b;
+    const float* __restrict__ CL = a.CL + (size_t)bs * T * D + (on ? d : 0);
     float4 g4[TPF], m4[TPF], c4[TPF];
 #pragma unroll
     for (int i = 0; i < TPF; ++i) {
@@ -685,7 +711,7 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
 
     if (w < 3) {          // three softmaxes over T, one wave each
         // the lane's scores are read ONCE, all of them in flight together (three passes over e[] were three dependent round trips)
-        const float* e = (w == 0 ? a.eg : (w == 1 ? a.em : a.elt)) + (size_t)b * T;
+        const float* e = (w == 0 ? a.eg : (w == 1 ? a.em : a.elt)) + (size_t)bs * T;
         constexpr int NE = (TMAX + 63) / 64;
         float ev[NE];
 #pragma unroll
@@ -788,15 +814,31 @@ static bool spatial_small_path(const SpatialArgs& a) {
     static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
     return !nosm && !a.bf16 && !spatial_shared_path(a) && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024;
 }
-bool spatial_update_supported(const SpatialArgs& a) { return a.M > 0 && a.K >= 1 && a.D % 4 == 0 && spatial_small_path(a); }
+bool spatial_update_supported(const SpatialArgs& a) {
+    return a.M > 0 && a.K >= 1 && a.K <= KMAX && a.D % 4 == 0 && !a.bf16 && !a.rider.nblocks && (spatial_small_path(a) || spatial_shared_path(a));
+}
 
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* upd) {
     if (upd) {
         if (!spatial_update_supported(a) || !upd->stats || !upd->ticket || upd->nvid < 1 || upd->ntile < 1 || upd->k > PN_STATS_KB ||
             (upd->stochastic && (upd->k != 1 || upd->tile_cols < 1)) || (upd->proj_next && (!upd->proj_step || upd->nproj % 4)))
             return hipErrorInvalidValue;
+        if (spatial_shared_path(a)) {
+            const dim3 grid(a.M / a.group * a.T + upd->nvid), block(256);
+            switch (a.group) {
+                case 2: hipLaunchKernelGGL(spatial_shared_update_kernel<2>, grid, block, 0, s, a, *upd); break;
+                case 3: hipLaunchKernelGGL(spatial_shared_update_kernel<3>, grid, block, 0, s, a, *upd); break;
+                case 4: hipLaunchKernelGGL(spatial_shared_update_kernel<4>, grid, block, 0, s, a, *upd); break;
+                case 5: hipLaunchKernelGGL(spatial_shared_update_kernel<5>, grid, block, 0, s, a, *upd); break;
+                case 6: hipLaunchKernelGGL(spatial_shared_update_kernel<6>, grid, block, 0, s, a, *upd); break;
+                case 7: hipLaunchKernelGGL(spatial_shared_update_kernel<7>, grid, block, 0, s, a, *upd); break;
+                default: hipLaunchKernelGGL(spatial_shared_update_kernel<8>, grid, block, 0, s, a, *upd); break;
+            }
+            return hipGetLastError();
+        }
         const int nt = ((a.D / 4 + 63) / 64) * 64;
-        hipLaunchKernelGGL(spatial_small_update_kernel, dim3(a.M * a.T + upd->nvid), dim3(nt), 0, s, a, *upd);
+        if (upd->k > 1) hipLaunchKernelGGL(spatial_small_update_wide_kernel, dim3(a.M * a.T + upd->nvid), dim3(1024), 0, s, a, *upd);
+        else hipLaunchKernelGGL(spatial_small_update_kernel, dim3(a.M * a.T + upd->nvid), dim3(nt), 0, s, a, *upd);
         return hipGetLastError();
     }
     if (a.M <= 0) return hipSuccess;

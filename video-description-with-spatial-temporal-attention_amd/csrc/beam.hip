@@ -111,6 +111,7 @@ __global__ __launch_bounds__(256) void beam_init_kernel(const BeamInitArgs a) {
         a.vid[i] = i / a.k;
         a.next_w[i] = -1;
         a.score0[i] = 0.f;
+        if (a.rowmap) a.rowmap[i] = i;
     }
     if (gid < (size_t)a.nvid) { a.live_k[gid] = 1; a.dead_k[gid] = 0; }
     if (gid == 0) { *a.ticket = 0; *a.step = 0; }

@@ -274,6 +274,11 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
     __syncthreads();
     BM_STAMP(5);
     const int n = s_n;
+    if (a.rowmap && tid < k) {      // parent of the hypothesis that now sits in row tid (unused rows: themselves)
+        int src = tid;
+        for (int r = 0; r < n; ++r) if (!s_fin[r] && s_slot[r] == tid) src = s_ti[r];
+        a.rowmap[v * k + tid] = v * k + src;
+    }
     // Copies of the n surviving candidates: tokens, then -- for the ones that stay live -- the parent's state, the next
     // step's state projections, the packed h and the embedding of the chosen word.  One flat index space per field over ALL
     // candidates: the loads of every row are in flight together.  (A loop over the candidates around per-row loops was a

@@ -277,6 +277,7 @@ struct TemporalArgs {
     float* ctx;        // [M,D]
     float* ctx_pk;     // optional: ctx once more in the packed A layout of the row-panel LSTM kernel (pn_pack_offset)
     int M, T, D;
+    const int* rowmap; // optional [M]: row b reads the scores eg / em / elt and the region contexts CL of row rowmap[b] (BeamArgs::rowmap)
 };
 hipError_t launch_temporal(hipStream_t s, const TemporalArgs& a);
 
@@ -429,6 +430,7 @@ struct BeamInitArgs {
     float* zero[6]; size_t zero_n[6];            // buffers to clear (floats)
     float* emb;                                  // [M, E] <- 0
     int* ticket; int* step;
+    int* rowmap;                                 // optional [M] <- identity (BeamArgs::rowmap)
 };
 hipError_t launch_beam_init(hipStream_t s, const BeamInitArgs& a);
 
@@ -455,6 +457,8 @@ struct BeamArgs {
     // ... and gathers the NEXT step's state projections (computed from h of this step before the beam was re-ordered)
     const float* proj_step; float* proj_next; int nproj;   // [nvid*k, nproj] rows (sproj | preh), or null
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
+    int* rowmap;                        // optional [nvid*k]: row of the PARENT of the hypothesis now in each row (identity for unused rows): what the
+                                        // temporal kernel needs when the next word's attention ran before the re-ordering (TemporalArgs::rowmap)
 };
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch

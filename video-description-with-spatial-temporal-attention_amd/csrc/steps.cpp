@@ -286,7 +286,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
     const bool rider = io.pn && io.h_prev_pk && io.M <= 64 && !io.skip_hproj && spatial_rider_supported(sa);
     const int ldp = io.ldproj ? io.ldproj : 4 * D;
     if (io.phase != 2) { h->path_fwd_rider += rider; h->path_fwd_panel += io.pn != nullptr; }
-    if (io.upd && (io.phase != 1 || !io.skip_hproj)) return fail(h, STATTN_EINVAL, "run_step: an update rider needs phase 1 of a step with its projections in place");
+    if (io.upd && io.phase != 1) return fail(h, STATTN_EINVAL, "run_step: an update rider needs phase 1 of a step");
     if (io.phase == 2 || io.skip_hproj) {
     } else if (io.pn) {   // state projections on the row-panel kernel: one launch, every weight byte streamed once
         Prof pr(h, KC_HPROJ);
@@ -360,7 +360,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.h_prev = io.h_prev; a.W_sel = h->opt.selector ? w.W_sel : nullptr; a.b_sel = w.b_sel;
         a.alphag = io.alphag; a.alpham = io.alpham; a.alphalt = io.alphalt;
         a.csum = io.csum; a.cparts = io.cparts; a.sel = io.sel; a.ctx = io.ctx; a.ctx_pk = io.pn ? io.ctx_pk : nullptr;
-        a.M = io.M; a.T = io.T; a.D = D;
+        a.M = io.M; a.T = io.T; a.D = D; a.rowmap = io.rowmap;
         HIPCHK(h, launch_temporal(h->stream, a));
     }
     if (io.pn) {   // preact = h.U + x_ + ctx.Wc, gates, cell update (:437-457) on the row-panel kernel

@@ -71,6 +71,7 @@ struct StepIO {
     float* hd_pk;                    // with pn, sampling: packed copy of hd for the readout (or null)
     int phase;                       // 0: the whole step; 1: state projections + attention launch only; 2: temporal fuse + LSTM only
                                      // (one-hypothesis decode runs the attention of word w + 1 in the last launch of word w)
+    const int* rowmap;               // phase 2 of a step whose attention ran before the beam was re-ordered: TemporalArgs::rowmap
     const stattn::BeamArgs* upd;     // phase 1 only: beam bookkeeping of the previous word, extra workgroups of the attention launch
 };
 

@@ -96,6 +96,9 @@ def run_beam(n, seed, only=None, verbose=False):
         k, maxlen = int(rng.randint(1, 7)), int(rng.randint(3, 10))
         if case % 5 == 4:              # more than 64 rows: wide row-panel kernels with the vocabulary statistics epilogue (needs V, E, D % 32)
             nvid, k = int(rng.randint(10, 25)), int(rng.randint(4, 9))
+        if case % 5 == 3:              # many videos x frames (>= 2048 items): the shared-slab attention kernel; with > 64 rows its launch
+            nvid, T, K = int(rng.randint(26, 40)), int(rng.randint(80, 97)), int(rng.randint(1, 4))     # also carries the previous word's update
+            k = int(rng.randint(3, 7))
         precision = ["fp32", "split"][case % 2]
         opt = dict(O.default_options(**dims), stattn_precision=precision, lt_mode=int(rng.randint(2)))
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
@@ -109,6 +112,7 @@ def run_beam(n, seed, only=None, verbose=False):
         f_init, f_next = model.build_sampler(tparams, opt, None, None)
         f_next.device_loop = False
         res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
+        rode = tparams.decoder.path_counts()['upd_rider'] > 0
         ok, why = True, ""
         for v in range(nvid):
             args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
@@ -143,7 +147,7 @@ def run_beam(n, seed, only=None, verbose=False):
         bad += not ok
         print("%3d %-5s lt%d D=%3d E=%3d V=%3d sel=%d p2o=%d c2o=%d videos=%d T=%2d K=%2d beam=%d maxlen=%d  %s"
               % (case, precision, opt['lt_mode'], D, dims['dim_word'], dims['n_words'], dims['selector'], dims['prev2out'], dims['ctx2out'],
-                 nvid, T, K, k, maxlen, "ok" if ok else "FAIL: " + why), flush=True)
+                 nvid, T, K, k, maxlen, ("ok" if ok else "FAIL: " + why) + (" (update rode)" if rode else "")), flush=True)
     print("beam cases %d  failures %d" % (n, bad))
     return bad
 

@@ -265,7 +265,7 @@ def leg_decode_c1(args, local):
     for k in (1, 5):
         us, _ = word_loop_us(dec, k)
         nbytes = wb + k * ctx_row
-        out["k%d" % k].update(us_per_word=us, roofline=dict(kernel="device word loop, one video, %d row(s): 6 launches per word" % k, bound="hbm",
+        out["k%d" % k].update(us_per_word=us, roofline=dict(kernel="device word loop, one video, %d row(s): %d launches per word" % (k, 5 if dec.path_counts()["upd_rider"] else 6), bound="hbm",
                                                              achieved=nbytes / (us * 1e-6) / 1e9, peak=HBM_PEAK_GBS, unit="GB/s",
                                                              frac=nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, traffic=None,
                                                              bytes_per_word=nbytes, weight_bytes=wb, context_bytes_per_row=ctx_row))

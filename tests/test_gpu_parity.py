@@ -664,6 +664,41 @@ def test_one_hypothesis_update_rides_in_the_next_attention_launch(stattn_mod, O,
         assert x[0] == y[0] and np.array_equal(np.asarray(x[1], np.float32), np.asarray(y[1], np.float32))
 
 
+@pytest.mark.parametrize("lt_mode", [0, 1])
+def test_beam_update_rides_on_the_small_path_in_both_lt_modes(stattn_mod, O, monkeypatch, lt_mode):
+    """Beams of 3 and 5 on the <= 16-row path: the attention of the next word runs on the hypotheses before the re-ordering and carries
+    the update; in lt_mode 0 the per-step CL.Wclt GEMM of that word must then add the slt of the SAME (parent) rows.  Same beams and
+    scores as the launch-of-its-own order and as the float64 oracle, over enough words that the beam order is shuffled."""
+    dims = dict(dim=128, dim_word=64, n_words=300, ctxg_dim=128, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=128)
+    opt = dict(O.default_options(**dims), lt_mode=lt_mode)
+    for seed, k in ((5, 5), (6, 3), (7, 5)):
+        P = O.random_params(opt, seed=seed, dtype=np.float32)
+        P['ff_logit_b'] = (P['ff_logit_b'] + 1.0 * np.random.RandomState(seed).standard_normal(300)).astype(np.float32)
+        P['ff_logit_b'][0] -= 2.0
+        P64 = O.cast_params(P, np.float64)
+        b = O.synthetic_batch(opt, B=3, T=6, K=4, t=3, seed=80 + seed)
+        model = stattn_mod.Attention()
+        tparams = model.init_tparams(P)
+        f_init, f_next = model.build_sampler(tparams, opt, None, None)
+        out = {}
+        for ride in (True, False):
+            if ride:
+                monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+            else:
+                monkeypatch.setenv('STATTN_NO_UPDATE_RIDER', '1')
+            out[ride] = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=12)
+            assert (f_next.decoder.path_counts()['upd_rider'] > 0) == ride
+        monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+        for v, ((s1, c1), (s2, c2)) in enumerate(zip(out[True], out[False])):
+            assert s1 == s2
+            np.testing.assert_allclose(c1, c2, rtol=1e-5, atol=1e-5)
+            args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+            a64 = tuple(a.astype(np.float64) for a in args)
+            sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=k, maxlen=12)
+            np.testing.assert_allclose(sorted(c1), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=2e-4)
+            assert s1[int(np.argmin(c1))] == sr[int(np.argmin(scr))]
+
+
 # ------------------------------------------------------------------ robustness
 def test_changing_batch_shapes_and_relu_like_features(stattn_mod, O):
     """Consecutive minibatches of different (t, m, T, K) on one handle (device buffers grow and are re-used), and

@@ -485,6 +485,9 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         StepIO io = step_io();
         io.phase = ride ? 2 : 0;
         if (pre) { io.rowmap = rowmap; io.h_out_pk = ho_pk; }
+        // (lt_mode 0 forms CL.Wclt + slt in this phase, from the CL rows the attention launch left in the order BEFORE the re-ordering:
+        //  the slt of those rows, not the gathered ones)
+        if (pre && small) io.sproj = proj_step;
         CHK(run_step(h, io));
         std::unique_ptr<Prof> pro(new Prof(h, KC_READOUT));        // readout + vocabulary launch (+ softmax) of this word
         if (small) {       // readout layer 1 + the next word's state projections (before the beam is re-ordered), then logits -> statistics
@@ -579,6 +582,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         HIPCHK(h, launch_beam_update(s, ba, tk_cost, tk_idx));
         return STATTN_OK;
     };
+    if (pre && small)      // (first word: the attention launch and the lt_mode-0 GEMM read the projections of the initial states there)
+        HIPCHK(h, hipMemcpyAsync(proj_step, proj, (size_t)M * 8 * D * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ride) {            // attention of the first word (with `pre`: behind the state projections of the initial states)
         StepIO io = step_io();
         io.phase = 1;            // (h.U of the initial states goes straight to `preh`: nothing re-orders the beam before the first LSTM launch)

@@ -97,8 +97,8 @@ def run_beam(n, seed, only=None, verbose=False):
         if case % 5 == 4:              # more than 64 rows: wide row-panel kernels with the vocabulary statistics epilogue (needs V, E, D % 32)
             nvid, k = int(rng.randint(10, 25)), int(rng.randint(4, 9))
         if case % 5 == 3:              # many videos x frames (>= 2048 items): the shared-slab attention kernel; with > 64 rows its launch
-            nvid, T, K = int(rng.randint(26, 40)), int(rng.randint(80, 97)), int(rng.randint(1, 4))     # also carries the previous word's update
-            k = int(rng.randint(3, 7))
+            nvid, T, K = int(rng.randint(8, 40)), int(rng.randint(40, 97)), int(rng.randint(1, 13))     # also carries the previous word's update
+            k = int(rng.randint(2, 7))                                                                    # (17 .. 64 rows: shared-slab kernel, update as a launch of its own)
         precision = ["fp32", "split"][case % 2]
         opt = dict(O.default_options(**dims), stattn_precision=precision, lt_mode=int(rng.randint(2)))
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)

@@ -161,6 +161,7 @@ void stattn_destroy(stattn_handle* h) {
     comm_release(h);
     if (h->beam_gexec) (void)hipGraphExecDestroy(h->beam_gexec);
     if (h->beam_gexec8) (void)hipGraphExecDestroy(h->beam_gexec8);
+    if (h->beam_gexec_last) (void)hipGraphExecDestroy(h->beam_gexec_last);
     if (h->pin_io) (void)hipHostFree(h->pin_io);
     if (h->pin_res) (void)hipHostFree(h->pin_res);
     if (h->pin_plan[0]) (void)hipHostFree(h->pin_plan[0]);

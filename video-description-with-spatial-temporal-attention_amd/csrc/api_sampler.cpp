@@ -420,6 +420,25 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
         }
     }
+    // Tool switch (STATTN_MERGE_PG=1, measured in DESIGN.md section 6): the state projections of the new h as two more segments of the
+    // logits launch -- both only need what the LSTM launch left -- instead of a launch of their own in front of the attention.
+    PnArgs lgargs_pg{};
+    bool merge_pg = false;
+    if (pre && !small) {
+        const char* mpg = getenv("STATTN_MERGE_PG");
+        merge_pg = mpg && mpg[0] == '1';
+        if (merge_pg) {
+            lgargs_pg.M = M; lgargs_pg.nseg = 3; lgargs_pg.plain_order = 1;
+            for (int i = 0; i < 2; ++i) {
+                PnSeg& sg = lgargs_pg.seg[i];
+                pn_seg_defaults(sg);
+                sg.npairs = 1; sg.p[0] = PnPair{ho_pk, D, i == 0 ? pn.Wd : pn.U, D, 1};
+                sg.C = i == 0 ? sproj : preh_step; sg.ldc = 4 * D; sg.N = 4 * D;
+            }
+            lgargs_pg.seg[2] = lgargs.seg[0];
+            merge_pg = panel_wide_supported(lgargs_pg);
+        }
+    }
     int* d_ticket;
     CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
     {   // the initial beam (one live, empty, zero-score hypothesis per video on row v * k, next word -1, :871-893), its states,
@@ -481,7 +500,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         }
         return io;
     };
-    auto enqueue_word = [&](int parity) -> int {
+    auto enqueue_word = [&](int parity, bool last = false) -> int {      // last: the word at maxlen - 1 (its update is a launch of its own:
+                                                                         // there is no next word whose attention could carry it)
         StepIO io = step_io();
         io.phase = ride ? 2 : 0;
         if (pre) { io.rowmap = rowmap; io.h_out_pk = ho_pk; }
@@ -522,7 +542,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
             HIPCHK(h, launch_panel(s, a));
             if (vocab_stats) {
-                HIPCHK(h, launch_panel(s, lgargs));
+                HIPCHK(h, launch_panel(s, (merge_pg && !last) ? lgargs_pg : lgargs));
             } else {
                 PnArgs b{};
                 b.M = M; b.nseg = 1;
@@ -572,9 +592,10 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         } else {
             HIPCHK(h, launch_beam_topk(s, ba, tk_cost, tk_idx));
         }
-        if (ride) {        // the next word's attention launch carries this word's update
+        if (ride && !last) {        // the next word's attention launch carries this word's update
             io.phase = 1; io.upd = &ba; io.rowmap = nullptr;
             if (pre && small) io.sproj = proj_step;                                      // where the readout launch of this word left them
+            else if (pre && merge_pg) { io.skip_hproj = true; }                            // (they rode in the logits launch)
             else if (pre) { io.h_prev = ho; io.h_prev_pk = ho_pk; io.preh = preh_step; }     // state projections of the new h, before the re-ordering
             CHK(run_step(h, io));
             return STATTN_OK;
@@ -598,7 +619,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
     h->beam_graph_replays = 0;
     // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
-    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride, (uintptr_t)pre, (uintptr_t)rowmap, (uintptr_t)preh_step,
+    std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride, (uintptr_t)pre, (uintptr_t)merge_pg, (uintptr_t)rowmap, (uintptr_t)preh_step,
                                   (uintptr_t)h->opt.lt_mode, (uintptr_t)h->opt.precision, (uintptr_t)s};
     for (const void* q : {(const void*)c.G, (const void*)c.L, (const void*)c.Mo, (const void*)c.PG, (const void*)c.PL, (const void*)c.PM,
                           (const void*)c.LW, (const void*)vid, (const void*)live_k, (const void*)dead_k,
@@ -614,14 +635,14 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
                           (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket,
                           (const void*)proj, (const void*)proj_step, (const void*)ho_pk, (const void*)vstats})
         sig.push_back((uintptr_t)q);
-    hipGraphExec_t gexec8 = nullptr;
-    auto capture = [&](int nwords) -> hipGraphExec_t {
+    hipGraphExec_t gexec8 = nullptr, gexec_last = nullptr;
+    auto capture = [&](int nwords, bool ends = false) -> hipGraphExec_t {
         hipGraph_t graph = nullptr;
         hipGraphExec_t ge = nullptr;
         bool ok = hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess;
         if (ok) {
             int r = STATTN_OK;
-            for (int i = 0; i < nwords && r == STATTN_OK; ++i) r = enqueue_word(i & 1);
+            for (int i = 0; i < nwords && r == STATTN_OK; ++i) r = enqueue_word(i & 1, ends && i == nwords - 1);
             const hipError_t e = hipStreamEndCapture(s, &graph);
             ok = r == STATTN_OK && e == hipSuccess && graph != nullptr;
         }
@@ -631,27 +652,34 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         return ge;
     };
     if (!nograph && !h->profiling && L0 >= 2 && h->beam_gexec && h->beam_gsig == sig) {
-        gexec = h->beam_gexec; gexec8 = h->beam_gexec8;          // same buffers and shapes as last time: replay as is
+        gexec = h->beam_gexec; gexec8 = h->beam_gexec8; gexec_last = h->beam_gexec_last;          // same buffers and shapes as last time: replay as is
     } else if (!nograph && !h->profiling && L0 >= 2) {
         if (h->beam_gexec) { (void)hipGraphExecDestroy(h->beam_gexec); h->beam_gexec = nullptr; }
         if (h->beam_gexec8) { (void)hipGraphExecDestroy(h->beam_gexec8); h->beam_gexec8 = nullptr; }
+        if (h->beam_gexec_last) { (void)hipGraphExecDestroy(h->beam_gexec_last); h->beam_gexec_last = nullptr; }
         gexec = capture(2);
         if (gexec && L0 >= 8) gexec8 = capture(8);
-        if (gexec) { h->beam_gexec = gexec; h->beam_gexec8 = gexec8; h->beam_gsig = sig; }
+        if (gexec && ride) gexec_last = capture(2, true);
+        if (gexec) { h->beam_gexec = gexec; h->beam_gexec8 = gexec8; h->beam_gexec_last = gexec_last; h->beam_gsig = sig; }
     }
     int steps_run = 0;
     int rc_loop = STATTN_OK;
     for (int st = 0; st < L0;) {
-        if (gexec8 && (st & 1) == 0 && st + 8 <= L0) {
+        const int tail = gexec_last ? 2 : 0;                       // words kept for the graph that ends the search
+        if (gexec_last && (st & 1) == 0 && st + 2 == L0) {
+            if (hipGraphLaunch(gexec_last, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
+            st += 2;
+            ++h->beam_graph_replays;
+        } else if (gexec8 && (st & 1) == 0 && st + 8 <= L0 - tail) {
             if (hipGraphLaunch(gexec8, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
             st += 8;
             ++h->beam_graph_replays;
-        } else if (gexec && (st & 1) == 0 && st + 2 <= L0) {
+        } else if (gexec && (st & 1) == 0 && st + 2 <= L0 - tail) {
             if (hipGraphLaunch(gexec, s) != hipSuccess) { rc_loop = fail(h, STATTN_EHIP, "beam_search: hipGraphLaunch failed"); break; }
             st += 2;
             ++h->beam_graph_replays;
         } else {
-            rc_loop = enqueue_word(st & 1);
+            rc_loop = enqueue_word(st & 1, ride && st + 1 == L0);
             if (rc_loop != STATTN_OK) break;
             st += 1;
         }

@@ -802,7 +802,13 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
 // four workgroups per CU, the bf16 and shared-slab kernels are not per-row)
 static bool spatial_shared_path(const SpatialArgs& a) {
     static const char* noshare = getenv("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
-    return a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= 2048;
+    static const char* mn = getenv("STATTN_SHARED_MIN");               // tools/shared_rounds_probe.py: smallest (video, frame) grid that takes it
+    // Smallest (video, frame) grid that takes it, measured against the per-row kernels at beam 5, D = 1024 (tools/shared_rounds_probe.py, attention +
+    // state-projection launches together -- up to 64 rows the per-row launch also carries h.U): K = 8, T = 26: 104 / 312 / 520 items lose (45 / 57 / 89 us
+    // against 34 / 46 / 74), 832 tie, 1300 win (79 against 92); K = 16, T = 40: 160 items lose (47 against 41), 320 win (64 against 73), 1280: 92 against 188;
+    // K = 32, T = 80: 160 lose, 320 win (48 against 59), 640: 65 against 185, 1920: 170 against 535.  (Until the end of round 4 the rule was 2048 items.)
+    const int min_items = mn ? atoi(mn) : (a.K <= 8 ? 800 : 320);
+    return a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= min_items;
 }
 bool spatial_rider_supported(const SpatialArgs& a) {
     static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
@@ -851,7 +857,7 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
         return hipGetLastError();
     }
     // beam search: the `group` consecutive rows of a video share its region tensors -> one pass over each slab
-    // (worth it once the (video, frame) grid alone fills the chip several times: 104 workgroups at configs[0] do not)
+    // (worth it from a few hundred (video, frame) items on: the rule and its measurements are in spatial_shared_path)
     if (spatial_shared_path(a)) {
         const dim3 grid(a.M / a.group * a.T), block(256);
         switch (a.group) {

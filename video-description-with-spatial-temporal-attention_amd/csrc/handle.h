@@ -112,6 +112,7 @@ struct stattn_handle {
     bool ck_proj = false;
     // beam search: the captured two-word graph is kept while every pointer and shape it baked in is unchanged
     hipGraphExec_t beam_gexec = nullptr;    // two words (even + odd ping-pong parity)
+    hipGraphExec_t beam_gexec_last = nullptr;   // two words, the second one the LAST of a search (no attention launch for a word that never comes)
     hipGraphExec_t beam_gexec8 = nullptr;   // eight words: a replay costs 10-16 us of launch overhead whatever it holds
     std::vector<uintptr_t> beam_gsig;
     long beam_graph_replays = 0;        // replays in the last stattn_beam_search (0 = eager launches)

@@ -171,7 +171,7 @@ __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
     constexpr int NTH = 64 * KS, FPITCH = WCB + 1;
     extern __shared__ __attribute__((aligned(16))) float red[];
     constexpr int RB = MB * 32, BUF = RB * WPITCH;
-    int cb = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), si = 0;
+    int cb = a.plain_order ? (int)blockIdx.x : xcd_contiguous((int)blockIdx.x, (int)gridDim.x), si = 0;
     while (si + 1 < a.nseg && cb >= a.seg[si].N / WCB) { cb -= a.seg[si].N / WCB; ++si; }
     const PnSeg& sg = a.seg[si];
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;

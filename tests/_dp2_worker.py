@@ -27,6 +27,8 @@ def problem():
 
 def main():
     rank, world, outdir, mode = int(sys.argv[1]), int(sys.argv[2]), sys.argv[3], int(sys.argv[4])
+    import faulthandler
+    faulthandler.dump_traceback_later(100, exit=False)          # a rank that hangs says where (the caller's time limit is longer)
     import stattn
     from stattn import dp
     O, opt, P, batch = problem()

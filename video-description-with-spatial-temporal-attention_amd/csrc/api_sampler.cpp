@@ -334,7 +334,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     CHK(getbuf_t(h, "bs_ctx", (size_t)M * D, &ctx)); CHK(getbuf_t(h, "bs_a1", (size_t)M * E, &a1));
     CHK(getbuf_t(h, "bs_lg", (size_t)M * Vp, &lg)); CHK(getbuf_t(h, "bs_pr", (size_t)M * Vp, &pr));
 
-    // one decoded word = a fixed sequence of 10 kernel launches whose arguments depend on the word index only through
+    // one decoded word = a fixed sequence of kernel launches (five to ten, by path: below) whose arguments depend on the word index only through
     // the parity of the ping-pong buffers (the index itself lives in d_step on the device)
     FwdPanels pn{};
     const bool panels = use_panels(h, M, 1) && Vp % 16 == 0;
@@ -348,7 +348,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     }
     // Small batches (<= 16 rows: the reference's own evaluation decodes ONE video at a time, metrics.py:121-135) are
     // launch-latency bound -- each of the ten launches of a word costs 5-11 us however little it computes.  Their word is
-    // six launches: attention, temporal fuse, LSTM, [readout layer 1 | state projections of the NEXT word] in one
+    // six launches (five once the update rides in the next word's attention launch, further down): attention, temporal fuse, LSTM,
+    // [readout layer 1 | state projections of the NEXT word] in one
     // row-panel launch (both only need the new h; the projections are linear in h, so beam_update gathers their rows
     // with the hypotheses instead of recomputing them), logits with the vocabulary statistics in the epilogue (tile
     // max / sum-exp / best candidates: no logits or probabilities are stored, no softmax or top-k launch), update.

@@ -4,6 +4,9 @@
 #include "kernels.h"
 #include "devmath.h"
 
+#ifndef STATTN_BEAM_PF
+#define STATTN_BEAM_PF 4
+#endif
 #ifndef BM_STAMP
 #define BM_STAMP(i) do {} while (0)
 #endif
@@ -121,9 +124,10 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
         const int per = nt * nsel;                             // the nsel best of every tile cover the nsel best overall
         const int C = live * per;
         const float r_per = 1.0f / (float)per, r_nsel = 1.0f / (float)nsel;
-        float pv[4]; int pi[4], pj[4];
+        constexpr int PF = STATTN_BEAM_PF;                     // candidates per thread requested up front (-DSTATTN_BEAM_PF=12 / 20 measured: beam-5 word 57.2-57.5 / 57.1-58.9 us against 57.6-58.0, greedy 35.3-35.8 / 35.8-36.4 against 35.0-35.4: within noise, not kept)
+        float pv[PF]; int pi[PF], pj[PF];
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
+        for (int u = 0; u < PF; ++u) {
             const int e = u * NT + tid;
             pv[u] = -INFINITY; pi[u] = 0x7fffffff; pj[u] = 0;
             if (e < C) {
@@ -179,11 +183,11 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
 #pragma unroll
         for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
 #pragma unroll
-        for (int u = 0; u < 4; ++u)
+        for (int u = 0; u < PF; ++u)
             if (pv[u] > -INFINITY) list_insert(lc, li, (a.stochastic ? 0.f : (one ? hyp0 : s_hyp[pj[u]] + s_lse[pj[u]])) - pv[u], pi[u]);
         // the rest of the flat index space over (live row, tile, rank), four candidates' loads in flight per thread before they
         // are inserted (row by row and one at a time, the 37 inserts of a thread at k = 5 were 37 exposed L2 latencies)
-        for (int c0 = 4 * NT; c0 < C; c0 += 4 * NT) {
+        for (int c0 = PF * NT; c0 < C; c0 += 4 * NT) {
             // (value AND index of the four candidates requested together, unconditionally -- the last candidate is re-read past the
             // end: with the index load inside `if (val > -inf)` the four were eight dependent round trips)
             float cv[4], val[4]; int ci[4], ix[4], jj[4];

@@ -1018,7 +1018,7 @@ def main():
         out["decode_c1"] = leg_decode_c1(args, local)
         out["beam_c5"] = leg_beam_c5(args, local, params)
     if rank == 0:
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:      # the CPU leg belongs to the N = 1 line only (other ranks would idle at the barrier)
             out["cpu_baseline"] = cpu_baseline(c, options, params, 99, train)
             out["cpu_baseline"].update(host_info())
         print(json.dumps(out))

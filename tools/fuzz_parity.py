@@ -45,6 +45,10 @@ def run(n, seed, large=False):
         # regions have weights near 1/2, where the same relative error is 2.0e-3 absolute: 3e-3 here)
         bar_a, bar_l, bar_g = (3e-3, 3e-2, 5e-2) if precision == "bf16" else (1e-4, 1e-4, 1e-4)
         opt = O.default_options(**dims)
+        only = os.environ.get("FUZZ_ONLY")          # replay of one case, every gradient's error listed (and an fp32 handle's beside a bf16 one)
+        if only is not None and case != int(only):
+            rng.randint(1 << 30); rng.randint(1 << 30); rng.choice([0.0, 0.70602])      # (the draws of a case that is not run)
+            continue
         P = O.random_params(opt, seed=int(rng.randint(1 << 30)), dtype=np.float32)
         batch = O.synthetic_batch(opt, B=B, T=T, K=K, t=t, seed=int(rng.randint(1 << 30)))
         dec = stattn.Decoder(opt, lt_mode=lt_mode, precision=precision)
@@ -67,9 +71,22 @@ def run(n, seed, large=False):
         eg, which = 0.0, ""
         for k in got:
             scale = np.abs(np.asarray(rg['grads'][k])).max()
+            if precision == "bf16" and k == 'decoder_b_sel':
+                # a SCALAR: the signed sum of the gate's pre-activation gradients over every (row, step).  Its bf16 error is a fraction of
+                # sum |terms|, not of |sum| -- and sum |terms| >= max |dW_sel| (dW_sel = sum term * h with |h| < 1).  Seed 8801 case 11:
+                # |sum| 6.5e-4 beside max |dW_sel| 2.4e-2, error 9e-5 (the fp32 handle: 2e-8) -- 14 % of |sum|, 0.4 % of the terms' scale.
+                scale = max(scale, np.abs(np.asarray(rg['grads']['decoder_W_sel'])).max())
             r = np.abs(got[k] - rg['grads'][k]).max() / (bar_g * scale + 5e-6)      # <= 1 passes (zero-gradient floor 5e-6)
             if r > eg:
                 eg, which = r, k
+        if only is not None:
+            d32 = stattn.Decoder(opt, lt_mode=lt_mode, precision="fp32")
+            d32.set_params(P); d32.set_batch(**batch); d32.forward_train(); d32.backward(alpha_c=alpha_c)
+            g32 = d32.get_grads()
+            for k in sorted(got):
+                ref_k = np.asarray(rg['grads'][k]); scale = np.abs(ref_k).max()
+                print("   %-28s scale %.3e  |got - ref| %.3e (%.4f of scale)  fp32 handle %.3e" %
+                      (k, scale, np.abs(got[k] - ref_k).max(), np.abs(got[k] - ref_k).max() / (scale + 1e-30), np.abs(g32[k] - ref_k).max()))
         ok = ef < 1e-4 and eg <= 1.0
         bad += not ok
         worst_f, worst_g = max(worst_f, ef), max(worst_g, eg)

@@ -699,6 +699,54 @@ def test_beam_update_rides_on_the_small_path_in_both_lt_modes(stattn_mod, O, mon
             assert s1[int(np.argmin(c1))] == sr[int(np.argmin(scr))]
 
 
+@pytest.mark.parametrize("lt_mode", [0, 1])
+def test_row_workgroup_update_is_bit_equal_to_the_single_workgroup_update(stattn_mod, O, monkeypatch, lt_mode):
+    """Beams of 2 .. 8 hypotheses on the <= 16-row path: the update of a word runs as k workgroups per video (each forms one live row's
+    log-sum-exp and its nsel best candidates; the last arriver of a video merges them and does the bookkeeping -- beam_inl.h).  Same
+    arithmetic value for value as one workgroup per video (STATTN_NO_ROW_WG=1): tokens, scores and final states bit-equal, riding in
+    the attention launch and as a launch of its own; the best hypothesis agrees with the float64 oracle."""
+    dims = dict(dim=128, dim_word=64, n_words=700, ctxg_dim=128, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=128)
+    opt = dict(O.default_options(**dims), lt_mode=lt_mode)
+    for seed, k, nvid in ((11, 2, 1), (12, 5, 1), (13, 8, 2), (14, 5, 3), (15, 3, 5)):
+        P = O.random_params(opt, seed=seed, dtype=np.float32)
+        P['ff_logit_b'] = (P['ff_logit_b'] + 1.0 * np.random.RandomState(seed).standard_normal(700)).astype(np.float32)
+        P['ff_logit_b'][0] += 1.0                       # <eos> likely: hypotheses die, live rows < k
+        P64 = O.cast_params(P, np.float64)
+        b = O.synthetic_batch(opt, B=nvid, T=5, K=3, t=3, seed=90 + seed)
+        model = stattn_mod.Attention()
+        f_init, f_next = model.build_sampler(model.init_tparams(P), opt, None, None)
+        dec = f_next.decoder
+        for noride in (False, True):
+            if noride:
+                monkeypatch.setenv('STATTN_NO_UPDATE_RIDER', '1')
+            else:
+                monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+            res = {}
+            for rowwg in (True, False):
+                if rowwg:
+                    monkeypatch.delenv('STATTN_NO_ROW_WG', raising=False)
+                else:
+                    monkeypatch.setenv('STATTN_NO_ROW_WG', '1')
+                r = dec.beam_search(b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=10)
+                assert (dec.path_counts()['upd_rowwg'] > 0) == rowwg
+                assert (dec.path_counts()['upd_rider'] > 0) == (not noride)
+                res[rowwg] = (r, dec.beam_final_state())
+            monkeypatch.delenv('STATTN_NO_ROW_WG', raising=False)
+            (r1, f1), (r2, f2) = res[True], res[False]
+            for v in range(nvid):
+                assert [list(x) for x in r1[v][0]] == [list(x) for x in r2[v][0]]
+                assert np.array_equal(np.asarray(r1[v][1], np.float32), np.asarray(r2[v][1], np.float32))
+                assert np.array_equal(f1[v][0], f2[v][0]) and np.array_equal(f1[v][1], f2[v][1])
+        monkeypatch.delenv('STATTN_NO_UPDATE_RIDER', raising=False)
+        for v in range(nvid):
+            args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+            a64 = tuple(a.astype(np.float64) for a in args)
+            sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_), lambda *a: O.f_next(P64, opt, *a), *a64, k=k, maxlen=10)
+            c1 = np.asarray(r1[v][1], np.float64)
+            np.testing.assert_allclose(sorted(c1), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=2e-4)
+            assert list(r1[v][0][int(np.argmin(c1))]) == list(sr[int(np.argmin(scr))])
+
+
 # ------------------------------------------------------------------ robustness
 def test_changing_batch_shapes_and_relu_like_features(stattn_mod, O):
     """Consecutive minibatches of different (t, m, T, K) on one handle (device buffers grow and are re-used), and

@@ -671,7 +671,7 @@ class Decoder(object):
         """Which kernels the decoder steps ran on: steps of the last forward_train (or f_next calls since) whose
         attention launch carried the h.U rider / that used the row-panel kernels, and the same for the reverse steps of
         the last backward.  Tests assert with it that a shape exercises the path it is meant to."""
-        names = ("fwd_rider", "fwd_panel", "bwd_rider", "bwd_panel", "upd_rider")
+        names = ("fwd_rider", "fwd_panel", "bwd_rider", "bwd_panel", "upd_rider", "upd_rowwg")
         return {n: int(self._lib.stattn_dbg_counter(self._h, i + 1)) for i, n in enumerate(names)}
 
     def time_gemm_bf16(self, M, N, K, tile=0, iters=20):

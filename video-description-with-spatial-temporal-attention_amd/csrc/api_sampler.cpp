@@ -442,6 +442,13 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     }
     int* d_ticket;
     CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
+    // Beams of 2 .. 8 hypotheses on the small path: k update workgroups per video (beam_inl.h, "row workgroups"); STATTN_NO_ROW_WG=1: one (A/B)
+    float* rw_cost = nullptr; int *rw_idx = nullptr, *rw_ticket = nullptr;
+    if (small && vocab_stats && !stochastic && k > 1 && !getenv("STATTN_NO_ROW_WG")) {
+        CHK(getbuf_t(h, "bs_rw_cost", (size_t)M * 8, &rw_cost)); CHK(getbuf_t(h, "bs_rw_idx", (size_t)M * 8, &rw_idx));
+        CHK(getbuf_t(h, "bs_rw_ticket", (size_t)nvid, &rw_ticket));
+        HIPCHK(h, hipMemsetAsync(rw_ticket, 0, (size_t)nvid * sizeof(int), s));
+    }
     {   // the initial beam (one live, empty, zero-score hypothesis per video on row v * k, next word -1, :871-893), its states,
         // the eval dropout multiplier, zeroed packed buffers, the zero embedding of the first word (:803-804), counters:
         // ONE launch (beam.hip beam_init_kernel) instead of twenty memsets and small copies
@@ -486,6 +493,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         ride = !noride && spatial_update_supported(probe);
     }
     h->path_upd_rider = 0;
+    h->path_upd_rowwg = 0;
     auto step_io = [&]() {
         StepIO io{};
         io.M = M; io.T = T; io.K = K; io.c = c; io.vid = vid; io.group = k;
@@ -587,6 +595,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         ba.Wemb = w.Wemb; ba.E = E; ba.emb_next = emb; ba.emb_next_pk = emb_pk; ba.ticket = d_ticket;
         if (vocab_stats) {
             ba.probs = nullptr; ba.stats = vstats; ba.ntile = vtile; ba.tile_cols = Vp / vtile; ba.stochastic = stochastic;
+            ba.rw_cost = rw_cost; ba.rw_idx = rw_idx; ba.rw_ticket = rw_ticket;
             if (small && !direct) { ba.proj_step = proj_step; ba.proj_next = proj; ba.nproj = 8 * D; }
             if (pre) { ba.rowmap = rowmap; ba.h_next_pk = nullptr; }          // (the packed h of the re-ordered beam has no reader any more)
             if (pre && !small) { ba.proj_step = preh_step; ba.proj_next = preh; ba.nproj = 4 * D; }
@@ -634,7 +643,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
                           (const void*)pn.U, (const void*)pn.Wc, (const void*)pn.W, (const void*)pn.Wl1, (const void*)pn.Wl2,
                           (const void*)pn.Wo, (const void*)end_h, (const void*)end_c, (const void*)end_rows, (const void*)hp_pk,
                           (const void*)ctx_pk, (const void*)emb_pk, (const void*)hd_pk, (const void*)a1_pk, (const void*)d_ticket,
-                          (const void*)proj, (const void*)proj_step, (const void*)ho_pk, (const void*)vstats})
+                          (const void*)proj, (const void*)proj_step, (const void*)ho_pk, (const void*)vstats, (const void*)rw_cost, (const void*)rw_ticket})
         sig.push_back((uintptr_t)q);
     hipGraphExec_t gexec8 = nullptr, gexec_last = nullptr;
     auto capture = [&](int nwords, bool ends = false) -> hipGraphExec_t {
@@ -696,6 +705,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     }
     if (rc_loop != STATTN_OK) return rc_loop;
     h->path_upd_rider = ride ? steps_run : 0;      // (replayed graphs included)
+    h->path_upd_rowwg = rw_cost ? steps_run : 0;
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
         const int fb = steps_run & 1;     // buffers written by the last executed step

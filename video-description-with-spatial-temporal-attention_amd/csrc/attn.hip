@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void spatial_small_update_kernel(const Spatial
 // contribute zeros), and what the 128-register budget of sixteen waves costs it disappears under the update beside it.
 __global__ __launch_bounds__(1024) void spatial_small_update_wide_kernel(const SpatialArgs a, const BeamArgs u) {
     const int items = a.M * a.T;
-    if ((int)blockIdx.x >= items) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x - items, u.nvid); return; }
+    if ((int)blockIdx.x >= items) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x - items, u.rw_cost ? u.nvid * u.k : u.nvid); return; }
     spatial_small_body(a);
 }
 
@@ -829,6 +829,10 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
         if (!spatial_update_supported(a) || !upd->stats || !upd->ticket || upd->nvid < 1 || upd->ntile < 1 || upd->k > PN_STATS_KB ||
             (upd->stochastic && (upd->k != 1 || upd->tile_cols < 1)) || (upd->proj_next && (!upd->proj_step || upd->nproj % 4)))
             return hipErrorInvalidValue;
+        BeamArgs u1;
+        if (upd->rw_cost && (spatial_shared_path(a) || upd->k < 2 || !upd->rw_idx || !upd->rw_ticket)) {     // row workgroups: the 1024-thread small launch only
+            u1 = *upd; u1.rw_cost = nullptr; upd = &u1;
+        }
         if (spatial_shared_path(a)) {
             const dim3 grid(a.M / a.group * a.T + upd->nvid), block(256);
             switch (a.group) {
@@ -843,7 +847,7 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
             return hipGetLastError();
         }
         const int nt = ((a.D / 4 + 63) / 64) * 64;
-        if (upd->k > 1) hipLaunchKernelGGL(spatial_small_update_wide_kernel, dim3(a.M * a.T + upd->nvid), dim3(1024), 0, s, a, *upd);
+        if (upd->k > 1) hipLaunchKernelGGL(spatial_small_update_wide_kernel, dim3(a.M * a.T + (upd->rw_cost ? upd->nvid * upd->k : upd->nvid)), dim3(1024), 0, s, a, *upd);
         else hipLaunchKernelGGL(spatial_small_update_kernel, dim3(a.M * a.T + upd->nvid), dim3(nt), 0, s, a, *upd);
         return hipGetLastError();
     }

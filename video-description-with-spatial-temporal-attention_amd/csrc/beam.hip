@@ -154,7 +154,9 @@ hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* par
     if (!a.ticket) return hipErrorInvalidValue;
     if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB || (a.stochastic && (a.k != 1 || a.tile_cols < 1)))) return hipErrorInvalidValue;
     if (a.proj_next && (!a.proj_step || a.nproj % 4)) return hipErrorInvalidValue;
-    hipLaunchKernelGGL(beam_update_kernel, dim3(a.nvid), dim3(a.stats ? 1024 : 256), 0, s, a, beam_topk_splits(a.nvid), part_cost, part_idx);
+    BeamArgs u = a;
+    if (u.rw_cost && !(u.stats && u.k > 1 && u.rw_idx && u.rw_ticket)) u.rw_cost = nullptr;     // row workgroups: statistics mode, k > 1 (1024 threads)
+    hipLaunchKernelGGL(beam_update_kernel, dim3(u.rw_cost ? u.nvid * u.k : u.nvid), dim3(u.stats ? 1024 : 256), 0, s, u, beam_topk_splits(u.nvid), part_cost, part_idx);
     return hipGetLastError();
 }
 

@@ -97,8 +97,18 @@ __device__ __forceinline__ void list_insert(float (&lc)[KB], int (&li)[KB], floa
 // (:923-928), then build the new hypotheses, retire the finished ones and gather the states (:939-985).
 // 256 threads per video, or 1024 on the small-batch path (launch_beam_update): a single video's selection is one workgroup's
 // serial work -- lse, candidate scan, selection, gathers -- and at k = 5 it was half of the decoded word
+//
+// Row workgroups (BeamArgs::rw_cost set: beams of 2 .. 8 hypotheses on the small path, 1024 threads): k workgroups per video instead
+// of one.  Workgroup (v, j) forms the log-sum-exp of live row j and the nsel best candidates of THAT row -- the nsel best overall are
+// among the rows' nsel best -- and leaves them in rw_cost / rw_idx; the last of a video's k workgroups to arrive (a ticket per video)
+// merges the <= 64 row winners and goes on with the bookkeeping and the gathers.  The arithmetic is the single workgroup's, value for
+// value: row j's tiles are walked by waves 0 .. wpr - 1 exactly as waves j, j + live, ... walk them there, the partials are combined
+// in the same order, a candidate's cost is the same expression; (cost, index) is a total order, so the selection is the same set in
+// the same order.  No workgroup waits for another (last arriver, no spin), so the launch cannot deadlock.
 __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, const float* __restrict__ pcost,
-                                                 const int* __restrict__ pidx, const int v, const int nwg) {
+                                                 const int* __restrict__ pidx, const int wg, const int nwg) {
+    const bool rw = a.rw_cost != nullptr;
+    const int v = rw ? wg / a.k : wg, jrow = rw ? wg - v * a.k : 0;
     __shared__ int s_slot[KB], s_fin[KB], s_ti[KB], s_wi[KB];
     __shared__ int s_n, s_ended, s_rows;
     __shared__ float s_c2[16 * KB];
@@ -111,7 +121,103 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
     const int live0 = a.live_k[v], dead0 = a.dead_k[v];
     const int nsel = live0 > 0 ? k - dead0 : 0;                // how many candidates survive (:923)
     BM_STAMP(1);
-    if (nsel > 0 && a.stats) {
+    // the word counter: every workgroup read *a.step when it started; the LAST one to get here (a ticket) knows all of them did, so
+    // it may write step + 1 for the next word's kernels (was a one-thread launch of its own)
+    auto advance_step = [&]() {
+        __syncthreads();
+        if (tid == 0) {
+            if (nwg == 1) {                            // one video, one workgroup: the last by construction
+                *a.step = step + 1;
+            } else {
+                __threadfence();
+                if (atomicAdd(a.ticket, 1) == nwg - 1) { *a.ticket = 0; *a.step = step + 1; }
+            }
+        }
+    };
+    if (rw) {
+        __shared__ int s_last;
+        __shared__ float s_m1[16], s_s1[16];
+        if (nsel > 0 && jrow < live0) {
+            const int live = live0, nt = a.ntile, lane = tid & 63, w = tid >> 6, nwv = NT >> 6;
+            const int C = nt * nsel;
+            const float r_nsel = 1.0f / (float)nsel;
+            const float* recs = a.stats + (size_t)(v * k + jrow) * nt * PN_STATS_REC;
+            constexpr int PFR = 6;                             // (752 tiles x 8 candidates over 1024 threads)
+            float pv[PFR]; int pi[PFR];
+#pragma unroll
+            for (int u = 0; u < PFR; ++u) {
+                const int e = u * NT + tid;
+                pv[u] = -INFINITY; pi[u] = 0x7fffffff;
+                if (e < C) {
+                    const int t = fdiv(e, nsel, r_nsel), i = e - t * nsel;
+                    const float* rec = recs + (size_t)t * PN_STATS_REC;
+                    pv[u] = rec[2 + i];
+                    pi[u] = jrow * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i];
+                }
+            }
+            const float hyp = a.hyp_score[v * k + jrow];
+            const int wpr = nwv / live;                        // waves per row of the single-workgroup pass (live <= 8 < 16 waves)
+            float rm = -INFINITY, rs = 0.f;
+            for (int t = w < wpr ? w * 64 + lane : nt; t < nt; t += wpr * 64) {
+                const float tm = recs[(size_t)t * PN_STATS_REC], ts = recs[(size_t)t * PN_STATS_REC + 1];
+                if (tm > -INFINITY) {
+                    const float nm = fmaxf(rm, tm);
+                    rs = rs * __expf(rm - nm) + ts * __expf(tm - nm);
+                    rm = nm;
+                }
+            }
+            const float wm = wave_max(rm);
+            const float ws = wave_sum(rm > -INFINITY ? rs * __expf(rm - wm) : 0.f);
+            if (lane == 0) { s_m1[w] = wm; s_s1[w] = ws; }
+            __syncthreads();
+            float m = -INFINITY;
+            for (int q = 0; q < nwv; ++q) m = fmaxf(m, s_m1[q]);
+            float ssum = 0.f;
+            for (int q = 0; q < nwv; ++q) if (s_m1[q] > -INFINITY) ssum += s_s1[q] * __expf(s_m1[q] - m);
+            const float lse = m + logf(ssum);
+            const bool one = live == 1;                        // (one live row: its log-sum-exp is added after the selection, as there)
+            const float base = one ? hyp : hyp + lse;
+            float lc[KB]; int li[KB];
+#pragma unroll
+            for (int i = 0; i < KB; ++i) { lc[i] = INFINITY; li[i] = 0x7fffffff; }
+#pragma unroll
+            for (int u = 0; u < PFR; ++u)
+                if (pv[u] > -INFINITY) list_insert(lc, li, base - pv[u], pi[u]);
+            for (int e = PFR * NT + tid; e < C; e += NT) {     // (vocabularies beyond 6 candidates per thread)
+                const int t = fdiv(e, nsel, r_nsel), i = e - t * nsel;
+                const float* rec = recs + (size_t)t * PN_STATS_REC;
+                const float val = rec[2 + i];
+                if (val > -INFINITY) list_insert(lc, li, base - val, jrow * V + reinterpret_cast<const int*>(rec)[2 + PN_STATS_KB + i]);
+            }
+            block_select2(lc, li, nsel, s_c2, s_i2, res_c, res_i);
+            if (tid < nsel) {
+                float c = res_c[tid];
+                if (one && res_i[tid] != 0x7fffffff) c += lse;
+                // (agent-scope stores: written through to where every XCD reads them, no L2 write-back of the whole cache as a release fence does)
+                __hip_atomic_store(a.rw_cost + (size_t)(v * k + jrow) * KB + tid, c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(a.rw_idx + (size_t)(v * k + jrow) * KB + tid, res_i[tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __builtin_amdgcn_s_waitcnt(0);                 // both stores acknowledged before the barrier in front of the ticket
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_last = atomicAdd(a.rw_ticket + v, 1) == k - 1;
+        __syncthreads();
+        if (!s_last) { advance_step(); return; }
+        if (tid == 0) a.rw_ticket[v] = 0;
+        if (nsel > 0 && tid < 64) {                            // merge of the <= live * nsel <= 64 row winners, one per lane
+            const int nrow = live0 * nsel;
+            const bool in = tid < nrow;
+            const int row = in ? tid / nsel : 0, r = in ? tid - row * nsel : 0;
+            const float c = in ? __hip_atomic_load(a.rw_cost + (size_t)(v * k + row) * KB + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : INFINITY;
+            const int ix = in ? __hip_atomic_load(a.rw_idx + (size_t)(v * k + row) * KB + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0x7fffffff;
+            unsigned long long key = cand_key(c, ix);
+            for (int q = 0; q < nsel; ++q) {
+                const unsigned long long best = wave_min_key(key);
+                if (tid == 0) { res_c[q] = key_cost(best); res_i[q] = (int)(unsigned)best; }
+                if (key == best) key = cand_key(INFINITY, 0x7fffffff);
+            }
+        }
+    } else if (nsel > 0 && a.stats) {
         // Small-batch decode: no probabilities were materialised.  The logits launch left, per (row, vocabulary tile),
         // the tile max, sum exp(v - max) and its best values; here: log-sum-exp per live row, then
         // cost = hyp_score - log p = hyp_score + lse - v for the tiles' candidates, merged like the slice winners above.
@@ -368,17 +474,7 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
         for (int i = tid; i < s_rows * D; i += NT) { a.end_h[base + i] = a.h_step[base + i]; a.end_c[base + i] = a.c_step[base + i]; }
     }
     BM_STAMP(6);
-    // Advance the word counter.  Every workgroup read *a.step when it started; the LAST one to get here (a ticket)
-    // knows all of them did, so it may write step + 1 for the next word's kernels (was a one-thread launch of its own).
-    __syncthreads();
-    if (tid == 0) {
-        if (nwg == 1) {                            // one video: this workgroup is the last by construction
-            *a.step = step + 1;
-        } else {
-            __threadfence();
-            if (atomicAdd(a.ticket, 1) == nwg - 1) { *a.ticket = 0; *a.step = step + 1; }
-        }
-    }
+    advance_step();
     BM_STAMP(7);
 }
 

@@ -458,6 +458,9 @@ struct BeamArgs {
     // ... and gathers the NEXT step's state projections (computed from h of this step before the beam was re-ordered)
     const float* proj_step; float* proj_next; int nproj;   // [nvid*k, nproj] rows (sproj | preh), or null
     float* end_h; float* end_c; int* end_rows;      // [nvid*k, D], [nvid]: f_next's state outputs of the word that ended a video's loop
+    // row workgroups (small path, k > 1; beam_inl.h): k update workgroups per video; null = one workgroup per video
+    float* rw_cost; int* rw_idx;        // [nvid*k, 8] the nsel best candidates of every live row
+    int* rw_ticket;                     // [nvid], zero: a video's last row workgroup merges them and does the bookkeeping
     int* rowmap;                        // optional [nvid*k]: row of the PARENT of the hypothesis now in each row (identity for unused rows): what the
                                         // temporal kernel needs when the next word's attention ran before the re-ordering (TemporalArgs::rowmap)
 };

@@ -30,7 +30,8 @@ __device__ void temporal_row(const Args& a, int b, int d0, int dn, int tid, int 
     // three softmaxes over T (T <= 64: one wave), then the weighted sums for columns [d0, d0 + dn)
     if (tid < 64) {
         for (int x = 0; x < 3; ++x) {
-            const float v = tid < a.T ? a.e[((size_t)x * a.M + b) * a.T + tid] : -INFINITY;
+            const float v = tid < a.T ? (a.fused == 2 ? __hip_atomic_load(a.e + ((size_t)x * a.M + b) * a.T + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+                                                      : a.e[((size_t)x * a.M + b) * a.T + tid]) : -INFINITY;
             float m = v;
             for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o, 64));
             const float ex = tid < a.T ? __expf(v - m) : 0.f;
@@ -48,7 +49,12 @@ __device__ void temporal_row(const Args& a, int b, int d0, int dn, int tid, int 
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
                 const int t = min(t0 + q, a.T - 1);
-                g[q] = ld4(a.G + base + (size_t)t * a.D); m[q] = ld4(a.Mo + base + (size_t)t * a.D); c[q] = ld4(a.CL + base + (size_t)t * a.D);
+                g[q] = ld4(a.G + base + (size_t)t * a.D); m[q] = ld4(a.Mo + base + (size_t)t * a.D);
+                if (a.fused == 2) {                            // variant C: what other workgroups of THIS launch wrote, read at agent scope
+                    const float* cp = a.CL + base + (size_t)t * a.D;
+                    c[q].x = __hip_atomic_load(cp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); c[q].y = __hip_atomic_load(cp + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    c[q].z = __hip_atomic_load(cp + 2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); c[q].w = __hip_atomic_load(cp + 3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                } else c[q] = ld4(a.CL + base + (size_t)t * a.D);
             }
 #pragma unroll
             for (int q = 0; q < 8; ++q) {
@@ -74,6 +80,26 @@ __global__ __launch_bounds__(256) void stream_kernel(const Args a) {
         for (int q = 0; q < 4; ++q) v[q] = ld4(sl + 4 * (i + q * 256 < a.slab_floats / 4 ? i + q * 256 : i));
 #pragma unroll
         for (int q = 0; q < 4; ++q) { acc.x += v[q].x; acc.y += v[q].y; acc.z += v[q].z; acc.w += v[q].w; }
+    }
+    if (a.fused == 2) {
+        // variant C (end of round 4): no fences.  The hand-off data is written with agent-scope stores (written through to where every XCD
+        // reads it), the stores are waited for, the ticket is a relaxed agent-scope add, the last arriver reads with agent-scope loads.
+        for (int d4 = tid; d4 < a.D / 4; d4 += 256) {
+            float* cp = a.CL + (size_t)bt * a.D + 4 * d4;
+            __hip_atomic_store(cp, acc.x, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(cp + 1, acc.y, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(cp + 2, acc.z, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); __hip_atomic_store(cp + 3, acc.w, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (tid < 3) __hip_atomic_store(a.e + ((size_t)tid * a.M + b) * a.T + t, acc.x * 1e-3f + 0.1f * t * (tid + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+            const int old = __hip_atomic_fetch_add(a.ticket + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            s_last = old == a.T - 1;
+            if (s_last) a.ticket[b] = 0;
+        }
+        __syncthreads();
+        if (s_last) temporal_row(a, b, 0, a.D, tid, 256, s_al);
+        return;
     }
     for (int d4 = tid; d4 < a.D / 4; d4 += 256) st4(a.CL + (size_t)bt * a.D + 4 * d4, acc);
     if (tid < 3) a.e[((size_t)tid * a.M + b) * a.T + t] = acc.x * 1e-3f + 0.1f * t * (tid + 1);
@@ -101,18 +127,18 @@ static void run(int M, int T, int D, size_t slab_bytes) {
     Args a{};
     a.M = M; a.T = T; a.D = D; a.slab_floats = slab_bytes / 4;
     const size_t items = (size_t)M * T;
-    float *slab, *G, *Mo, *CL, *e, *ctxA, *ctxB; int* tk;
+    float *slab, *G, *Mo, *CL, *e, *ctxA, *ctxB, *ctxC; int* tk;
     CK(hipMalloc(&slab, items * slab_bytes)); CK(hipMalloc(&G, items * D * 4)); CK(hipMalloc(&Mo, items * D * 4)); CK(hipMalloc(&CL, items * D * 4));
-    CK(hipMalloc(&e, 3 * items * 4)); CK(hipMalloc(&ctxA, (size_t)M * D * 4)); CK(hipMalloc(&ctxB, (size_t)M * D * 4)); CK(hipMalloc(&tk, M * 4));
+    CK(hipMalloc(&e, 3 * items * 4)); CK(hipMalloc(&ctxA, (size_t)M * D * 4)); CK(hipMalloc(&ctxB, (size_t)M * D * 4)); CK(hipMalloc(&ctxC, (size_t)M * D * 4)); CK(hipMalloc(&tk, M * 4));
     std::vector<float> hb(items * D);
     for (size_t i = 0; i < hb.size(); ++i) hb[i] = (float)((i * 2654435761u) % 1000) * 1e-3f - 0.5f;
     CK(hipMemcpy(G, hb.data(), hb.size() * 4, hipMemcpyHostToDevice)); CK(hipMemcpy(Mo, hb.data(), hb.size() * 4, hipMemcpyHostToDevice));
     CK(hipMemset(slab, 0, items * slab_bytes)); CK(hipMemset(tk, 0, M * 4));
     a.slab = slab; a.G = G; a.Mo = Mo; a.CL = CL; a.e = e; a.ticket = tk;
     hipEvent_t e0, e1; CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-    float ms[2];
-    for (int fused = 0; fused < 2; ++fused) {
-        a.fused = fused; a.ctx = fused ? ctxB : ctxA;
+    float ms[3];
+    for (int fused = 0; fused < 3; ++fused) {
+        a.fused = fused; a.ctx = fused == 2 ? ctxC : fused ? ctxB : ctxA;
         auto step = [&] {
             hipLaunchKernelGGL(stream_kernel, dim3((unsigned)items), dim3(256), 0, 0, a);
             if (!fused) hipLaunchKernelGGL(temporal_kernel, dim3(M, (D + 255) / 256), dim3(64), 0, 0, a);
@@ -123,12 +149,13 @@ static void run(int M, int T, int D, size_t slab_bytes) {
         CK(hipEventRecord(e1, 0)); CK(hipEventSynchronize(e1));
         CK(hipEventElapsedTime(&ms[fused], e0, e1));
     }
-    std::vector<float> A((size_t)M * D), B((size_t)M * D);
+    std::vector<float> A((size_t)M * D), B((size_t)M * D), Cc((size_t)M * D);
     CK(hipMemcpy(A.data(), ctxA, A.size() * 4, hipMemcpyDeviceToHost)); CK(hipMemcpy(B.data(), ctxB, B.size() * 4, hipMemcpyDeviceToHost));
-    double err = 0; for (size_t i = 0; i < A.size(); ++i) err = fmax(err, fabs((double)A[i] - B[i]));
-    printf("M=%3d T=%2d D=%4d slab %6.1f KB/item (%.0f MB per launch): two launches %6.2f us | last-arriver tail in one launch %6.2f us | max |diff| %.1e\n",
-           M, T, D, slab_bytes / 1024.0, items * slab_bytes / 1e6, ms[0] * 5.f, ms[1] * 5.f, err);
-    hipFree(slab); hipFree(G); hipFree(Mo); hipFree(CL); hipFree(e); hipFree(ctxA); hipFree(ctxB); hipFree(tk);
+    CK(hipMemcpy(Cc.data(), ctxC, Cc.size() * 4, hipMemcpyDeviceToHost));
+    double err = 0; for (size_t i = 0; i < A.size(); ++i) err = fmax(err, fmax(fabs((double)A[i] - B[i]), fabs((double)A[i] - Cc[i])));
+    printf("M=%3d T=%2d D=%4d slab %6.1f KB/item (%.0f MB per launch): two launches %6.2f us | last-arriver tail, fences %6.2f us | tail, agent-scope stores / loads, no fence %6.2f us | max |diff| %.1e\n",
+           M, T, D, slab_bytes / 1024.0, items * slab_bytes / 1e6, ms[0] * 5.f, ms[1] * 5.f, ms[2] * 5.f, err);
+    hipFree(slab); hipFree(G); hipFree(Mo); hipFree(CL); hipFree(e); hipFree(ctxA); hipFree(ctxB); hipFree(ctxC); hipFree(tk);
 }
 
 int main() {

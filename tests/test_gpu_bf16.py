@@ -143,7 +143,7 @@ def test_bf16_c4_bench_shape_rider_and_row_panel_path(B, t, tmp_path):
     np.testing.assert_allclose(out['cost'], ref['cost'], rtol=2e-2, atol=2e-2)
     dec.backward(alpha_c=0.70602)
     pc = dec.path_counts()
-    assert pc == dict(fwd_rider=t, fwd_panel=t, bwd_rider=t, bwd_panel=t, upd_rider=0), pc         # (1)
+    assert pc == dict(fwd_rider=t, fwd_panel=t, bwd_rider=t, bwd_panel=t, upd_rider=0, upd_rowwg=0), pc         # (1)
     got = dec.get_grads()
     f32 = stattn.Decoder(opt, lt_mode=1, precision="fp32")
     f32.set_params(P); f32.set_batch(**batch); f32.forward_train()

@@ -152,7 +152,13 @@ def run_beam(n, seed, only=None, verbose=False):
                 # the two loops round their candidate costs differently (device: (score + lse) - logit, host: score - log p, both float32):
                 # a near-tie at the pruning boundary may keep different survivors.  Accepted only when the device loop reproduces the
                 # float64 oracle's hypotheses and scores exactly -- then it is the host loop that sits on the other side of a tie.
-                if not (bs == sr and np.allclose(bsc, scr, rtol=1e-4, atol=1e-4)):
+                # ... or when both loops hold the SAME hypotheses with the same scores and merely list two of them whose scores are within
+                # 2e-4 of each other in the other order (seed 424242 case 119: 17.698643 / 17.698645 after four words, device order swapped
+                # against host and oracle, with and without the riding update)
+                same_set = (sorted(map(tuple, bs)) == sorted(map(tuple, s_)) and
+                            np.allclose([dict(zip(map(tuple, bs), bsc))[h_] for h_ in map(tuple, s_)], np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4) and
+                            all(tuple(x) == tuple(y) or abs(float(cx) - float(cy)) < 2e-4 for x, y, cx, cy in zip(bs, s_, bsc, sc)))
+                if not same_set and not (bs == sr and np.allclose(bsc, scr, rtol=1e-4, atol=1e-4)):
                     ok, why = False, "device loop != host loop (video %d)" % v
             elif len(bs) != len(sr) or not np.allclose(sorted(bsc), sorted(scr), rtol=1e-4, atol=1e-4):
                 # a near-tie at the beam boundary may swap which hypothesis survives; accept only if the oracle itself is that close

@@ -46,7 +46,7 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
             return fail(h, STATTN_EINVAL, "split kernel: N % 128 == 0, k-contiguous operands 16-byte aligned");
         hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);
         if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
-    } else if (kind == 2) {
+    } else if (kind == 2 || kind == 6) {
         // bf16-MFMA kernel: operands rounded to bf16 on the device, B kept k-contiguous ([N][K])
         if (transA || alpha != 1.f || K % 8 != 0) return fail(h, STATTN_EINVAL, "bf16 kernel: no transA, alpha must be 1, K % 8 == 0");
         uint16_t *bA, *bB;
@@ -60,8 +60,22 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         g.bias = bias ? dbias : nullptr;
         if (add) { g.add = dadd; g.ldadd = N; }
         g.act = act; g.rowgroup = 1;
+        float* dC2 = nullptr;
+        if (kind == 6) {
+            // two outputs in one launch (GemmBfArgs::n_split): columns >= N / 2 go to a second [M][N / 2] buffer with the
+            // second half of the bias; the halves are put side by side again for the caller
+            if (N % 128 != 0 || add) return fail(h, STATTN_EINVAL, "split-output GEMM: N % 128 == 0, no add");
+            CHK(getbuf_t(h, "dbg_C2", (size_t)M * N / 2, &dC2));
+            g.ldc = N / 2; g.n_split = N / 2; g.C2 = dC2; g.bias2 = bias ? dbias + N / 2 : nullptr;
+        }
         hipError_t e = launch_gemm_bf16(s, g);
         if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
+        if (kind == 6) {
+            HIPCHK(h, hipMemcpy2DAsync(C, (size_t)N * 4, dC, (size_t)N * 2, (size_t)N * 2, M, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipMemcpy2DAsync(C + N / 2, (size_t)N * 4, dC2, (size_t)N * 2, (size_t)N * 2, M, hipMemcpyDeviceToHost, s));
+            HIPCHK(h, hipStreamSynchronize(s));
+            return STATTN_OK;
+        }
     } else if (kind == 3) {
         // row-panel kernel: B repacked on the device (transB: the operand is B^T, packed straight from B [N][K])
         if (transA || alpha != 1.f || !panel_supported(M) || N % 16 || K % 16)

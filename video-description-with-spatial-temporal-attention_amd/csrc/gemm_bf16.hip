@@ -13,6 +13,7 @@
 // row: k = 16 kk + 8 (lane >> 5) + j.
 #include "kernels.h"
 #include "devmath.h"
+#include "gemm_bf16_epi.h"
 
 #include <cstdlib>
 
@@ -64,7 +65,8 @@ struct TileB {
     }
 };
 
-template <int TM, int TN, bool EDGE>
+// WIDE: the epilogue of gemm_bf16_epi.h (16-byte aligned rows everywhere); else one element at a time
+template <int TM, int TN, bool EDGE, bool WIDE>
 __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     using TA = TileB<BM>;
@@ -160,7 +162,13 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
     if (kt < nk) STATTN_BF16_TILE(kt, ra1, rb1)
 #undef STATTN_BF16_TILE
 
-    // epilogue.  32x32 C/D map (dtype independent): col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
+    if constexpr (WIDE) {
+        __syncthreads();                              // every wave is done reading the stages
+        float* stage = reinterpret_cast<float*>(smem) + wave * (bf16_epi::Stage<TN>::BYTES / 4);
+        bf16_epi::store_tile<TM, TN, true>(g, acc, stage, m0 + wm * 32 * TM, n0 + wn * 32 * TN, lane);
+        return;
+    }
+    // epilogue, one element at a time (unaligned outputs).  32x32 C/D map: col = lane & 31, row = (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
@@ -307,45 +315,8 @@ __global__ __launch_bounds__(512, 1) void gemm_bf16_glds_kernel(const GemmBfArgs
         __builtin_amdgcn_sched_barrier(0);
     }
 
-    // bf16-only output (L, PL, LW): each wave stages its 64 x 64 tile in LDS (free after the main loop) and writes
-    // whole 128-byte rows with 16-byte stores -- 8 store instructions per wave instead of 64 two-byte ones, which cost
-    // ~25 % of the kernel on the K = 1024 projections
-    const bool packed = g.Cb && !g.C && (g.ldcb % 8 == 0);
-    uint16_t* wtile = smem + wave * (64 * 64);
-    if (packed) __syncthreads();                                  // every wave is done reading the stages
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-#pragma unroll
-        for (int j = 0; j < 2; ++j) {
-            const int col = n0 + wn * 64 + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int lrow = i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;
-                const int row = m0 + wm * 64 + lrow;
-                if (MEDGE && row >= g.M) continue;
-                float v = acc[i][j][r] + bias;
-                if (g.add) v += g.add[(size_t)row * g.ldadd + col];
-                if (g.rowadd) v += g.rowadd[(size_t)(row / g.rowgroup) * g.ldrow + col];
-                if (g.act == 1) v = fast_tanh(v);
-                if (g.mul) v *= g.mul[(size_t)row * g.ldmul + col];
-                if (packed) { wtile[lrow * 64 + j * 32 + l31] = f2bf(v); continue; }
-                if (g.C) g.C[(size_t)row * g.ldc + col] = v;
-                if (g.Cb) g.Cb[(size_t)row * g.ldcb + col] = f2bf(v);
-            }
-        }
-    }
-    if (packed) {
-        // the wave reads back only what it wrote itself: LDS ordering within a wave needs no barrier
-#pragma unroll
-        for (int it = 0; it < 8; ++it) {
-            const int lrow = it * 8 + (lane >> 3), ch = lane & 7;
-            const int row = m0 + wm * 64 + lrow;
-            if (MEDGE && row >= g.M) continue;
-            const u32x4 v = *reinterpret_cast<const u32x4*>(wtile + lrow * 64 + 8 * ch);
-            *reinterpret_cast<u32x4*>(g.Cb + (size_t)row * g.ldcb + n0 + wn * 64 + 8 * ch) = v;
-        }
-    }
+    __syncthreads();                                  // every wave is done reading the stages
+    bf16_epi::store_tile<2, 2, MEDGE>(g, acc, reinterpret_cast<float*>(smem) + wave * (bf16_epi::STAGE_BYTES / 4), m0 + wm * 64, n0 + wn * 64, lane);
 }
 
 // dst[i] = bf16(src[i]), 8 elements per thread (n % 8 == 0, both 16-byte aligned)
@@ -384,8 +355,15 @@ template <int TM, int TN>
 hipError_t launch_tile(hipStream_t s, const GemmBfArgs& g) {
     const int BM = 64 * TM, BN = 64 * TN;
     const int tiles = ((g.M + BM - 1) / BM) * (g.N / BN);
-    if (g.K % BKB != 0) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, true>), dim3(tiles), dim3(256), 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, false>), dim3(tiles), dim3(256), 0, s, g);
+    const bool wide = bf16_epi::wide_ok(g) && (g.n_split <= 0 || g.n_split % BN == 0);
+    if (!wide && g.n_split > 0) return hipErrorInvalidValue;
+    if (wide) {
+        if (g.K % BKB != 0) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, true, true>), dim3(tiles), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, false, true>), dim3(tiles), dim3(256), 0, s, g);
+    } else {
+        if (g.K % BKB != 0) hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, true, false>), dim3(tiles), dim3(256), 0, s, g);
+        else hipLaunchKernelGGL((gemm_bf16_kernel<TM, TN, false, false>), dim3(tiles), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
@@ -400,9 +378,12 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     g.xcd_remap = noremap ? 0 : 1;
     // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 84 forces one for the sweep
     static const char* force = getenv("STATTN_BF16_TILE");
-    const bool glds_ok = g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB;      // M edge: clamped rows
+    const bool glds_ok = g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB && bf16_epi::wide_ok(g) && g.n_split % 128 == 0;      // M edge: clamped rows
     int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
     if (!g.tile && tile == 84 && !glds_ok) tile = 0;          // forced through the environment: only where it applies
+    if (!g.tile && tile == 22 && g.N % 128 != 0) tile = 0;
+    if (!g.tile && tile == 88 && !gemm_bf16_8ph_supported(g)) tile = 0;
+    if (tile == 88) return launch_gemm_bf16_8ph(s, g);
     if (tile == 84) {        // 256 x 128, 8 waves, direct-to-LDS staging
         if (!glds_ok) return hipErrorInvalidValue;
         if (g.M % 256) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3(((g.M + 255) / 256) * (g.N / 128)), dim3(512), 0, s, g);
@@ -413,6 +394,9 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (tile == 21) return launch_tile<2, 1>(s, g);
     if (tile == 22 && g.N % 128 == 0) return launch_tile<2, 2>(s, g);
     if (tile) return hipErrorInvalidValue;
+    // problems of at least half a round of 256 x 256 tiles: the eight-phase kernel (tools/gemm_bf16_sweep.py, round 5:
+    // 1215 against 916 TFLOP/s on the MSR-VTT ff_local shape, 644 against 440 on the logits)
+    if (gemm_bf16_8ph_supported(g) && (long)((g.M + 255) / 256) * (g.N / 256) >= 128) return launch_gemm_bf16_8ph(s, g);
     // large edge-free problems: the direct-to-LDS 256 x 128 kernel (881 vs 724 TFLOP/s on the MSR-VTT ff_local shape)
     if (glds_ok && (long)((g.M + 255) / 256) * (g.N / 128) >= 256) {
         if (g.M % 256) hipLaunchKernelGGL(gemm_bf16_glds_kernel<true>, dim3(((g.M + 255) / 256) * (g.N / 128)), dim3(512), 0, s, g);

@@ -75,10 +75,16 @@ struct GemmBfArgs {
     const float* rowadd; int ldrow; int rowgroup;
     int act;                           // 0 none, 1 tanh
     const float* mul; int ldmul;       // [M,N] multiplier applied after act (dropout mask), or null
-    int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) register-staged tile, 84 = 256 x 128 direct-to-LDS (sweep tool)
+    // two problems that share A in one launch (PL = L.Wcl + bl and LW = L.Wclt: B = [Wcl ; Wclt] stacked, N = both): columns
+    // >= n_split (a multiple of 256) go to C2 / Cb2 with bias2, same leading dimensions; 0 = one output
+    int n_split; float* C2; uint16_t* Cb2; const float* bias2;
+    int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) register-staged tile, 84 = 256 x 128 direct-to-LDS, 88 = 256 x 256 eight-phase (sweep tool)
     int xcd_remap;                     // internal
 };
 hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
+// the 256 x 256 eight-phase kernel (gemm_bf16_8ph.hip): N % 256 == 0, K % 64 == 0; launch_gemm_bf16 routes to it (tile 88)
+bool gemm_bf16_8ph_supported(const GemmBfArgs& g);
+hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& g);
 hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n);               // n % 8 == 0
 hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N);  // dst[n][k] = src[k][n]
 hipError_t launch_cvt_f32(hipStream_t s, const uint16_t* src, float* dst, size_t n);                 // exact widening, n % 8 == 0

@@ -1,5 +1,6 @@
 // Shared host-side building blocks of libstattn.so (declared in steps.h).  Orchestration only: every number is computed
 // by the hand-written gfx950 kernels (gemm*.hip, panel.hip, skinny.hip, attn.hip, misc.hip).
+#include <cstdlib>
 #include "steps.h"
 
 namespace stattn_detail {
@@ -61,9 +62,15 @@ int bf16_weights(stattn_handle* h, BfWeights* b, bool readout) {
         {"bw_W", w.W, E, 4 * D, &b->W, true}, {"bw_Wl1", w.Wl1, D, E, &b->Wl1, true},
         {"bw_Wl2", w.Wl2, D, E, &b->Wl2, true}, {"bw_Wo", w.Wo, E, Vp, &b->Wo, true},
     };
+    // Wcl and Wclt share one buffer, [Wcl^T ; Wclt^T] stacked: PL = L.Wcl + bl and LW = L.Wclt are ONE launch over N = 2 D
+    // columns (GemmBfArgs::n_split) -- 5 whole rounds of 256 x 256 tiles at configs[3] instead of twice 2.5
+    uint16_t* wcl2 = nullptr;
+    if (!readout) CHK(getbuf_t(h, "bw_Wcl_Wclt", (size_t)2 * D * D, &wcl2));
     for (const Item& it : items) {
         if (it.ro != readout || !it.src) continue;      // absent parameter (ff_logit_ctxglm without ctx2out)
-        CHK(getbuf_t(h, it.name, (size_t)it.K * it.N, it.dst));
+        if (it.dst == &b->Wcl) *it.dst = wcl2;
+        else if (it.dst == &b->Wclt) *it.dst = wcl2 + (size_t)D * D;
+        else CHK(getbuf_t(h, it.name, (size_t)it.K * it.N, it.dst));
         HIPCHK(h, launch_cvt_bf16_t(s, it.src, it.N, *it.dst, it.K, it.K, it.N));
     }
     return STATTN_OK;
@@ -109,14 +116,22 @@ static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const fl
     g = bf_args(xg, D, bw.Wcg, (int)nf, D, D);                                // pctxg_
     g.bias = w.bg; g.C = c.PG; g.ldc = D;
     HIPCHK(h, gemm_bf(h, g));
-    g = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                                // pctxl_
-    g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
-    HIPCHK(h, gemm_bf(h, g));
+    static const char* nofuse = getenv("STATTN_BF16_NOFUSE");                 // A/B switch for tools
+    if (D % 256 == 0 && !nofuse) {
+        g = bf_args(Lb, D, bw.Wcl, (int)nl, 2 * D, D);                        // pctxl_ | LW = L . [Wcl | Wclt]  (+ bl on the first half)
+        g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
+        g.n_split = D; g.Cb2 = reinterpret_cast<uint16_t*>(c.LW);
+        HIPCHK(h, gemm_bf(h, g));
+    } else {
+        g = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                            // pctxl_
+        g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
+        HIPCHK(h, gemm_bf(h, g));
+        g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                           // LW = L . Wclt
+        g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
+        HIPCHK(h, gemm_bf(h, g));
+    }
     g = bf_args(mo, D, bw.Wcm, (int)nf, D, D);                                // pctxm_
     g.bias = w.bm; g.C = c.PM; g.ldc = D;
-    HIPCHK(h, gemm_bf(h, g));
-    g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                               // LW = L . Wclt
-    g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
     HIPCHK(h, gemm_bf(h, g));
     return STATTN_OK;
 }

@@ -848,7 +848,11 @@ def main():
     else:
         tail = [[("readout_h", R, E, D)]] + ([[("readout_ctx", R, E, D)]] if options["ctx2out"] else []) + [[("logits", R, Vp, E)]]
     if bf16:
-        launches = [[x_] for x_ in proj1 + [proj2[0]] + [proj2[-1]] + proj2[1:-1]] + [[("xproj", R, 4 * D, E)]] + tail
+        if dec.lt_mode == 1 and D % 256 == 0 and not os.environ.get("STATTN_BF16_NOFUSE"):
+            # PL = L.Wcl + bl and LW = L.Wclt are ONE launch over N = 2 D columns with two outputs (csrc/steps.cpp)
+            launches = [[x_] for x_ in proj1] + [[("pctxl|L.Wclt", BTK, 2 * D, D)], [proj2[-1]], [("xproj", R, 4 * D, E)]] + tail
+        else:
+            launches = [[x_] for x_ in proj1 + [proj2[0]] + [proj2[-1]] + proj2[1:-1]] + [[("xproj", R, 4 * D, E)]] + tail
     elif os.environ.get("STATTN_GEMM_NOGROUP"):
         launches = [[x_] for x_ in proj1 + [("xproj", R, 4 * D, E)] + proj2] + tail
     else:
@@ -856,7 +860,7 @@ def main():
     nn_flops = sum(2.0 * m_ * n_ * k_ for l_ in launches for _, m_, n_, k_ in l_) + (2.0 * BT * D * D * t if dec.lt_mode == 0 else 0.0)
     g_ms, g_n = kms["gemm_nn"]
     per_fwd = g_n / 3.0
-    gname = "gemm_bf16_kernel<TM,TN>" if bf16 else ("gemm3_kernel<MT,NT,false,false,EDGE>" if split else "gemm2_kernel<TM,TN,false,false,EDGE>")
+    gname = "gemm_bf16_8ph_kernel / gemm_bf16_kernel<TM,TN>" if bf16 else ("gemm3_kernel<MT,NT,false,false,EDGE>" if split else "gemm2_kernel<TM,TN,false,false,EDGE>")
     ggroup = "gemm3_group_kernel" if split else "gemm2_group_kernel"
     roofline = dict(kernel="%s%s (all %d plain launches of one forward pass)" % (gname, "" if bf16 else " / " + ggroup, round(per_fwd)),
                     bound="mfma", achieved=(nn_flops / per_fwd) / (g_ms * 1e-3) / 1e12 if g_ms else None,

@@ -109,13 +109,14 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout
     // only as a = tanh(z) * d2.  The backward pass is the fp32 one, evaluated at those stored activations: they are widened
     // (exactly) into fp32 buffers, tanh(z) is recovered from a and the dropout multiplier, everything else was fp32 anyway.
-    if (h->opt.precision == 1) {
-        float *L32, *PL32, *LW32;
-        CHK(getbuf_t(h, "b_L32", MTK * D, &L32)); CHK(getbuf_t(h, "b_PL32", MTK * D, &PL32)); CHK(getbuf_t(h, "b_LW32", MTK * D, &LW32));
-        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(L), L32, MTK * D));
-        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(PL), PL32, MTK * D));
-        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(LW), LW32, MTK * D));
-        L = L32; PL = PL32; LW = LW32;
+    const bool bf = h->opt.precision == 1;
+    // the attention backward kernels read the region tensors as they are stored (bf16 on a bf16 handle: half their stream)
+    const float *Ls = L, *PLs = PL, *LWs = LW;
+    if (bf) {
+        float* L32;
+        CHK(getbuf_t(h, "b_L32", MTK * D, &L32));
+        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(L), L32, MTK * D));      // operand of the fp32 weight-gradient GEMMs
+        L = L32; PL = nullptr; LW = nullptr;
         HIPCHK(h, launch_unmul(s, a1, d2, tz, R * E));
     }
 
@@ -128,6 +129,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         gemm_defaults(g); g.split = h->opt.precision != 0;
         g.A = L; g.lda = D; g.B = w.Wclt; g.ldb = D; g.C = LW; g.ldc = D; g.M = (int)MTK; g.N = D; g.K = D;
         HIPCHK(h, launch_gemm(s, g, false, false));
+        LWs = LW;
     }
 
     // ---- regulariser terms d/d alpha (same for every step) and its value (:1138-1147)
@@ -264,7 +266,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         }
         {
             SpatialBwdArgs a{};
-            a.PL = PL; a.L = L; a.LW = LW; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
+            a.PL = PLs; a.L = Ls; a.LW = LWs; a.bf16 = bf ? 1 : 0; a.sproj = sproj + r0 * 4 * D; a.ldsp = 4 * D;
             a.dctxP = dctxP; a.nP = panels ? kz1 : KZ1; a.dctx_r = h->opt.ctx2out ? dctx_r + r0 * D : nullptr;
             a.csum = csum + r0 * D; a.sel = sel + r0; a.has_sel = h->opt.selector ? 1 : 0;
             a.cparts = cparts + r0 * 3 * D;
@@ -315,7 +317,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
                                 dph0, dpc0, m, D));
     {
         CtxGradArgs a{};
-        a.PL = PL; a.LW = LW; a.PG = PG; a.PM = PM; a.sproj = sproj; a.dcsum = dcsum; a.dplt = dplt;
+        a.PL = PLs; a.LW = LWs; a.bf16 = bf ? 1 : 0; a.PG = PG; a.PM = PM; a.sproj = sproj; a.dcsum = dcsum; a.dplt = dplt;
         a.alphal = al; a.del = del; a.alt = alt; a.delt = delt; a.am = am; a.deg = deg; a.dem = dem;
         a.Ul = w.Ul; a.Ult = w.Ult; a.Ug = w.Ug; a.Um = w.Um; a.blt = w.blt;
         a.dPL = dPL; a.dL = dL; a.dLW = dLW; a.dPG = dPG; a.dPM = dPM; a.dMo = dMo;

@@ -46,14 +46,17 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
             return fail(h, STATTN_EINVAL, "split kernel: N % 128 == 0, k-contiguous operands 16-byte aligned");
         hipError_t e = launch_gemm(s, g, transA != 0, transB != 0);
         if (e != hipSuccess) return fail(h, e == hipErrorInvalidValue ? STATTN_EINVAL : STATTN_EHIP, "dbg_gemm: %s", hipGetErrorString(e));
-    } else if (kind == 2 || kind == 6) {
-        // bf16-MFMA kernel: operands rounded to bf16 on the device, B kept k-contiguous ([N][K])
-        if (transA || alpha != 1.f || K % 8 != 0) return fail(h, STATTN_EINVAL, "bf16 kernel: no transA, alpha must be 1, K % 8 == 0");
+    } else if (kind == 2 || kind == 6 || kind == 7) {
+        // bf16-MFMA kernel: operands rounded to bf16 on the device and made k-contiguous (A [M][K], B [N][K]): a transposed
+        // operand goes through the transposing conversion the weight-gradient GEMMs of a bf16 handle use
+        if (alpha != 1.f || K % 8 != 0 || (transA && M % 8 != 0)) return fail(h, STATTN_EINVAL, "bf16 kernel: alpha must be 1, K % 8 == 0 (transA: M % 8 == 0)");
         uint16_t *bA, *bB;
         CHK(getbuf_t(h, "dbg_bA", (size_t)M * K, &bA));
         CHK(getbuf_t(h, "dbg_bB", (size_t)K * N, &bB));
-        HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
+        if (transA) HIPCHK(h, launch_transpose_to_bf16(s, dA, 0, M, bA, K, K, M));
+        else HIPCHK(h, launch_cvt_bf16(s, dA, bA, (size_t)M * K));
         if (transB) HIPCHK(h, launch_cvt_bf16(s, dB, bB, (size_t)K * N));
+        else if (N % 8 == 0) HIPCHK(h, launch_transpose_to_bf16(s, dB, 0, N, bB, K, K, N));
         else HIPCHK(h, launch_cvt_bf16_t(s, dB, N, bB, K, K, N));
         GemmBfArgs g{};
         g.A = bA; g.lda = K; g.B = bB; g.ldb = K; g.C = dC; g.ldc = N; g.M = M; g.N = N; g.K = K;
@@ -61,6 +64,13 @@ int stattn_dbg_gemm(stattn_handle* h, int kind, int transA, int transB, int M, i
         if (add) { g.add = dadd; g.ldadd = N; }
         g.act = act; g.rowgroup = 1;
         float* dC2 = nullptr;
+        if (kind == 7) {       // split-K of the 256 x 256 kernel (three slices, or what fills the chip if that is more)
+            float* dws;
+            g.tile = 88; g.kslices = gemm_bf16_8ph_slices(g) > 3 ? gemm_bf16_8ph_slices(g) : 3;
+            g.ws_floats = (size_t)g.kslices * M * N;
+            CHK(getbuf_t(h, "dbg_ws", g.ws_floats, &dws));
+            g.ws = dws;
+        }
         if (kind == 6) {
             // two outputs in one launch (GemmBfArgs::n_split): columns >= N / 2 go to a second [M][N / 2] buffer with the
             // second half of the bias; the halves are put side by side again for the caller

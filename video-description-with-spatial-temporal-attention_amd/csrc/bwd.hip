@@ -41,6 +41,19 @@ __device__ __forceinline__ void block_sum(float (&v)[N], float* s_red /*[nwaves]
     __syncthreads();
 }
 
+// four consecutive values of a region tensor at element offset `off`: fp32, or -- bf16 handles (BF): the tensor is stored
+// as bf16 behind the float pointer (steps.cpp project_context_bf16) -- one 8-byte load widened exactly
+template <bool BF>
+__device__ __forceinline__ float4 lds4(const float* base, size_t off) {
+    if constexpr (BF) {
+        const uint2 v = *reinterpret_cast<const uint2*>(reinterpret_cast<const uint16_t*>(base) + off);
+        return make_float4(__uint_as_float(v.x << 16), __uint_as_float(v.x & 0xffff0000u),
+                           __uint_as_float(v.y << 16), __uint_as_float(v.y & 0xffff0000u));
+    } else {
+        return ld4(base + off);
+    }
+}
+
 __device__ __forceinline__ float dot4(float4 a, float4 b) { return a.x * b.x + a.y * b.y + a.z * b.z + a.w * b.w; }
 __device__ __forceinline__ float4 tanh4s(float4 x, float4 s) {
     return make_float4(fast_tanh(x.x + s.x), fast_tanh(x.y + s.y), fast_tanh(x.z + s.z), fast_tanh(x.w + s.w));
@@ -169,7 +182,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_kernel(const LstmBwdArgs a) {
 // KR = regions whose LW rows a lane holds in registers across the two uses (plt, then the d alpha dot products): 8 at four
 // waves per SIMD (128 VGPRs), 16 at three (168) -- for 8 < K <= 16 (configs[3]) that saves the second pass over the LW slab
 // of the generic path.
-template <int KR>
+template <int KR, bool BF>
 __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const SpatialBwdArgs a) {
     __shared__ float s_red[4 * KR];
     __shared__ float s_al[KMAX], s_da[KMAX];
@@ -184,9 +197,9 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
     // all frames of a batch row on one XCD: they share the row's sproj, dcsum partials, csum / cparts
     const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, tid = threadIdx.x;
     const size_t slab = (size_t)bt * K * D;
-    const float* __restrict__ PL = a.PL + slab;
-    const float* __restrict__ L = a.L + slab;
-    const float* __restrict__ LW = a.LW + slab;
+    auto ldPL = [&](size_t o) { return lds4<BF>(a.PL, slab + o); };      // BF: the slabs are bf16 (half the stream of this kernel)
+    auto ldL = [&](size_t o) { return lds4<BF>(a.L, slab + o); };
+    auto ldLW = [&](size_t o) { return lds4<BF>(a.LW, slab + o); };
     const float* __restrict__ sp = a.sproj + (size_t)b * a.ldsp;
     const int nd4 = D >> 2;
     __shared__ float s_de[3];
@@ -198,7 +211,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
     float4 lw0[NPF];
     if (K <= KR) {
 #pragma unroll
-        for (int kk = 0; kk < NPF; ++kk) lw0[kk] = ld4(LW + (size_t)min(kk, K - 1) * D + 4 * min(tid, nd4 - 1));
+        for (int kk = 0; kk < NPF; ++kk) lw0[kk] = ldLW((size_t)min(kk, K - 1) * D + 4 * min(tid, nd4 - 1));
     }
     // ---- temporal part
     const int tf = bt - b * T;
@@ -280,7 +293,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
             float4 lw[KR];
 #pragma unroll
             for (int kk = 0; kk < KR; ++kk)
-                lw[kk] = (kk < NPF && d4 == tid) ? lw0[kk < NPF ? kk : 0] : ld4(LW + (size_t)min(kk, K - 1) * D + 4 * d4);
+                lw[kk] = (kk < NPF && d4 == tid) ? lw0[kk < NPF ? kk : 0] : ldLW((size_t)min(kk, K - 1) * D + 4 * d4);
             float4 pl = ld4(a.blt + 4 * d4);
 #pragma unroll
             for (int kk = 0; kk < KR; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
@@ -290,7 +303,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
             const float4 dcl = scale4(dcs_lds ? ld4(&s_dcs[4 * d4]) : scale4(form_dcs(d4), sel), alt);
 #pragma unroll
             for (int kk = 0; kk < KR; ++kk)
-                p[kk] += dot4(dcl, ld4(L + (size_t)min(kk, K - 1) * D + 4 * d4)) + dot4(dpl, lw[kk]);
+                p[kk] += dot4(dcl, ldL((size_t)min(kk, K - 1) * D + 4 * d4)) + dot4(dpl, lw[kk]);
         }
         block_sum<KR>(p, s_red, tid, 4);
         if (tid < KR && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
@@ -299,7 +312,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
         for (int d4 = tid; d4 < nd4; d4 += 256) {
             float4 pl = ld4(a.blt + 4 * d4);
 #pragma unroll 8
-            for (int k = 0; k < K; ++k) fma4(pl, s_al[k], ld4(LW + (size_t)k * D + 4 * d4));
+            for (int k = 0; k < K; ++k) fma4(pl, s_al[k], ldLW((size_t)k * D + 4 * d4));
             const float4 th = tanh4s(pl, ld4(sp + 3 * D + 4 * d4));
             st4(a.dplt + (size_t)bt * D + 4 * d4, scale4(mul4(ld4(a.Ult + 4 * d4), one_minus_sq(th)), delt));
         }
@@ -314,7 +327,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
 #pragma unroll
                 for (int kk = 0; kk < 8; ++kk) {
                     const size_t o = (size_t)min(k0 + kk, K - 1) * D + 4 * d4;
-                    p[kk] += dot4(dcl, ld4(L + o)) + dot4(dpl, ld4(LW + o));
+                    p[kk] += dot4(dcl, ldL(o)) + dot4(dpl, ldLW(o));
                 }
             }
             block_sum<8>(p, s_red, tid, 4);
@@ -337,7 +350,7 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
         const float4 sl = ld4(sp + 4 * d4);
         float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 8
-        for (int k = 0; k < K; ++k) fma4(acc, s_da[k], one_minus_sq(tanh4s(ld4(PL + (size_t)k * D + 4 * d4), sl)));
+        for (int k = 0; k < K; ++k) fma4(acc, s_da[k], one_minus_sq(tanh4s(ldPL((size_t)k * D + 4 * d4), sl)));
         st4(a.dslp + (size_t)bt * D + 4 * d4, mul4(acc, ld4(a.Ul + 4 * d4)));
     }
 }
@@ -385,7 +398,7 @@ __global__ __launch_bounds__(256) void reduce_T_kernel(const float* __restrict__
 // KR = 8 (K <= 8): the frame workgroup also forms the dUlt partial, the frame's LW slab in registers (NG + 1 workgroups per
 // item).  KR = 16 (K > 8): the dUlt partial has a workgroup of its own with up to 16 LW rows in registers (NG + 2): with the
 // rows re-read from L2 every step, configs[3] (K = 16) took 1065 us; split at K <= 8 as well it is slower (291 vs 237 us).
-template <int KR>
+template <int KR, bool BF>
 __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, const int NG) {
     constexpr bool WITH_ULT = KR <= 8;           // frame workgroup also does the dUlt partial
     const int S = a.S, M = a.M, T = a.T, K = a.K, D = a.D;
@@ -412,7 +425,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             const float4 pg = exp2x4(ld4(a.PG + fo)), pm = exp2x4(ld4(a.PM + fo));
             float4 lw[8];                          // the frame's LW slab (K <= 8): plt = blt + sum_k alpha_k LW_k is recomputed per step
 #pragma unroll
-            for (int k = 0; k < 8; ++k) lw[k] = (WITH_ULT && K <= 8) ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < 8; ++k) lw[k] = (WITH_ULT && K <= 8) ? lds4<BF>(a.LW, slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 dpg = make_float4(0.f, 0.f, 0.f, 0.f), dpm = dpg, dmo = dpg, ug = dpg, um = dpg, pult = dpg;
             float sdeg = 0.f, sdem = 0.f;
             struct FrameIn { float4 sg, sm, slt, dcs; float deg, dem, am, delt; float al[8]; };
@@ -444,7 +457,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
                     for (int k = 0; k < 8; ++k) if (k < K) fma4(plt, cf.al[k], lw[k]);
                 } else {
                     const float* als = a.alphal + (s * MT + bt) * K;
-                    for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
+                    for (int k = 0; k < K; ++k) fma4(plt, als[k], lds4<BF>(a.LW, slab + (size_t)k * D + 4 * d4));
                 }
                 fma4(pult, cf.delt, tanh4s(plt, cf.slt));
             }
@@ -466,7 +479,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
             const float4 blt = ld4(a.blt + 4 * d4);
             float4 lw[KR];
 #pragma unroll
-            for (int k = 0; k < KR; ++k) lw[k] = K <= KR ? ld4(a.LW + slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int k = 0; k < KR; ++k) lw[k] = K <= KR ? lds4<BF>(a.LW, slab + (size_t)min(k, K - 1) * D + 4 * d4) : make_float4(0.f, 0.f, 0.f, 0.f);
             float4 pult = make_float4(0.f, 0.f, 0.f, 0.f);
             struct UltIn { float4 slt; float delt; float al[KR]; };
             auto fetch_u = [&](int s_) {
@@ -488,7 +501,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
                     for (int k = 0; k < KR; ++k) if (k < K) fma4(plt, cu.al[k], lw[k]);
                 } else {
                     const float* als = a.alphal + (s * MT + bt) * K;
-                    for (int k = 0; k < K; ++k) fma4(plt, als[k], ld4(a.LW + slab + (size_t)k * D + 4 * d4));
+                    for (int k = 0; k < K; ++k) fma4(plt, als[k], lds4<BF>(a.LW, slab + (size_t)k * D + 4 * d4));
                 }
                 fma4(pult, cu.delt, tanh4s(plt, cu.slt));
             }
@@ -505,7 +518,7 @@ __global__ __launch_bounds__(256, 3) void ctxgrad_kernel(const CtxGradArgs a, co
         float4 pl[4], dpl[4], dl[4], dlw[4];
 #pragma unroll
         for (int kk = 0; kk < 4; ++kk) {
-            pl[kk] = exp2x4(ld4(a.PL + slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4));       // e^{2 PL} (see the frame part)
+            pl[kk] = exp2x4(lds4<BF>(a.PL, slab + (size_t)min(k0 + kk, K - 1) * D + 4 * d4));       // e^{2 PL} (see the frame part)
             dpl[kk] = make_float4(0.f, 0.f, 0.f, 0.f); dl[kk] = dpl[kk]; dlw[kk] = dpl[kk];
         }
         struct StepIn { float4 sl, dcs, dp; float alt; float al[4], de[4]; };
@@ -812,8 +825,13 @@ hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     if (a.K > KMAX) return hipErrorInvalidValue;
     if (a.rider.nblocks && !rider_shape_ok(a.rider)) return hipErrorInvalidValue;
     if (!a.cparts || !a.csum || !a.dctxP || !a.dcsum || !a.dselpre) return hipErrorInvalidValue;
-    if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL(spatial_bwd_kernel<16>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
-    else hipLaunchKernelGGL(spatial_bwd_kernel<8>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
+    const dim3 grid(a.M * a.T + a.rider.nblocks);
+    if (a.bf16) {
+        if (a.D % 4) return hipErrorInvalidValue;
+        if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL((spatial_bwd_kernel<16, true>), grid, dim3(256), 0, s, a);
+        else hipLaunchKernelGGL((spatial_bwd_kernel<8, true>), grid, dim3(256), 0, s, a);
+    } else if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL((spatial_bwd_kernel<16, false>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((spatial_bwd_kernel<8, false>), grid, dim3(256), 0, s, a);
     return hipGetLastError();
 }
 hipError_t launch_reduce_T(hipStream_t s, const float* dslp, const float* dsgp, const float* dsmp, const float* dplt,
@@ -826,8 +844,11 @@ int ctxgrad_groups(int K) { return (K + 3) / 4; }
 hipError_t launch_ctxgrad(hipStream_t s, const CtxGradArgs& a) {
     const int NG = ctxgrad_groups(a.K);
     const int items8 = (a.M * a.T + 7) / 8;
-    if (a.K <= 8) hipLaunchKernelGGL(ctxgrad_kernel<8>, dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
-    else hipLaunchKernelGGL(ctxgrad_kernel<16>, dim3(items8 * 8 * (NG + 2)), dim3(256), 0, s, a, NG);
+    if (a.bf16) {
+        if (a.K <= 8) hipLaunchKernelGGL((ctxgrad_kernel<8, true>), dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
+        else hipLaunchKernelGGL((ctxgrad_kernel<16, true>), dim3(items8 * 8 * (NG + 2)), dim3(256), 0, s, a, NG);
+    } else if (a.K <= 8) hipLaunchKernelGGL((ctxgrad_kernel<8, false>), dim3(items8 * 8 * (NG + 1)), dim3(256), 0, s, a, NG);
+    else hipLaunchKernelGGL((ctxgrad_kernel<16, false>), dim3(items8 * 8 * (NG + 2)), dim3(256), 0, s, a, NG);
     return hipGetLastError();
 }
 // dst[n] (+)= sum_r X[r, n]; `part` must hold colsum_parts(rows, N) * N floats

@@ -408,6 +408,83 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     return launch_tile<1, 1>(s, g);
 }
 
+__global__ __launch_bounds__(256) void cvt_bf16_2d_kernel(const float* __restrict__ src, size_t ld_src, uint16_t* __restrict__ dst, size_t ld_dst,
+                                                          size_t rows, int c8) {
+    const size_t total = rows * c8;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const size_t r = i / c8; const int c = (int)(i % c8) * 8;
+        const float4 x = ld4(src + r * ld_src + c), y = ld4(src + r * ld_src + c + 4);
+        uint4 o;
+        o.x = f2bf(x.x) | ((uint32_t)f2bf(x.y) << 16);
+        o.y = f2bf(x.z) | ((uint32_t)f2bf(x.w) << 16);
+        o.z = f2bf(y.x) | ((uint32_t)f2bf(y.y) << 16);
+        o.w = f2bf(y.z) | ((uint32_t)f2bf(y.w) << 16);
+        *reinterpret_cast<uint4*>(dst + r * ld_dst + c) = o;
+    }
+}
+hipError_t launch_cvt_bf16_2d(hipStream_t s, const float* src, size_t ld_src, uint16_t* dst, size_t ld_dst, size_t rows, int cols) {
+    if (rows == 0 || cols <= 0) return hipSuccess;
+    if (cols % 8 || ld_src % 4 || ld_dst % 8) return hipErrorInvalidValue;
+    const size_t total = rows * (cols / 8);
+    size_t nb = (total + 255) / 256; if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(cvt_bf16_2d_kernel, dim3((unsigned)nb), dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols / 8);
+    return hipGetLastError();
+}
+
+// dst[c][r] = bf16(src[r][c]): 64 x 64 tiles through LDS as DWORDS (a pair of neighbouring source columns per word, row pitch 33
+// words): the source is read 16 bytes per lane along its rows; on the way out a lane collects the same word of eight consecutive
+// source rows (2-way bank conflicts at worst) and splits it into the 16-byte runs of TWO destination rows, so that 8 lanes write
+// 128 contiguous bytes
+template <bool SRC_BF>
+__global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __restrict__ srcv, size_t ld_src, uint16_t* __restrict__ dst, size_t ld_dst,
+                                                                int rows, int cols) {
+    __shared__ uint32_t tile[64][33];
+    const int tid = threadIdx.x;
+    const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+    if constexpr (SRC_BF) {
+        const uint16_t* src = static_cast<const uint16_t*>(srcv);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {                 // 64 rows x 8 chunks of 8 bf16
+            const int idx = tid + 256 * i, r = idx >> 3, c = (idx & 7) * 8;
+            uint4 v = make_uint4(0u, 0u, 0u, 0u);
+            if (r0 + r < rows && c0 + c < cols) v = *reinterpret_cast<const uint4*>(src + (size_t)(r0 + r) * ld_src + c0 + c);
+            tile[r][c / 2] = v.x; tile[r][c / 2 + 1] = v.y; tile[r][c / 2 + 2] = v.z; tile[r][c / 2 + 3] = v.w;
+        }
+    } else {
+        const float* src = static_cast<const float*>(srcv);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {                 // 64 rows x 16 chunks of 4 floats
+            const int idx = tid + 256 * i, r = idx >> 4, c = (idx & 15) * 4;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r0 + r < rows && c0 + c < cols) v = ld4(src + (size_t)(r0 + r) * ld_src + c0 + c);
+            tile[r][c / 2] = f2bf(v.x) | ((uint32_t)f2bf(v.y) << 16);
+            tile[r][c / 2 + 1] = f2bf(v.z) | ((uint32_t)f2bf(v.w) << 16);
+        }
+    }
+    __syncthreads();
+    const int rg = tid & 7, c2 = tid >> 3;
+    if (r0 + 8 * rg >= rows || c0 + 2 * c2 >= cols) return;
+    uint32_t w[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) w[j] = tile[8 * rg + j][c2];
+    uint4 lo, hi;
+    lo.x = (w[0] & 0xffffu) | (w[1] << 16); hi.x = (w[0] >> 16) | (w[1] & 0xffff0000u);
+    lo.y = (w[2] & 0xffffu) | (w[3] << 16); hi.y = (w[2] >> 16) | (w[3] & 0xffff0000u);
+    lo.z = (w[4] & 0xffffu) | (w[5] << 16); hi.z = (w[4] >> 16) | (w[5] & 0xffff0000u);
+    lo.w = (w[6] & 0xffffu) | (w[7] << 16); hi.w = (w[6] >> 16) | (w[7] & 0xffff0000u);
+    uint16_t* d = dst + (size_t)(c0 + 2 * c2) * ld_dst + r0 + 8 * rg;
+    *reinterpret_cast<uint4*>(d) = lo;
+    *reinterpret_cast<uint4*>(d + ld_dst) = hi;
+}
+hipError_t launch_transpose_to_bf16(hipStream_t s, const void* src, int src_is_bf16, size_t ld_src, uint16_t* dst, size_t ld_dst, int rows, int cols) {
+    if (rows <= 0 || cols <= 0) return hipSuccess;
+    if (rows % 8 || cols % 8 || ld_dst % 8 || ld_src % (src_is_bf16 ? 8 : 4)) return hipErrorInvalidValue;
+    const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+    if (src_is_bf16) hipLaunchKernelGGL(transpose_to_bf16_kernel<true>, grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    else hipLaunchKernelGGL(transpose_to_bf16_kernel<false>, grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
+    return hipGetLastError();
+}
+
 hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n) {
     if (n == 0) return hipSuccess;
     if (n % 8 != 0) return hipErrorInvalidValue;

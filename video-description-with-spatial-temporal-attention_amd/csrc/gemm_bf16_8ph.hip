@@ -101,12 +101,18 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8ph_kernel(const GemmBfArgs 
     const i32x4 rsA = make_rsrc(g.A + (size_t)m0 * g.lda);
     const i32x4 rsB = make_rsrc(g.B + (size_t)n0 * g.ldb);
     const unsigned ldsw = lds0 + (unsigned)wave * 1024u;
-    const int nk = g.K / BK8;
+    // deterministic split-K (kslices > 1: weight-gradient shapes, small M x N and a huge K): blockIdx.y owns a run of K-tiles and
+    // leaves an fp32 partial tile in g.ws; splitk_reduce_bf_kernel adds the slices in order and applies the epilogue
+    const int nk_all = g.K / BK8, kslices = g.kslices > 1 ? g.kslices : 1;
+    const int kper = (nk_all + kslices - 1) / kslices;
+    const int kbeg = (int)blockIdx.y * kper;
+    const int nk = min(kper, nk_all - kbeg);
+    const unsigned kbase = (unsigned)kbeg * 128u;
 
     // part 0 / 1 = A rows 0-127 / 128-255, part 2 / 3 = B columns 0-127 / 128-255 of K-tile kt, into buffer s
 #define DMA_PART(s, part, kt)                                                                                 \
     {                                                                                                         \
-        const unsigned so_ = (unsigned)(kt) * 128u;                                                           \
+        const unsigned so_ = kbase + (unsigned)(kt) * 128u;                                                           \
         const unsigned ld_ = ldsw + (unsigned)(s) * KBUF + (unsigned)(part) * PART;                           \
         if (!(VAR & 8) || (kt) < 2) {                                                                         \
         if ((part) < 2) { dma16(voa[(part) & 1][0], rsA, so_, ld_); dma16(voa[(part) & 1][1], rsA, so_, ld_ + 8192u); } \
@@ -224,14 +230,49 @@ __global__ __launch_bounds__(512, 2) void gemm_bf16_8ph_kernel(const GemmBfArgs 
         return;
     }
     __syncthreads();                                  // every wave is done reading the K-tile buffers
-    bf16_epi::store_tile<4, 2, MEDGE>(g, acc, reinterpret_cast<float*>(smem + wave * bf16_epi::STAGE_BYTES), m0 + wr * 128, n0 + wc * 64, lane);
+    float* stage = reinterpret_cast<float*>(smem + wave * bf16_epi::STAGE_BYTES);
+    if (kslices > 1) {
+        GemmBfArgs gp{};                              // the raw partial tile of this K-slice
+        gp.M = g.M; gp.N = g.N; gp.C = g.ws + (size_t)blockIdx.y * g.M * g.N; gp.ldc = g.N; gp.rowgroup = 1;
+        bf16_epi::store_tile<4, 2, MEDGE>(gp, acc, stage, m0 + wr * 128, n0 + wc * 64, lane);
+        return;
+    }
+    bf16_epi::store_tile<4, 2, MEDGE>(g, acc, stage, m0 + wr * 128, n0 + wc * 64, lane);
+}
+
+// C = epilogue(sum over the K-slices of the partial tiles), four consecutive columns per thread, slices added in order
+__global__ __launch_bounds__(256) void splitk_reduce_bf_kernel(const GemmBfArgs g) {
+    const int n4 = g.N >> 2;
+    const size_t total = (size_t)g.M * n4, MN = (size_t)g.M * g.N;
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+        const int row = (int)(i / n4);
+        int col = (int)(i % n4) * 4;
+        float4 v = ld4(g.ws + (size_t)row * g.N + col);
+        for (int sl = 1; sl < g.kslices; ++sl) {
+            const float4 p = ld4(g.ws + sl * MN + (size_t)row * g.N + col);
+            v.x += p.x; v.y += p.y; v.z += p.z; v.w += p.w;
+        }
+        const bf16_epi::Out o = bf16_epi::select_out(g, col);
+        if (o.bias) { const float4 b = ld4(o.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (g.add) { const float4 b = ld4(g.add + (size_t)row * g.ldadd + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (g.rowadd) { const float4 b = ld4(g.rowadd + (size_t)(row / g.rowgroup) * g.ldrow + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (g.act == 1) { v.x = fast_tanh(v.x); v.y = fast_tanh(v.y); v.z = fast_tanh(v.z); v.w = fast_tanh(v.w); }
+        if (g.mul) { const float4 b = ld4(g.mul + (size_t)row * g.ldmul + col); v.x *= b.x; v.y *= b.y; v.z *= b.z; v.w *= b.w; }
+        if (o.C) st4(o.C + (size_t)row * g.ldc + col, v);
+        if (o.Cb) *reinterpret_cast<uint2*>(o.Cb + (size_t)row * g.ldcb + col) = make_uint2(bf16_epi::pack_bf16(v.x, v.y), bf16_epi::pack_bf16(v.z, v.w));
+    }
 }
 
 template <int VAR>
 hipError_t launch_var(hipStream_t s, const GemmBfArgs& g) {
     const int tiles = ((g.M + 255) / 256) * (g.N / 256);
-    if (g.M % 256) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, true>), dim3(tiles), dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, false>), dim3(tiles), dim3(512), 0, s, g);
+    const dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1);
+    if (g.M % 256) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, true>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, false>), grid, dim3(512), 0, s, g);
+    if (g.kslices > 1) {
+        const size_t total = (size_t)g.M * (g.N / 4);
+        hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, s, g);
+    }
     return hipGetLastError();
 }
 
@@ -242,8 +283,24 @@ bool gemm_bf16_8ph_supported(const GemmBfArgs& g) {
            (size_t)256 * g.lda * 2 < 0xffffffffull && (size_t)256 * g.ldb * 2 < 0xffffffffull && bf16_epi::wide_ok(g);
 }
 
-hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& g) {
+// K-slices for a problem of `tiles` 256 x 256 tiles and nk K-tiles: fill the 256 CUs, at least 8 K-tiles per slice
+int gemm_bf16_8ph_slices(const GemmBfArgs& g) {
+    const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
+    const int nk = g.K / BK8;
+    if (tiles >= 192 || nk < 16) return 1;
+    int sl = (int)((256 + tiles - 1) / tiles);
+    if (sl > nk / 8) sl = nk / 8;
+    return sl < 1 ? 1 : sl;
+}
+
+hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& gin) {
+    GemmBfArgs g = gin;
     if (!gemm_bf16_8ph_supported(g)) return hipErrorInvalidValue;
+    if (g.kslices > 1) {
+        const int nk = g.K / BK8, kper = (nk + g.kslices - 1) / g.kslices;
+        g.kslices = (nk + kper - 1) / kper;           // no empty slice
+        if (!g.ws || g.ws_floats < (size_t)g.kslices * g.M * g.N || ((size_t)g.ws & 15) || g.N % 4) return hipErrorInvalidValue;
+    }
     static const char* var = getenv("STATTN_8PH_VAR");       // ablations (tools/gemm_8ph_probe.py); the product runs variant 0
     const int v = var ? atoi(var) : 0;
     if (v == 1) return launch_var<1>(s, g);

@@ -78,6 +78,9 @@ struct GemmBfArgs {
     // two problems that share A in one launch (PL = L.Wcl + bl and LW = L.Wclt: B = [Wcl ; Wclt] stacked, N = both): columns
     // >= n_split (a multiple of 256) go to C2 / Cb2 with bias2, same leading dimensions; 0 = one output
     int n_split; float* C2; uint16_t* Cb2; const float* bias2;
+    // deterministic split-K of the 256 x 256 kernel (tile 88 only): kslices > 1 cuts K, fp32 partial tiles go to ws
+    // (>= kslices * M * N floats) and a second kernel adds them in order and applies the epilogue
+    int kslices; float* ws; size_t ws_floats;
     int tile;                          // 0 = choose; 11 / 21 / 22 = (64*TM) x (64*TN) register-staged tile, 84 = 256 x 128 direct-to-LDS, 88 = 256 x 256 eight-phase (sweep tool)
     int xcd_remap;                     // internal
 };
@@ -85,6 +88,11 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
 // the 256 x 256 eight-phase kernel (gemm_bf16_8ph.hip): N % 256 == 0, K % 64 == 0; launch_gemm_bf16 routes to it (tile 88)
 bool gemm_bf16_8ph_supported(const GemmBfArgs& g);
 hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& g);
+int gemm_bf16_8ph_slices(const GemmBfArgs& g);     // K-slices that fill the chip for this shape (1 = none)
+// dst[r * ld_dst + c] = bf16(src[r * ld_src + c]), c < cols (cols % 8 == 0; 16-byte aligned rows): K-concatenated operands
+hipError_t launch_cvt_bf16_2d(hipStream_t s, const float* src, size_t ld_src, uint16_t* dst, size_t ld_dst, size_t rows, int cols);
+// dst[c * ld_dst + r] = bf16(src[r * ld_src + c]): k-contiguous operands of the weight-gradient (TN) GEMMs; src fp32 or bf16
+hipError_t launch_transpose_to_bf16(hipStream_t s, const void* src, int src_is_bf16, size_t ld_src, uint16_t* dst, size_t ld_dst, int rows, int cols);
 hipError_t launch_cvt_bf16(hipStream_t s, const float* src, uint16_t* dst, size_t n);               // n % 8 == 0
 hipError_t launch_cvt_bf16_t(hipStream_t s, const float* src, int ld_src, uint16_t* dst, int ld_dst, int K, int N);  // dst[n][k] = src[k][n]
 hipError_t launch_cvt_f32(hipStream_t s, const uint16_t* src, float* dst, size_t n);                 // exact widening, n % 8 == 0
@@ -329,6 +337,7 @@ struct LstmBwdArgs {
 
 struct SpatialBwdArgs {
     const float* PL; const float* L; const float* LW;     // [M,T,K,D]
+    int bf16;                                             // the three region tensors are stored as bf16 (bf16 handles)
     const float* sproj; int ldsp;
     // temporal part (was a launch of its own): dctx = readout term + K-slice partials of dpre.Wc^T, selector backward,
     // d alpha of the three temporal attentions and their softmax backward
@@ -357,6 +366,7 @@ struct SpatialBwdArgs {
 
 struct CtxGradArgs {
     const float* PL; const float* LW; const float* PG; const float* PM;
+    int bf16;                    // PL and LW are stored as bf16 (bf16 handles)
     const float* sproj;          // [S,M,4D]
     const float* dcsum;          // [S,M,D]
     const float* dplt;           // [S,M,T,D]

@@ -117,7 +117,8 @@ static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const fl
     g.bias = w.bg; g.C = c.PG; g.ldc = D;
     HIPCHK(h, gemm_bf(h, g));
     static const char* nofuse = getenv("STATTN_BF16_NOFUSE");                 // A/B switch for tools
-    if (D % 256 == 0 && !nofuse) {
+    const bool fuse = D % 256 == 0 && !nofuse;
+    if (fuse) {
         g = bf_args(Lb, D, bw.Wcl, (int)nl, 2 * D, D);                        // pctxl_ | LW = L . [Wcl | Wclt]  (+ bl on the first half)
         g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
         g.n_split = D; g.Cb2 = reinterpret_cast<uint16_t*>(c.LW);
@@ -126,13 +127,15 @@ static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const fl
         g = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                            // pctxl_
         g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
         HIPCHK(h, gemm_bf(h, g));
-        g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                           // LW = L . Wclt
-        g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
-        HIPCHK(h, gemm_bf(h, g));
     }
     g = bf_args(mo, D, bw.Wcm, (int)nf, D, D);                                // pctxm_
     g.bias = w.bm; g.C = c.PM; g.ldc = D;
     HIPCHK(h, gemm_bf(h, g));
+    if (!fuse) {
+        g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                           // LW = L . Wclt
+        g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
+        HIPCHK(h, gemm_bf(h, g));
+    }
     return STATTN_OK;
 }
 

@@ -183,9 +183,10 @@ def test_bf16_c4_bench_shape_rider_and_row_panel_path(B, t, tmp_path):
         assert np.abs(out[name] - nr[name]).max() < 2e-6, name
     # (fp32-rounding-level differences in h flip bf16 roundings of the readout GEMM's operands: 2^-9 relative per flip)
     assert np.abs(out['logit'] - nr['logit']).max() < 2e-3
+    # (round 5: the backward GEMMs of a bf16 handle round their operands to bf16 as well, so the same flips reach the gradients)
     for k in W.GRADS:
         scale = np.abs(got[k]).max()
-        assert np.abs(got[k] - nr['g_' + k]).max() <= 1e-4 * scale + 1e-7, k
+        assert np.abs(got[k] - nr['g_' + k]).max() <= 2e-3 * scale + 1e-7, k
 
 
 def test_bf16_sampler_and_beam_search_agree_with_fp32_captions():

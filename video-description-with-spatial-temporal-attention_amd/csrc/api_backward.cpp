@@ -1,5 +1,7 @@
 // C ABI of libstattn.so, part 4: hand-written BPTT of the training loss, loss value, clip + Adadelta
 // (model_attention.py:1129-1147, 1193-1203; common.py:178-195).
+#include <cstdio>
+#include <vector>
 #include "steps.h"
 
 extern "C" {
@@ -67,6 +69,60 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     CHK(getbuf_t(h, "b_dph0", (size_t)m * D, &dph0)); CHK(getbuf_t(h, "b_dpc0", (size_t)m * D, &dpc0));
     CHK(getbuf_t(h, "b_lossreg", 4, &lossreg));
 
+    // bf16 handle (mixed precision, BASELINE configs[3]): every LDS-tiled GEMM of the pass runs on the bf16 MFMA kernels
+    // (csrc/gemm_bf16*.hip: C = A[M][K] . B[N][K]^T, fp32 accumulation and fp32 results).  Operands are rounded to bf16 on the
+    // way in; an operand that is not k-contiguous (both operands of a weight gradient X^T . dY) goes through the transposing
+    // conversion.  Conversions are remembered for the pass (hs^T feeds five products, dpre^T three, L^T two) and dropped
+    // when a GEMM writes their source.
+    const bool bf = h->opt.precision == 1;
+    struct BfOp { const void* src; bool tr; uint16_t* buf; };
+    std::vector<BfOp> bfops;
+    const void* const L_as_stored = L;               // bf16 handle: the only operand that already is bf16
+    auto bf_operand = [&](const float* X, int ld, int rows, int cols, bool tr, uint16_t** out) -> int {
+        for (const BfOp& o : bfops) if (o.src == X && o.tr == tr) { *out = o.buf; return STATTN_OK; }
+        char name[32];
+        snprintf(name, sizeof name, "bfop_%d", (int)bfops.size());
+        uint16_t* buf;
+        const int rows8 = (rows + 7) / 8 * 8;         // transposed: the k extent is padded to whole 16-byte chunks with zeros
+        CHK(getbuf_t(h, name, (size_t)rows8 * cols, &buf));
+        const bool src_bf = (X == L_as_stored);
+        if (tr) HIPCHK(h, launch_transpose_to_bf16(s, X, src_bf ? 1 : 0, (size_t)ld, buf, (size_t)rows8, rows, cols));     // [cols][rows8]
+        else if (src_bf) { *out = reinterpret_cast<uint16_t*>(const_cast<float*>(X)); return STATTN_OK; }
+        else HIPCHK(h, launch_cvt_bf16_2d(s, X, (size_t)ld, buf, (size_t)cols, (size_t)rows, cols));
+        bfops.push_back(BfOp{X, tr, buf});
+        *out = buf;
+        return STATTN_OK;
+    };
+    float* bfws = nullptr;
+    size_t bfws_floats = 0;
+    auto gemm_bf_one = [&](const GemmArgs& g, bool tA, bool tB) -> int {
+        if (g.A2 || g.alpha != 1.f || g.bias || g.rowadd || g.mul || g.act || g.Cact)
+            return fail(h, STATTN_EINVAL, "backward (bf16 handle): unexpected GEMM form");
+        uint16_t *Ab, *Bb;
+        // A: [M][K] (k-contiguous) or, tA, given as [K][M];  B: [K][N] or, tB, given as [N][K] (k-contiguous)
+        if (tA) CHK(bf_operand(g.A, g.lda, g.K, g.M, true, &Ab)); else CHK(bf_operand(g.A, g.lda, g.M, g.K, false, &Ab));
+        if (tB) CHK(bf_operand(g.B, g.ldb, g.N, g.K, false, &Bb)); else CHK(bf_operand(g.B, g.ldb, g.K, g.N, true, &Bb));
+        const int K8 = (g.K + 7) / 8 * 8;
+        if (K8 != g.K && (!tA || tB)) return fail(h, STATTN_EINVAL, "backward (bf16 handle): K %% 8 != 0 with a k-contiguous operand");
+        GemmBfArgs q = bf_args(Ab, K8, Bb, g.M, g.N, K8);
+        if (!tA && g.A == L_as_stored) q.lda = g.lda;
+        q.C = g.C; q.ldc = g.ldc;
+        if (g.accumulate) { q.add = g.C; q.ldadd = g.ldc; }
+        else if (g.add) { q.add = g.add; q.ldadd = g.ldadd; }
+        // small M x N with a long K (weight gradients over all region rows, the vocabulary-long input gradient): deterministic split-K
+        const long tiles = (long)((g.M + 255) / 256) * (g.N / 256);
+        if (gemm_bf16_8ph_supported(q) && tiles < 128 && K8 >= 4096) {
+            q.tile = 88; q.kslices = gemm_bf16_8ph_slices(q);
+            if (q.kslices > 1) {
+                const size_t need = (size_t)q.kslices * g.M * g.N;
+                if (need > bfws_floats) { CHK(getbuf_t(h, "b_bfws", need, &bfws)); bfws_floats = need; }
+                q.ws = bfws; q.ws_floats = bfws_floats;
+            }
+        }
+        for (size_t i = 0; i < bfops.size();) { if (bfops[i].src == (const void*)g.C) { bfops[i] = bfops.back(); bfops.pop_back(); } else ++i; }
+        HIPCHK(h, launch_gemm_bf16(s, q));
+        return STATTN_OK;
+    };
     auto gemm = [&](bool tA, bool tB, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M, int N, int Kd,
                     int accumulate, const float* add = nullptr, int ldadd = 0) -> hipError_t {
         GemmArgs g;
@@ -76,11 +132,16 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         if (!add) { g.ws = ws; g.ws_floats = WS; }
         const int seq = h->bwd_seq++;
         Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
+        if (bf) return gemm_bf_one(g, tA, tB) == STATTN_OK ? hipSuccess : hipErrorUnknown;
         return launch_gemm(s, g, tA, tB);
     };
     auto gemm_grp = [&](const GemmArgs* gs, int n, bool tA, bool tB) -> hipError_t {
         const int seq = h->bwd_seq++;
         Prof one(h, KC_BWD0 + (seq < KC_BWD_SEQ ? seq : 0), seq < KC_BWD_SEQ);
+        if (bf) {
+            for (int i = 0; i < n; ++i) if (gemm_bf_one(gs[i], tA, tB) != STATTN_OK) return hipErrorUnknown;
+            return hipSuccess;
+        }
         return launch_gemm_group(s, gs, n, tA, tB);
     };
     h->bwd_seq = 0;
@@ -109,14 +170,11 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout
     // only as a = tanh(z) * d2.  The backward pass is the fp32 one, evaluated at those stored activations: they are widened
     // (exactly) into fp32 buffers, tanh(z) is recovered from a and the dropout multiplier, everything else was fp32 anyway.
-    const bool bf = h->opt.precision == 1;
-    // the attention backward kernels read the region tensors as they are stored (bf16 on a bf16 handle: half their stream)
+    // the attention backward kernels, the tanh backward and the GEMM operand conversions read the region tensors as they are
+    // stored (bf16 on a bf16 handle: half their stream, no widened copies); tanh(z) of the readout is recovered from a = tanh(z) d2
     const float *Ls = L, *PLs = PL, *LWs = LW;
     if (bf) {
-        float* L32;
-        CHK(getbuf_t(h, "b_L32", MTK * D, &L32));
-        HIPCHK(h, launch_cvt_f32(s, reinterpret_cast<const uint16_t*>(L), L32, MTK * D));      // operand of the fp32 weight-gradient GEMMs
-        L = L32; PL = nullptr; LW = nullptr;
+        PL = nullptr; LW = nullptr;
         HIPCHK(h, launch_unmul(s, a1, d2, tz, R * E));
     }
 
@@ -371,7 +429,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         g3[2].A = dPM; g3[2].lda = D; g3[2].B = w.Wcm; g3[2].ldb = D; g3[2].C = dMo; g3[2].ldc = D;
         g3[2].M = (int)MT; g3[2].N = D; g3[2].K = D; g3[2].accumulate = 1;
         HIPCHK(h, gemm_grp(g3, 3, false, true));
-        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
+        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D, bf ? 1 : 0));
         HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
     }
     {   // Weight gradients over all (t*m) rows / all frames, K = 1664..1920 (and the two initial-state ones, K = m), as
@@ -409,7 +467,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (!ntgroup) {
         HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
         HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
-        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D));
+        HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D, bf ? 1 : 0));
     }
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
     CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);

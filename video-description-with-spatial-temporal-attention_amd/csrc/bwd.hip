@@ -677,10 +677,11 @@ __global__ __launch_bounds__(1024) void sum_all_kernel(const float* __restrict__
     }
 }
 // y = dy * (1 - t^2) [* mulmat]  elementwise (tanh backward), in place allowed
+template <bool TBF>        // TBF: t is stored as bf16 (the region tensor L of a bf16 handle)
 __global__ void tanh_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ t, const float* __restrict__ mul,
                                 float* __restrict__ out, size_t n4) {
     for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (size_t)gridDim.x * blockDim.x) {
-        float4 v = mul4(ld4(dy + 4 * i), one_minus_sq(ld4(t + 4 * i)));
+        float4 v = mul4(ld4(dy + 4 * i), one_minus_sq(lds4<TBF>(t, 4 * i)));
         if (mul) v = mul4(v, ld4(mul + 4 * i));
         st4(out + 4 * i, v);
     }
@@ -899,9 +900,10 @@ hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, f
     hipLaunchKernelGGL(sum_all_kernel, dim3(1), dim3(1024), 0, s, x, n, dst, scale, accumulate);
     return hipGetLastError();
 }
-hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n) {
+hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n, int t_bf16) {
     if (!n) return hipSuccess;
-    hipLaunchKernelGGL(tanh_bwd_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, dy, t, mul, out, n / 4);
+    if (t_bf16) hipLaunchKernelGGL(tanh_bwd_kernel<true>, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, dy, t, mul, out, n / 4);
+    else hipLaunchKernelGGL(tanh_bwd_kernel<false>, dim3(grid_for(n / 4, 256)), dim3(256), 0, s, dy, t, mul, out, n / 4);
     return hipGetLastError();
 }
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate) {

@@ -478,7 +478,8 @@ __global__ __launch_bounds__(256) void transpose_to_bf16_kernel(const void* __re
 }
 hipError_t launch_transpose_to_bf16(hipStream_t s, const void* src, int src_is_bf16, size_t ld_src, uint16_t* dst, size_t ld_dst, int rows, int cols) {
     if (rows <= 0 || cols <= 0) return hipSuccess;
-    if (rows % 8 || cols % 8 || ld_dst % 8 || ld_src % (src_is_bf16 ? 8 : 4)) return hipErrorInvalidValue;
+    // rows past `rows` of the last group of eight are written as zeros: ld_dst must have room for them
+    if (cols % 8 || ld_dst % 8 || ld_dst < (size_t)((rows + 7) / 8 * 8) || ld_src % (src_is_bf16 ? 8 : 4)) return hipErrorInvalidValue;
     const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
     if (src_is_bf16) hipLaunchKernelGGL(transpose_to_bf16_kernel<true>, grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);
     else hipLaunchKernelGGL(transpose_to_bf16_kernel<false>, grid, dim3(256), 0, s, src, ld_src, dst, ld_dst, rows, cols);

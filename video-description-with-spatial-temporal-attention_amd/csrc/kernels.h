@@ -404,7 +404,7 @@ constexpr size_t COLSUM_BATCH_PART_FLOATS = (size_t)24 * 131072;
 struct MultiSumArgs { const float* src[12]; size_t n[12]; float* dst[12]; float scale[12]; int count; };
 hipError_t launch_multi_sum(hipStream_t s, const MultiSumArgs& a, float* part);   // dst[i][0] = scale[i] * sum(src[i][0:n[i]]); part: >= 384 floats
 hipError_t launch_sum_all(hipStream_t s, const float* x, size_t n, float* dst, float scale, int accumulate);
-hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n);
+hipError_t launch_tanh_bwd(hipStream_t s, const float* dy, const float* t, const float* mul, float* out, size_t n, int t_bf16 = 0);
 // t[i] = mul[i] != 0 ? a[i] / mul[i] : 0: recovers tanh(z) from a = tanh(z) * mul where only a was kept (bf16 readout)
 hipError_t launch_unmul(hipStream_t s, const float* a, const float* mul, float* t, size_t n);
 hipError_t launch_add(hipStream_t s, const float* a, const float* b, float* out, size_t n, int accumulate);

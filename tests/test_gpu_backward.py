@@ -435,6 +435,46 @@ def test_full_size_c2_every_gradient_and_forward_output_against_the_float64_orac
     np.testing.assert_allclose(dec.get_loss(0.0), ref['loss'], rtol=2e-4)
 
 
+def test_full_size_c4_fp32_forward_and_every_gradient_against_the_float64_oracle():
+    """BASELINE.json configs[3] at the size bench.py --config c4 runs, in fp32 (no reduced dimension): batch 64,
+    T = 40, K = 16 regions, feat 2048, hidden 1024, E = 512, vocabulary 12 000; captions of up to 12 words (the caption length is
+    not part of the configuration; the float64 autograd oracle is the cost).  ALL 64 rows: attention weights and logits within
+    1e-4, cost 1e-4 relative, each of the 41 gradients within 1e-4 of its own scale, the loss within 2e-4 -- on the production
+    kernels of that shape (K = 16 attention kernels with the riders, 64-row panel GEMMs, grouped / split-K weight gradients)."""
+    import stattn
+    from oracle import stattn_oracle as O
+    from oracle import stattn_oracle_grad as OG
+    dims = dict(dim=1024, dim_word=512, n_words=12000, ctxg_dim=1024, ctxl_dim=2048, ctxm_dim=2048, ctxglm_dim=1024)
+    opt = O.default_options(**dims)
+    rng = np.random.RandomState(31)
+    P = OrderedDict()
+    for k, shp in O.param_shapes(opt).items():
+        if len(shp) == 2:
+            P[k] = (rng.standard_normal(shp) / np.sqrt(shp[0])).astype(np.float32) if shp[0] == shp[1] or k == 'decoder_U' \
+                else (0.02 * rng.standard_normal(shp)).astype(np.float32)
+        else:
+            P[k] = (0.05 * rng.standard_normal(shp)).astype(np.float32)
+    t, m, V = 12, 64, 12000
+    batch = O.synthetic_batch(opt, B=m, T=40, K=16, t=t, seed=78)
+    ref = OG.loss_and_grads(P, opt, batch, decay_c=0.0, alpha_c=0.70602)
+    dec = stattn.Decoder(opt, lt_mode=1)
+    dec.set_params(P)
+    dec.set_batch(**batch)
+    dec.forward_train()
+    out = dec.get_forward(logits=True)
+    for a in ('alphal', 'alphag', 'alpham', 'alphalt'):
+        assert np.abs(out[a] - ref[a]).max() < 1e-4, a
+    assert np.abs(out['logit'].reshape(t, m, V) - ref['logit']).max() < 1e-4
+    np.testing.assert_allclose(out['cost'], ref['cost'], rtol=1e-4)
+    dec.backward(alpha_c=0.70602)
+    pc = dec.path_counts()
+    assert pc['fwd_rider'] == t and pc['fwd_panel'] == t and pc['bwd_rider'] == t and pc['bwd_panel'] == t, pc
+    got = dec.get_grads()
+    assert list(got) == list(ref['grads']) and len(got) == 41
+    _check_grads(got, ref['grads'])
+    np.testing.assert_allclose(dec.get_loss(0.0), ref['loss'], rtol=2e-4)
+
+
 @pytest.mark.parametrize("seed", [5])
 def test_production_sized_random_configurations(seed):
     """tools/fuzz_parity.py `large`: D in {512, 768, 1024}, vocabulary 3 000 .. 12 000, 17 .. 64 rows, both lt_modes,

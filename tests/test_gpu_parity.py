@@ -334,9 +334,9 @@ def test_f_log_probs_and_strict_dtypes(stattn_mod, O):
 
 
 def test_c1_msvd_tiny_config_logits_and_alphas(stattn_mod, O):
-    """BASELINE.json configs[0] shapes: batch 4, T=26, K=8, feat 4096, hidden 512 (V reduced to 2000 to
-    keep the float64 oracle quick); init_params-scale weights."""
-    dims = dict(dim=512, dim_word=512, n_words=2000, ctxg_dim=512, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=512)
+    """BASELINE.json configs[0] at its stated size: batch 4, T=26, K=8, feat 4096, hidden 512, vocabulary 12 000
+    (no reduced dimension); init_params-scale weights."""
+    dims = dict(dim=512, dim_word=512, n_words=12000, ctxg_dim=512, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=512)
     for lt in (0, 1):
         opt, P, P64, dec = _decoder(stattn_mod, O, dims, lt, seed=17)
         batch = O.synthetic_batch(opt, B=4, T=26, K=8, t=5, seed=50)
@@ -506,10 +506,9 @@ def test_batched_beam_search_matches_gen_sample(stattn_mod, O, k, nvid):
 def test_c5_full_size_device_beam_search(stattn_mod, O, monkeypatch):
     """BASELINE.json configs[4] as written: 32 videos x beam 5 = 160 rows, T=80, K=32, hidden 1024, through the
     device-side beam search with its hipGraph-captured per-word sequence (stattn_beam_search).  Videos 0 and 1 are
-    checked against the oracle's gen_sample, the others against the product's host-driven gen_sample loop.  feat is
-    reduced to 512 (it only sizes the once-per-video F->D GEMM, covered at 4096 elsewhere) so that 32 videos of raw
-    features stay small; the vocabulary is 2000 so the oracle finishes in seconds."""
-    dims = dict(dim=1024, dim_word=512, n_words=2000, ctxg_dim=1024, ctxl_dim=512, ctxm_dim=512, ctxglm_dim=1024)
+    checked against the oracle's gen_sample, the others against the product's host-driven gen_sample loop.  Every
+    dimension is the bench's: feat 4096 (1.3 GB of raw region features for the 32 videos), vocabulary 12 000."""
+    dims = dict(dim=1024, dim_word=512, n_words=12000, ctxg_dim=1024, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=1024)
     opt = O.default_options(**dims)
     P = O.random_params(opt, seed=23, dtype=np.float32)
     P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 1.5        # some hypotheses end early

@@ -104,6 +104,7 @@ def run_beam(n, seed, only=None, verbose=False):
     may only differ when the oracle's two best scores are closer than that)."""
     rng = np.random.RandomState(seed)
     bad = 0
+    relaxed = dict(order_only=0, device_equals_oracle=0)
     for case in range(n):
         D = int(rng.choice([64, 128, 192]))
         dims = dict(dim=D, ctxg_dim=D, ctxglm_dim=D, dim_word=int(rng.choice([64, 128])), n_words=int(rng.randint(12, 400)),
@@ -155,10 +156,18 @@ def run_beam(n, seed, only=None, verbose=False):
                 # ... or when both loops hold the SAME hypotheses with the same scores and merely list two of them whose scores are within
                 # 2e-4 of each other in the other order (seed 424242 case 119: 17.698643 / 17.698645 after four words, device order swapped
                 # against host and oracle, with and without the riding update)
-                same_set = (sorted(map(tuple, bs)) == sorted(map(tuple, s_)) and
-                            np.allclose([dict(zip(map(tuple, bs), bsc))[h_] for h_ in map(tuple, s_)], np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4) and
-                            all(tuple(x) == tuple(y) or abs(float(cx) - float(cy)) < 2e-4 for x, y, cx, cy in zip(bs, s_, bsc, sc)))
-                if not same_set and not (bs == sr and np.allclose(bsc, scr, rtol=1e-4, atol=1e-4)):
+                # (the order-only rule checks the PARTNER -- a hypothesis that sits elsewhere in the other list must sit there at a
+                # position whose score is within 2e-4 of its own; and the run reports how many cases needed either relaxation)
+                dev_sc = dict(zip(map(tuple, bs), map(float, bsc)))
+                host_pos = {tuple(h_): i_ for i_, h_ in enumerate(s_)}
+                same_set = (sorted(map(tuple, bs)) == sorted(map(tuple, s_)) and len(host_pos) == len(s_) and
+                            np.allclose([dev_sc[h_] for h_ in map(tuple, s_)], np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4) and
+                            all(tuple(x) == tuple(y) or abs(float(cx) - float(sc[host_pos[tuple(x)]])) < 2e-4 and abs(float(cx) - float(bsc[host_pos[tuple(x)]])) < 2e-4
+                                for x, y, cx in zip(bs, s_, bsc)))
+                oracle_eq = bs == sr and np.allclose(bsc, scr, rtol=1e-4, atol=1e-4)
+                if same_set or oracle_eq:
+                    relaxed['order_only' if same_set else 'device_equals_oracle'] += 1
+                else:
                     ok, why = False, "device loop != host loop (video %d)" % v
             elif len(bs) != len(sr) or not np.allclose(sorted(bsc), sorted(scr), rtol=1e-4, atol=1e-4):
                 # a near-tie at the beam boundary may swap which hypothesis survives; accept only if the oracle itself is that close
@@ -171,7 +180,8 @@ def run_beam(n, seed, only=None, verbose=False):
         print("%3d %-5s lt%d D=%3d E=%3d V=%3d sel=%d p2o=%d c2o=%d videos=%d T=%2d K=%2d beam=%d maxlen=%d  %s"
               % (case, precision, opt['lt_mode'], D, dims['dim_word'], dims['n_words'], dims['selector'], dims['prev2out'], dims['ctx2out'],
                  nvid, T, K, k, maxlen, ("ok" if ok else "FAIL: " + why) + (" (update rode)" if rode else "")), flush=True)
-    print("beam cases %d  failures %d" % (n, bad))
+    print("beam cases %d  failures %d  accepted through a near-tie rule: %d order-only, %d device == float64 oracle != host loop"
+          % (n, bad, relaxed['order_only'], relaxed['device_equals_oracle']))
     return bad
 
 

@@ -705,7 +705,8 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     }
     if (rc_loop != STATTN_OK) return rc_loop;
     h->path_upd_rider = ride ? steps_run : 0;      // (replayed graphs included)
-    h->path_upd_rowwg = rw_cost ? steps_run : 0;
+    // (a riding update falls back to one workgroup per video when its attention launch is the shared-slab kernel: count what ran)
+    h->path_upd_rowwg = rw_cost && (!ride || h->upd_rowwg_last) ? steps_run : 0;
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
         const int fb = steps_run & 1;     // buffers written by the last executed step

@@ -184,14 +184,15 @@ int stattn_forward_train(stattn_handle* h) {
         HIPCHK(h, launch_embed(s, dx, w.Wemb, emb, (int)R, E, V, m));      // emb shifted one step (:613-617)
     }
     if (h->opt.precision == 1) {
-        CHK(project_context(h, m, T, K, c.G, rawl, rawm, c));
-        Prof pp(h, KC_PROLOGUE);
-        CHK(bf16_weights(h, &bw, true));
-        CHK(getbuf_t(h, "bx_emb", R * E, &bemb));
-        HIPCHK(h, launch_cvt_bf16(s, emb, bemb, R * E));
-        GemmBfArgs g = bf_args(bemb, E, bw.W, (int)R, 4 * D, E);       // x_ = emb.W + b (:334-335)
+        {
+            Prof pp(h, KC_PROLOGUE);
+            CHK(bf16_weights(h, &bw, true));
+            CHK(getbuf_t(h, "bx_emb", R * E, &bemb));
+            HIPCHK(h, launch_cvt_bf16(s, emb, bemb, R * E));
+        }
+        GemmBfArgs g = bf_args(bemb, E, bw.W, (int)R, 4 * D, E);       // x_ = emb.W + b (:334-335): rides with the projections
         g.bias = w.b; g.C = xproj; g.ldc = 4 * D;
-        HIPCHK(h, gemm_bf(h, g));
+        CHK(project_context(h, m, T, K, c.G, rawl, rawm, c, nullptr, &g));
     } else {
         GemmArgs g;
         gemm_defaults(g); g.split = h->opt.precision != 0;                                               // x_ = emb.W + b (:334-335): rides with the projections
@@ -245,8 +246,23 @@ int stattn_forward_train(stattn_handle* h) {
         CHK(getbuf_t(h, "bx_hd", R * D, &bhd));
         CHK(getbuf_t(h, "bx_ctx", R * D, &bctx));
         CHK(getbuf_t(h, "bx_a1", R * E, &ba1));
+        GemmBfArgs g;
+        static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools
+        if (h->opt.ctx2out && bw.Wl12 && !nopair) {
+            // a = tanh((h*d1).Wl1 + ctx.Wl2 + bl1 + bl2 [+ emb]) * d2 as ONE K-concatenated problem: [hd | ctx] rounded into one
+            // [R][2 D] operand, [Wl1 ; Wl2] in rows of 2 D (z1 is never formed)
+            uint16_t* bcat;
+            CHK(getbuf_t(h, "bx_hdctx", R * 2 * D, &bcat));
+            HIPCHK(h, launch_cvt_bf16_2d(s, hd, (size_t)D, bcat, (size_t)2 * D, R, D));
+            HIPCHK(h, launch_cvt_bf16_2d(s, ctx, (size_t)D, bcat + D, (size_t)2 * D, R, D));
+            g = bf_args(bcat, 2 * D, bw.Wl12, (int)R, E, 2 * D);
+            g.bias = w.bl1; g.bias_b = w.bl2;
+            if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
+            g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E; g.C = a1; g.ldc = E;   // (a1 in fp32 too: the backward pass reads it)
+            HIPCHK(h, gemm_bf(h, g));
+        } else {
         HIPCHK(h, launch_cvt_bf16(s, hd, bhd, R * D));
-        GemmBfArgs g = bf_args(bhd, D, bw.Wl1, (int)R, E, D);
+        g = bf_args(bhd, D, bw.Wl1, (int)R, E, D);
         g.bias = w.bl1;
         if (h->opt.prev2out) { g.add = emb; g.ldadd = E; }
         if (h->opt.ctx2out) { g.C = z1; g.ldc = E; }
@@ -258,6 +274,7 @@ int stattn_forward_train(stattn_handle* h) {
             g.bias = w.bl2; g.add = z1; g.ldadd = E; g.act = 1; g.mul = d2; g.ldmul = E; g.Cb = ba1; g.ldcb = E;
             g.C = a1; g.ldc = E;                                            // (a1 in fp32 too: the backward pass reads it)
             HIPCHK(h, gemm_bf(h, g));
+        }
         }
         g = bf_args(ba1, E, bw.Wo, (int)R, Vp, E);
         g.bias = w.bo; g.C = lg; g.ldc = Vp;

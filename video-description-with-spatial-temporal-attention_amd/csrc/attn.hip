@@ -824,13 +824,18 @@ bool spatial_update_supported(const SpatialArgs& a) {
     return a.M > 0 && a.K >= 1 && a.K <= KMAX && a.D % 4 == 0 && !a.bf16 && !a.rider.nblocks && (spatial_small_path(a) || spatial_shared_path(a));
 }
 
+// does a riding update (launch_spatial with `upd`) run as k workgroups per video?  (the caller's path counter asks what ran)
+bool spatial_update_row_workgroups(const SpatialArgs& a, const BeamArgs& u) {
+    return u.rw_cost && !spatial_shared_path(a) && u.k >= 2 && u.rw_idx && u.rw_ticket;
+}
+
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* upd) {
     if (upd) {
         if (!spatial_update_supported(a) || !upd->stats || !upd->ticket || upd->nvid < 1 || upd->ntile < 1 || upd->k > PN_STATS_KB ||
             (upd->stochastic && (upd->k != 1 || upd->tile_cols < 1)) || (upd->proj_next && (!upd->proj_step || upd->nproj % 4)))
             return hipErrorInvalidValue;
         BeamArgs u1;
-        if (upd->rw_cost && (spatial_shared_path(a) || upd->k < 2 || !upd->rw_idx || !upd->rw_ticket)) {     // row workgroups: the 1024-thread small launch only
+        if (upd->rw_cost && !spatial_update_row_workgroups(a, *upd)) {     // row workgroups: the 1024-thread small launch only
             u1 = *upd; u1.rw_cost = nullptr; upd = &u1;
         }
         if (spatial_shared_path(a)) {

@@ -127,12 +127,15 @@ __device__ __forceinline__ void beam_update_body(const BeamArgs& a, int nsplit, 
         __syncthreads();
         if (tid == 0) {
             if (nwg == 1) {                            // one video, one workgroup: the last by construction
-                *a.step = step + 1;
+                __hip_atomic_store(a.step, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             } else {
                 // (no fence: the ticket orders READS of *a.step before its one write -- every workgroup has consumed the value it loaded
                 // long before its add is issued -- and the write only has to be seen by the next launch.  A __threadfence here was a
                 // whole-L2 write-back per update workgroup, on the last arriver's critical path once a video has k of them.)
-                if (__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) { *a.ticket = 0; *a.step = step + 1; }
+                if (__hip_atomic_fetch_add(a.ticket, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == nwg - 1) {
+                    *a.ticket = 0;
+                    __hip_atomic_store(a.step, step + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // (kernels.h BeamArgs::step: no reader inside this launch)
+                }
             }
         }
     };

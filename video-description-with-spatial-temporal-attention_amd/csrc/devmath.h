@@ -3,6 +3,14 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+// gfx950 only.  Several hand-offs between workgroups of one launch (beam_inl.h row workgroups, the word counter) carry their data
+// in agent-scope (sc1, written-through) stores and loads around a relaxed ticket, with the order fixed by s_waitcnt + s_barrier
+// instead of release / acquire fences: measured correct and 2-3 us cheaper per hand-off on this chip, NOT a statement
+// about the HIP memory model.  Building for another target must fail here rather than run them.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(__gfx950__)
+#error "libstattn is written for gfx950 (MI355X / CDNA4) only"
+#endif
+
 namespace stattn {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));

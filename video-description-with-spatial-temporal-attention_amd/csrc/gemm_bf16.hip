@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256, 2) void gemm_bf16_kernel(const GemmBfArgs g) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = n0 + wn * 32 * TN + j * 32 + l31;
-            const float bias = g.bias ? g.bias[col] : 0.f;
+            const float bias = (g.bias ? g.bias[col] : 0.f) + (g.bias_b ? g.bias_b[col] : 0.f);
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int row = m0 + wm * 32 * TM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * kh;

@@ -28,6 +28,7 @@
 #include "gemm_bf16_epi.h"
 
 #include <cstdlib>
+#include <type_traits>
 
 namespace stattn {
 
@@ -69,15 +70,35 @@ __device__ __forceinline__ i32x4 make_rsrc(const void* p) {
 
 // VAR bits (tools/gemm_8ph_probe.py; the product runs VAR = 0): 1 = no s_setprio, 2 = no stagger between the wave halves,
 // 4 = no epilogue (one word per lane keeps the accumulators live), 8 = no DMA inside the loop, 16 = no fragment reads inside the loop
-template <int VAR, bool MEDGE>
-__global__ __launch_bounds__(512, 2) void gemm_bf16_8ph_kernel(const GemmBfArgs g) {
+// GROUP: up to eight independent problems in ONE launch (GemmBfGroup): block b runs on XCD b % 8, which walks its share of problem 0,
+// then of problem 1, ... -- the host lists the longest-K problems first, the hardware hands a free CU the next block, and the short
+// problems fill the last round of the long one (configs[3]: ff_local alone is 2.5 rounds of 256 tiles).
+template <int VAR, bool MEDGE, bool GROUP>
+__global__ __launch_bounds__(512, 2) void gemm_bf16_8ph_kernel(const typename std::conditional<GROUP, GemmBfGroup, GemmBfArgs>::type G) {
     __shared__ __attribute__((aligned(1024))) unsigned char smem[2 * KBUF];      // 128 KiB
     const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned char*)smem;
 
+    int lin;
+    GemmBfArgs g;                                        // (a copy: fields of a dynamically indexed kernel argument would be re-loaded at every use)
+    if constexpr (GROUP) {
+        const int bid = blockIdx.x, xcd = bid % NXCD8;
+        int j = bid / NXCD8, p = 0;
+        lin = -1;
+        for (; p < G.n; ++p) {
+            const int tiles = G.tile_start[p + 1] - G.tile_start[p], q8 = tiles / NXCD8, r8 = tiles % NXCD8;
+            const int mine = q8 + (xcd < r8 ? 1 : 0);
+            if (j < mine) { lin = xcd * q8 + (xcd < r8 ? xcd : r8) + j; break; }
+            j -= mine;
+        }
+        if (lin < 0) return;                             // padding block of this XCD
+        g = G.g[p];
+    } else {
+        g = G;
+        const int nblk = gridDim.x, bid = blockIdx.x;
+        const int xcd = bid % NXCD8, q8 = nblk / NXCD8, r8 = nblk % NXCD8;
+        lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD8 : bid;
+    }
     const int tiles_n = g.N / 256;
-    const int nblk = gridDim.x, bid = blockIdx.x;
-    const int xcd = bid % NXCD8, q8 = nblk / NXCD8, r8 = nblk % NXCD8;
-    const int lin = g.xcd_remap ? (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + bid / NXCD8 : bid;
     const int m0 = (lin / tiles_n) * 256;
     const int n0 = (lin % tiles_n) * 256;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -254,6 +275,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_bf_kernel(const GemmBfArgs 
         }
         const bf16_epi::Out o = bf16_epi::select_out(g, col);
         if (o.bias) { const float4 b = ld4(o.bias + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
+        if (g.bias_b) { const float4 b = ld4(g.bias_b + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (g.add) { const float4 b = ld4(g.add + (size_t)row * g.ldadd + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (g.rowadd) { const float4 b = ld4(g.rowadd + (size_t)(row / g.rowgroup) * g.ldrow + col); v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w; }
         if (g.act == 1) { v.x = fast_tanh(v.x); v.y = fast_tanh(v.y); v.z = fast_tanh(v.z); v.w = fast_tanh(v.w); }
@@ -267,8 +289,8 @@ template <int VAR>
 hipError_t launch_var(hipStream_t s, const GemmBfArgs& g) {
     const int tiles = ((g.M + 255) / 256) * (g.N / 256);
     const dim3 grid(tiles, g.kslices > 1 ? g.kslices : 1);
-    if (g.M % 256) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, true>), grid, dim3(512), 0, s, g);
-    else hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, false>), grid, dim3(512), 0, s, g);
+    if (g.M % 256) hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, true, false>), grid, dim3(512), 0, s, g);
+    else hipLaunchKernelGGL((gemm_bf16_8ph_kernel<VAR, false, false>), grid, dim3(512), 0, s, g);
     if (g.kslices > 1) {
         const size_t total = (size_t)g.M * (g.N / 4);
         hipLaunchKernelGGL(splitk_reduce_bf_kernel, dim3((unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256)), dim3(256), 0, s, g);
@@ -310,6 +332,30 @@ hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& gin) {
     if (v == 20) return launch_var<20>(s, g);
     if (v == 28) return launch_var<28>(s, g);
     return launch_var<0>(s, g);
+}
+
+// Up to GEMM_BF_GROUP_MAX independent problems (each gemm_bf16_8ph_supported, no split-K) in one launch; list the longest K first.
+hipError_t launch_gemm_bf16_8ph_group(hipStream_t s, const GemmBfArgs* gs, int n) {
+    if (n < 1 || n > GEMM_BF_GROUP_MAX) return hipErrorInvalidValue;
+    if (n == 1) return launch_gemm_bf16_8ph(s, gs[0]);
+    GemmBfGroup G{};
+    G.n = n;
+    int maxper = 0;
+    for (int p = 0; p < n; ++p) {
+        if (!gemm_bf16_8ph_supported(gs[p]) || gs[p].kslices > 1 || gs[p].M <= 0) return hipErrorInvalidValue;
+        G.g[p] = gs[p];
+        if (G.g[p].rowgroup < 1) G.g[p].rowgroup = 1;
+        const int tiles = ((gs[p].M + 255) / 256) * (gs[p].N / 256);
+        G.tile_start[p + 1] = G.tile_start[p] + tiles;
+    }
+    // every XCD gets ceil(tiles_p / 8) or floor blocks of problem p: the grid is 8 x the largest per-XCD total
+    for (int x = 0; x < NXCD8; ++x) {
+        int per = 0;
+        for (int p = 0; p < n; ++p) { const int t = G.tile_start[p + 1] - G.tile_start[p]; per += t / NXCD8 + (x < t % NXCD8 ? 1 : 0); }
+        maxper = per > maxper ? per : maxper;
+    }
+    hipLaunchKernelGGL((gemm_bf16_8ph_kernel<0, true, true>), dim3(maxper * NXCD8), dim3(512), 0, s, G);
+    return hipGetLastError();
 }
 
 }  // namespace stattn

@@ -56,6 +56,10 @@ __device__ __forceinline__ void store_tile(const GemmBfArgs& g, const f32x16 (&a
     const int col = col0 + 8 * cg;
     float4 b0 = make_float4(0.f, 0.f, 0.f, 0.f), b1 = b0;
     if (o.bias) { b0 = ld4(o.bias + col); b1 = ld4(o.bias + col + 4); }
+    if (g.bias_b) {
+        const float4 c0 = ld4(g.bias_b + col), c1 = ld4(g.bias_b + col + 4);
+        b0.x += c0.x; b0.y += c0.y; b0.z += c0.z; b0.w += c0.w; b1.x += c1.x; b1.y += c1.y; b1.z += c1.z; b1.w += c1.w;
+    }
     float* w0 = stage + (4 * kh) * W + (((l31 >> 2) << 2) | (l31 & 3));               // rows whose swizzle bit is 0
     float* w1 = stage + (4 * kh) * W + ((((l31 >> 2) ^ 1) << 2) | (l31 & 3));         // ... is 1: chunk ^ 1
 #pragma unroll
@@ -118,7 +122,7 @@ __host__ __device__ inline bool wide_ok(const GemmBfArgs& g) {
     auto al = [](const void* p) { return ((size_t)p & 15) == 0; };
     return (!g.C || (g.ldc % 4 == 0 && al(g.C))) && (!g.Cb || (g.ldcb % 8 == 0 && al(g.Cb))) &&
            (!g.add || (g.ldadd % 4 == 0 && al(g.add))) && (!g.rowadd || (g.ldrow % 4 == 0 && al(g.rowadd))) &&
-           (!g.mul || (g.ldmul % 4 == 0 && al(g.mul))) && (!g.bias || al(g.bias)) &&
+           (!g.mul || (g.ldmul % 4 == 0 && al(g.mul))) && (!g.bias || al(g.bias)) && (!g.bias_b || al(g.bias_b)) &&
            (g.n_split <= 0 || ((!g.C2 || al(g.C2)) && (!g.Cb2 || al(g.Cb2)) && (!g.bias2 || al(g.bias2))));
 }
 

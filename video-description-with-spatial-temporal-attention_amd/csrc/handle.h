@@ -121,6 +121,7 @@ struct stattn_handle {
     // whose attention launch carried the dhU rider, reverse steps on the row-panel kernels
     long path_fwd_rider = 0, path_fwd_panel = 0, path_bwd_rider = 0, path_bwd_panel = 0;
     long path_upd_rider = 0;        // words of the last beam / sample search whose update rode in the next word's attention launch
+    bool upd_rowwg_last = false;    // the last riding update launch ran row workgroups (set by run_step)
     long path_upd_rowwg = 0;        // ... whose update ran as k workgroups per video (row workgroups, beam_inl.h)
     bool ck_valid = false;
     // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs

@@ -71,6 +71,7 @@ struct GemmBfArgs {
     uint16_t* Cb; int ldcb;            // bf16 output or null
     int M, N, K;
     const float* bias;
+    const float* bias_b;               // a second [N] bias added to it (two layers summed into one pre-activation: the K-concatenated readout), or null
     const float* add; int ldadd;
     const float* rowadd; int ldrow; int rowgroup;
     int act;                           // 0 none, 1 tanh
@@ -88,6 +89,10 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& g);
 // the 256 x 256 eight-phase kernel (gemm_bf16_8ph.hip): N % 256 == 0, K % 64 == 0; launch_gemm_bf16 routes to it (tile 88)
 bool gemm_bf16_8ph_supported(const GemmBfArgs& g);
 hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& g);
+constexpr int GEMM_BF_GROUP_MAX = 6;
+struct GemmBfGroup { GemmBfArgs g[GEMM_BF_GROUP_MAX]; int tile_start[GEMM_BF_GROUP_MAX + 1]; int n; };
+// several independent problems (each gemm_bf16_8ph_supported, no split-K) in ONE launch, the longest K first
+hipError_t launch_gemm_bf16_8ph_group(hipStream_t s, const GemmBfArgs* gs, int n);
 int gemm_bf16_8ph_slices(const GemmBfArgs& g);     // K-slices that fill the chip for this shape (1 = none)
 // dst[r * ld_dst + c] = bf16(src[r * ld_src + c]), c < cols (cols % 8 == 0; 16-byte aligned rows): K-concatenated operands
 hipError_t launch_cvt_bf16_2d(hipStream_t s, const float* src, size_t ld_src, uint16_t* dst, size_t ld_dst, size_t rows, int cols);
@@ -273,6 +278,7 @@ struct BeamArgs;
 // neither the chosen word nor its embedding, so the update leaves the critical path of the word loop
 hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* upd = nullptr);
 bool spatial_update_supported(const SpatialArgs& a);
+bool spatial_update_row_workgroups(const SpatialArgs& a, const BeamArgs& u);   // would the riding update run as k workgroups per video?
 bool spatial_rider_supported(const SpatialArgs& a);   // would launch_spatial pick a kernel that can carry a rider?
 
 // elt[r] = dot(P[r,:], U) + c   (lt_mode 0, after the CL.Wclt GEMM with fused tanh)
@@ -454,7 +460,11 @@ hipError_t launch_beam_init(hipStream_t s, const BeamInitArgs& a);
 struct BeamArgs {
     const float* probs; int ldp;        // [nvid*k, ldp] next-word probabilities of this step
     int V, k, D, maxlen, nvid, suppress_eos;
-    int* step;                          // device counter: index of the word being decoded (so a captured graph replays unchanged)
+    // device counter: index of the word being decoded (so a captured graph replays unchanged).  INVARIANT (beam_inl.h advance_step,
+    // a relaxed ticket without fences): every workgroup of the update's launch reads *step once, at its start, and nothing inside that
+    // launch reads it after the last arriver's store (an agent-scope atomic store); every later consumer -- the statistics epilogue of
+    // the next word's logits launch -- is a separate kernel behind a launch boundary.  A rider that read *step late would race.
+    int* step;
     int* live_k; int* dead_k;           // [nvid]
     const float* hyp_score; float* hyp_score_out;   // [nvid*k] scores of the live hypotheses (in / out)
     const int* tok_in; int* tok_out;    // [nvid*k, maxlen] words of the live hypotheses (in / out)

@@ -66,6 +66,14 @@ int bf16_weights(stattn_handle* h, BfWeights* b, bool readout) {
     // columns (GemmBfArgs::n_split) -- 5 whole rounds of 256 x 256 tiles at configs[3] instead of twice 2.5
     uint16_t* wcl2 = nullptr;
     if (!readout) CHK(getbuf_t(h, "bw_Wcl_Wclt", (size_t)2 * D * D, &wcl2));
+    // readout layer 1 with ctx2out: a = tanh([hd | ctx] . [Wl1 ; Wl2] + bl1 + bl2 ...) is ONE K-concatenated problem (K = 2 D):
+    // Wl1^T and Wl2^T side by side in rows of 2 D
+    b->Wl12 = nullptr;
+    if (readout && w.Wl2) {
+        CHK(getbuf_t(h, "bw_Wl12", (size_t)2 * D * E, &b->Wl12));
+        HIPCHK(h, launch_cvt_bf16_t(s, w.Wl1, E, b->Wl12, 2 * D, D, E));
+        HIPCHK(h, launch_cvt_bf16_t(s, w.Wl2, E, b->Wl12 + D, 2 * D, D, E));
+    }
     for (const Item& it : items) {
         if (it.ro != readout || !it.src) continue;      // absent parameter (ff_logit_ctxglm without ctx2out)
         if (it.dst == &b->Wcl) *it.dst = wcl2;
@@ -82,6 +90,22 @@ hipError_t gemm_bf(stattn_handle* h, const GemmBfArgs& g) {
     Prof one(h, KC_COUNT + (seq < KC_GEMM_SEQ ? seq : 0), seq < KC_GEMM_SEQ);
     return launch_gemm_bf16(h->stream, g);
 }
+// several independent bf16 problems: ONE launch of the 256 x 256 kernel when every problem qualifies (one profiling slot, like the
+// fp32 path's grouped launches), else one launch each
+hipError_t gemm_bf_group(stattn_handle* h, const GemmBfArgs* gs, int n) {
+    static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");           // A/B switch for tools
+    bool ok = n > 1 && n <= GEMM_BF_GROUP_MAX && !nogroup;
+    long tiles = 0;
+    for (int i = 0; i < n && ok; ++i) { ok = gemm_bf16_8ph_supported(gs[i]); tiles += (long)((gs[i].M + 255) / 256) * (gs[i].N / 256); }
+    if (!ok || tiles < 128) {
+        for (int i = 0; i < n; ++i) { const hipError_t e = gemm_bf(h, gs[i]); if (e != hipSuccess) return e; }
+        return hipSuccess;
+    }
+    Prof pr(h, KC_GEMM_NN);
+    const int seq = h->gemm_seq++;
+    Prof one(h, KC_COUNT + (seq < KC_GEMM_SEQ ? seq : 0), seq < KC_GEMM_SEQ);
+    return launch_gemm_bf16_8ph_group(h->stream, gs, n);
+}
 GemmBfArgs bf_args(const uint16_t* A, int lda, const uint16_t* B, int M, int N, int Kd) {
     GemmBfArgs g{};
     g.A = A; g.lda = lda; g.B = B; g.ldb = Kd; g.M = M; g.N = N; g.K = Kd; g.rowgroup = 1;
@@ -90,7 +114,7 @@ GemmBfArgs bf_args(const uint16_t* A, int lda, const uint16_t* B, int M, int N, 
 
 // project_context with bf16 operands: L / PL / LW are written as bf16 INTO the (fp32-sized) buffers of CtxPtrs
 static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
-                         const CtxPtrs& c) {
+                         const CtxPtrs& c, const GemmBfArgs* extra) {
     const int D = h->D;
     const Weights& w = h->w;
     hipStream_t s = h->stream;
@@ -107,42 +131,45 @@ static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const fl
     HIPCHK(h, launch_cvt_bf16(s, ctxm, xm, nf * h->Fm));
     HIPCHK(h, launch_cvt_bf16(s, ctxg, xg, nf * D));
     uint16_t* Lb = reinterpret_cast<uint16_t*>(c.L);
-    GemmBfArgs g = bf_args(xl, h->Fl, bw.ff_local, (int)nl, D, h->Fl);       // L = tanh(ctxl . ff_local_W + b)
-    g.bias = w.ff_local_b; g.act = 1; g.Cb = Lb; g.ldcb = D;
-    HIPCHK(h, gemm_bf(h, g));
-    g = bf_args(xm, h->Fm, bw.ff_motion, (int)nf, D, h->Fm);                  // M = tanh(ctxm . ff_motion_W + b)
-    g.bias = w.ff_motion_b; g.act = 1; g.C = c.Mo; g.ldc = D; g.Cb = mo; g.ldcb = D;
-    HIPCHK(h, gemm_bf(h, g));
-    g = bf_args(xg, D, bw.Wcg, (int)nf, D, D);                                // pctxg_
-    g.bias = w.bg; g.C = c.PG; g.ldc = D;
-    HIPCHK(h, gemm_bf(h, g));
+    // first launch: everything that needs raw inputs only, the longest K first (gemm_bf_group): L = tanh(ctxl . ff_local_W + b),
+    // M = tanh(ctxm . ff_motion_W + b), pctxg_ and -- training -- the x projection the caller hands over
+    GemmBfArgs g1[4];
+    int n1 = 0;
+    g1[n1] = bf_args(xl, h->Fl, bw.ff_local, (int)nl, D, h->Fl);
+    g1[n1].bias = w.ff_local_b; g1[n1].act = 1; g1[n1].Cb = Lb; g1[n1].ldcb = D; ++n1;
+    g1[n1] = bf_args(xm, h->Fm, bw.ff_motion, (int)nf, D, h->Fm);
+    g1[n1].bias = w.ff_motion_b; g1[n1].act = 1; g1[n1].C = c.Mo; g1[n1].ldc = D; g1[n1].Cb = mo; g1[n1].ldcb = D; ++n1;
+    g1[n1] = bf_args(xg, D, bw.Wcg, (int)nf, D, D);
+    g1[n1].bias = w.bg; g1[n1].C = c.PG; g1[n1].ldc = D; ++n1;
+    if (extra) g1[n1++] = *extra;
+    HIPCHK(h, gemm_bf_group(h, g1, n1));
+    // second launch: what needs L / M.  PL = L.Wcl + bl and LW = L.Wclt are one problem over N = 2 D columns with two outputs
     static const char* nofuse = getenv("STATTN_BF16_NOFUSE");                 // A/B switch for tools
     const bool fuse = D % 256 == 0 && !nofuse;
+    GemmBfArgs g2[3];
+    int n2 = 0;
     if (fuse) {
-        g = bf_args(Lb, D, bw.Wcl, (int)nl, 2 * D, D);                        // pctxl_ | LW = L . [Wcl | Wclt]  (+ bl on the first half)
-        g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
-        g.n_split = D; g.Cb2 = reinterpret_cast<uint16_t*>(c.LW);
-        HIPCHK(h, gemm_bf(h, g));
+        g2[n2] = bf_args(Lb, D, bw.Wcl, (int)nl, 2 * D, D);                   // pctxl_ | LW = L . [Wcl | Wclt]  (+ bl on the first half)
+        g2[n2].bias = w.bl; g2[n2].Cb = reinterpret_cast<uint16_t*>(c.PL); g2[n2].ldcb = D;
+        g2[n2].n_split = D; g2[n2].Cb2 = reinterpret_cast<uint16_t*>(c.LW); ++n2;
     } else {
-        g = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                            // pctxl_
-        g.bias = w.bl; g.Cb = reinterpret_cast<uint16_t*>(c.PL); g.ldcb = D;
-        HIPCHK(h, gemm_bf(h, g));
+        g2[n2] = bf_args(Lb, D, bw.Wcl, (int)nl, D, D);                       // pctxl_
+        g2[n2].bias = w.bl; g2[n2].Cb = reinterpret_cast<uint16_t*>(c.PL); g2[n2].ldcb = D; ++n2;
     }
-    g = bf_args(mo, D, bw.Wcm, (int)nf, D, D);                                // pctxm_
-    g.bias = w.bm; g.C = c.PM; g.ldc = D;
-    HIPCHK(h, gemm_bf(h, g));
+    g2[n2] = bf_args(mo, D, bw.Wcm, (int)nf, D, D);                           // pctxm_
+    g2[n2].bias = w.bm; g2[n2].C = c.PM; g2[n2].ldc = D; ++n2;
     if (!fuse) {
-        g = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                           // LW = L . Wclt
-        g.Cb = reinterpret_cast<uint16_t*>(c.LW); g.ldcb = D;
-        HIPCHK(h, gemm_bf(h, g));
+        g2[n2] = bf_args(Lb, D, bw.Wclt, (int)nl, D, D);                      // LW = L . Wclt
+        g2[n2].Cb = reinterpret_cast<uint16_t*>(c.LW); g2[n2].ldcb = D; ++n2;
     }
+    HIPCHK(h, gemm_bf_group(h, g2, n2));
     return STATTN_OK;
 }
 
 // `extra`: one more independent plain GEMM that rides in the first launch (training: the x projection), or null.
 int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
-                    const CtxPtrs& c, const GemmArgs* extra) {
-    if (h->opt.precision == 1) return project_context_bf16(h, nv, T, K, ctxg, ctxl, ctxm, c);
+                    const CtxPtrs& c, const GemmArgs* extra, const GemmBfArgs* extra_bf) {
+    if (h->opt.precision == 1) return project_context_bf16(h, nv, T, K, ctxg, ctxl, ctxm, c, extra_bf);
     const int D = h->D;
     const Weights& w = h->w;
     Prof pr(h, KC_PROLOGUE);
@@ -358,6 +385,7 @@ int run_step(stattn_handle* h, const StepIO& io) {
         a.alphal = io.alphal; a.CL = io.CL; a.eg = io.eg; a.em = io.em; a.elt = io.elt;
         a.M = io.M; a.T = io.T; a.K = io.K; a.D = D;
         if (io.upd && !spatial_update_supported(a)) return fail(h, STATTN_EINVAL, "run_step: this attention launch cannot carry the update");
+        if (io.upd) h->upd_rowwg_last = spatial_update_row_workgroups(a, *io.upd);      // what the path counter reports (api_sampler.cpp)
         HIPCHK(h, launch_spatial(h->stream, a, io.upd));
     }
     if (io.phase == 1) return STATTN_OK;

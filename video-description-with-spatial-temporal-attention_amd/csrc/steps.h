@@ -29,13 +29,14 @@ int gemm_group(stattn_handle* h, const GemmArgs* gs, int n);
 // ---- context tensors of a batch / a video -------------------------------------------
 struct CtxPtrs { float *G, *L, *Mo, *PG, *PL, *PM, *LW; };
 
-struct BfWeights { uint16_t *ff_local, *ff_motion, *Wcg, *Wcl, *Wcm, *Wclt, *W, *Wl1, *Wl2, *Wo; };
+struct BfWeights { uint16_t *ff_local, *ff_motion, *Wcg, *Wcl, *Wcm, *Wclt, *W, *Wl1, *Wl2, *Wo, *Wl12; };
 
 int bf16_weights(stattn_handle* h, BfWeights* b, bool readout);
 hipError_t gemm_bf(stattn_handle* h, const GemmBfArgs& g);
+hipError_t gemm_bf_group(stattn_handle* h, const GemmBfArgs* gs, int n);
 GemmBfArgs bf_args(const uint16_t* A, int lda, const uint16_t* B, int M, int N, int Kd);
 int project_context(stattn_handle* h, int nv, int T, int K, const float* ctxg, const float* ctxl, const float* ctxm,
-                    const CtxPtrs& c, const GemmArgs* extra = nullptr);
+                    const CtxPtrs& c, const GemmArgs* extra = nullptr, const GemmBfArgs* extra_bf = nullptr);
 int init_state(stattn_handle* h, int nv, int T, const float* G, const float* maskG, float* mean, float* h0, float* c0);
 
 // ---- packed weight panels of the per-step kernels (panel.hip) -------------------------

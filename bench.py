@@ -294,7 +294,7 @@ def leg_decode_c1(args, local):
     return out
 
 
-def leg_eval_msvd(args, local, nvid=None, chunk=64):
+def leg_eval_msvd(args, local, nvid=None, chunk=32):
     """The reference's evaluation workload (metrics.py:121-135: every test video through gen_sample(beam = 5, maxlen = 50); 670 MSVD
     test videos, config.py shapes) on `gen_sample_batch`'s device path: host features handed over in chunks of `chunk` videos
     (staged, F -> D projected and decoded by ONE stattn_beam_search call per chunk), <eos> suppressed so the step count is fixed.
@@ -708,7 +708,8 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam", "eval"])
     ap.add_argument("--eval-videos", type=int, default=None, help="eval mode: videos of the pass (default: the 670 MSVD test videos)")
-    ap.add_argument("--eval-chunk", type=int, default=64, help="eval mode: videos per stattn_beam_search call")
+    ap.add_argument("--eval-chunk", type=int, default=32, help="eval mode: videos per stattn_beam_search call (32 = 160 rows: 2074 videos/s "
+                    "against 1447 / 1800 / 2043 / 1986 at 16 / 64 / 96 / 128, round 5)")
     ap.add_argument("--beam", type=int, default=None, help="beam width k of gen_sample (decode mode default 1 = greedy, beam mode default 5)")
     ap.add_argument("--h2d", default="none", choices=["none", "sync", "prefetch"],
                     help="train mode only: also move the minibatch host->device every step (never the headline value): "
@@ -934,9 +935,9 @@ def main():
         # (+ the x projection), then what needs L / M; PL = L.Wcl + bl and LW = L.Wclt are ONE problem over N = 2 D columns
         fuse = dec.lt_mode == 1 and D % 256 == 0 and not os.environ.get("STATTN_BF16_NOFUSE")
         g1 = proj1 + [("xproj", R, 4 * D, E)]
-        g2 = ([("pctxl|L.Wclt", BTK, 2 * D, D)] if fuse else [proj2[0]]) + [proj2[-1]] + ([] if fuse else proj2[1:-1])
+        g2 = [("pctxl|L.Wclt", BTK, 2 * D, D)] if fuse else [proj2[0]] + proj2[1:-1]
         grouped = not os.environ.get("STATTN_GEMM_NOGROUP") and all(n_ % 256 == 0 and k_ % 64 == 0 for _, _, n_, k_ in g1 + g2)
-        launches = ([g1, g2] if grouped else [[x_] for x_ in g1 + g2]) + tail
+        launches = ([g1] + ([g2] if len(g2) > 1 else [[g2[0]]]) if grouped else [[x_] for x_ in g1 + g2]) + [[proj2[-1]]] + tail
     elif os.environ.get("STATTN_GEMM_NOGROUP"):
         launches = [[x_] for x_ in proj1 + [("xproj", R, 4 * D, E)] + proj2] + tail
     else:
@@ -1005,17 +1006,23 @@ def main():
         else:
             bl += [("dWo+dWl1+dWl2", "TN", [(E, Vp, R), (D, E, R)] + ([(D, E, R)] if options["ctx2out"] else [])),
                    ("dhd+dctx_r", "NT", [(R, D, E)] + ([(R, D, E)] if options["ctx2out"] else []))]
-        bl += [("dWcl=L^T.dPL", "TN", [(D, D, MTK)]), ("dWclt=L^T.dLW", "TN", [(D, D, MTK)])]
         nogroup = bool(os.environ.get("STATTN_GEMM_NOGROUP"))
         ntgroup = args.precision == "fp32" and not os.environ.get("STATTN_READOUT_NOPAIR") and not nogroup
+        # after the reverse scan (csrc/api_backward.cpp): first the weight gradients that only need the scan's factors (their arrays open
+        # the decoder region: the data-parallel all-reduce of those 42 MB starts here), then ctxgrad's consumers
+        ga = [("dU", D, 4 * D, R), ("dWc", D, 4 * D, R), ("dW", E, 4 * D, R), ("dff_state_W", D, D, B), ("dff_memory_W", D, D, B)]
+        gq = [("dWcg", D, D, MT), ("dWcm", D, D, MT)] + [("dWd%d" % i, D, D, R) for i in range(4)] + ([("dff_motion_W", Fm, D, MT)] if ntgroup else [])
+        if nogroup:
+            bl += [(n_, "TN", [(a_, b_, c_)]) for n_, a_, b_, c_ in ga]
+        else:
+            bl += [("dU+dWc+dW+dff_state_W+dff_memory_W", "TN", [x_[1:] for x_ in ga])]
+        bl += [("dWcl=L^T.dPL", "TN", [(D, D, MTK)]), ("dWclt=L^T.dLW", "TN", [(D, D, MTK)])]
         if ntgroup:       # one grouped NT launch: demb, the K-concatenated dL pair, dMo
             bl += [("demb+dL(pair)+dMo", "NT", [(R, E, 4 * D), (MTK, D, 2 * D), (MT, D, D)])]
-        ga = [("dU", D, 4 * D, R), ("dWc", D, 4 * D, R), ("dW", E, 4 * D, R)] + ([("dff_motion_W", Fm, D, MT)] if ntgroup else [])
-        gq = [("dWcg", D, D, MT), ("dWcm", D, D, MT)] + [("dWd%d" % i, D, D, R) for i in range(4)] + [("dff_state_W", D, D, B), ("dff_memory_W", D, D, B)]
         if nogroup:
-            bl += [(n_, "TN", [(a_, b_, c_)]) for n_, a_, b_, c_ in ga + gq]
+            bl += [(n_, "TN", [(a_, b_, c_)]) for n_, a_, b_, c_ in gq]
         else:
-            bl += [("+".join(x_[0] for x_ in ga), "TN", [x_[1:] for x_ in ga]), ("dWcg+dWcm+4xdWd+dff_state_W+dff_memory_W", "TN", [x_[1:] for x_ in gq])]
+            bl += [("+".join(x_[0] for x_ in gq), "TN", [x_[1:] for x_ in gq])]
         if ntgroup:
             bl += [("dff_local_W=ctxl^T.dL", "TN", [(F, D, MTK)])]
         else:

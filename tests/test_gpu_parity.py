@@ -561,6 +561,71 @@ def test_c5_full_size_device_beam_search(stattn_mod, O, monkeypatch):
             np.testing.assert_allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)
 
 
+@pytest.mark.parametrize("nvid,k,V", [(9, 2, 1237), (4, 5, 2000), (6, 5, 333), (11, 3, 1237), (7, 7, 4099), (8, 8, 12000)])
+def test_mid_size_beams_take_the_vocabulary_statistics_path(stattn_mod, O, nvid, k, V):
+    """Beams of 17 .. 64 rows (18, 20, 30, 33, 49, 64): since round 5 their vocabulary launch runs on the wide row-panel kernel with
+    the statistics epilogue (no logits stored, no softmax / top-k launches) -- the change round 4 reverted after an unexplained memory
+    access fault.  Vocabularies that are no multiple of the 32-column blocks, <eos> deaths, every video against
+    the host-driven loop (which goes through f_next: stored logits, the softmax kernel)."""
+    dims = dict(dim=256, dim_word=128, n_words=V, ctxg_dim=256, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=256)
+    opt = O.default_options(**dims)
+    P = O.random_params(opt, seed=31 + nvid, dtype=np.float32)
+    P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 2.5
+    maxlen = 6
+    b = O.synthetic_batch(opt, B=nvid, T=7, K=5, t=3, seed=64 + k)
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    f_next.device_loop = False
+    dec = f_next.decoder
+    res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
+    assert dec.beam_vocab_stats_words() > 0
+    for v in range(nvid):
+        args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+        s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=maxlen)
+        bs, bsc = res[v]
+        assert bs == s, v
+        np.testing.assert_allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)
+
+
+def test_msvd_eval_shape_batched_beam_search(stattn_mod, O):
+    """The reference's evaluation workload at its real shape (metrics.py:121-135 with config.py's options: T = 28 frames, 8
+    regions, feat 4096, hidden 1024, E = 512, vocabulary 20 000, beam 5) on the path `bench.py`'s eval_msvd leg measures:
+    gen_sample_batch over a chunk of 32 videos = 160 rows (896 (video, frame) items: the shared-slab attention kernel by the
+    K <= 8 rule of 800 items, the update riding in it, the 160-row wide row-panel GEMMs with the vocabulary statistics).
+    Videos 0 and 1 against the oracle's gen_sample, the others against the product's host-driven loop."""
+    dims = dict(dim=1024, dim_word=512, n_words=20000, ctxg_dim=1024, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=1024)
+    opt = O.default_options(**dims)
+    P = O.random_params(opt, seed=29, dtype=np.float32)
+    P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 2.0        # some hypotheses end early
+    P64 = O.cast_params(P, np.float64)
+    nvid, T, K, k, maxlen = 32, 28, 8, 5, 7
+    b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=63)
+    model = stattn_mod.Attention()
+    tparams = model.init_tparams(P)
+    f_init, f_next = model.build_sampler(tparams, opt, None, None)
+    f_next.device_loop = False
+    dec = f_next.decoder
+    res = model.gen_sample_batch(tparams, opt, b['ctxg'], b['mask_ctxg'], b['ctxl'], b['ctxm'], k=k, maxlen=maxlen)
+    assert len(res) == nvid and dec.beam_graph_replays() > 0
+    assert dec.path_counts()['upd_rider'] > 0
+    for v in range(nvid):
+        args = (b['ctxg'][v], b['mask_ctxg'][v], b['ctxl'][v], b['mask_ctxl'][v], b['ctxm'][v], b['mask_ctxm'][v])
+        bs, bsc = res[v]
+        if v < 2:
+            a64 = tuple(a.astype(np.float64) for a in args)
+            cv = O.project_video(P64, opt, a64[0], a64[2], a64[4])
+            sr, scr, _, _ = O.gen_sample(lambda g_, m_: O.f_init(P64, opt, g_, m_),
+                                         lambda *a: O.f_next(P64, opt, *a, cached=cv), *a64, k=k, maxlen=maxlen)
+            assert len(bs) == len(sr)
+            np.testing.assert_allclose(sorted(bsc), sorted(np.asarray(scr, np.float64)), rtol=1e-4, atol=2e-4)
+            assert bs[int(np.argmin(bsc))] == sr[int(np.argmin(scr))]
+        elif v < 8:
+            s, sc, _, _ = model.gen_sample(tparams, f_init, f_next, *args, opt, None, k, maxlen=maxlen)
+            assert bs == s, v
+            np.testing.assert_allclose(bsc, np.asarray(sc, np.float32), rtol=1e-4, atol=1e-4)
+
+
 def test_c1_greedy_gen_sample_full_vocabulary(stattn_mod, O):
     """BASELINE.json configs[0] 'MSVD tiny': T=26, K=8, feat=4096, hidden=512, vocabulary 12 000, greedy decode --
     the reference's gen_sample(k=1, maxlen=30) protocol on one video against the oracle, on the host-driven loop AND

@@ -674,6 +674,10 @@ class Decoder(object):
         names = ("fwd_rider", "fwd_panel", "bwd_rider", "bwd_panel", "upd_rider", "upd_rowwg")
         return {n: int(self._lib.stattn_dbg_counter(self._h, i + 1)) for i, n in enumerate(names)}
 
+    def beam_vocab_stats_words(self):
+        """Words of the last beam search whose vocabulary launch ended in the statistics epilogue (no logits, softmax or top-k launch)."""
+        return int(self._lib.stattn_dbg_counter(self._h, 7))
+
     def time_gemm_bf16(self, M, N, K, tile=0, iters=20):
         ms = C.c_float()
         self._chk(self._lib.stattn_dbg_time_gemm_bf16(self._h, M, N, K, int(tile), iters, C.byref(ms)))

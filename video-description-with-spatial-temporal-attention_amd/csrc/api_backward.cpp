@@ -373,6 +373,31 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // the F->D projection gradients -- the largest GEMM of the pass -- are computed), then ff_*, then Wemb.
     HIPCHK(h, launch_state0_bwd(s, dhp_in, dhUP, rider ? kzU : kz1, dhWP, kz2, dselpre, h->opt.selector ? w.W_sel : nullptr, dc, hs, cs,
                                 dph0, dpc0, m, D));
+    {   // The weight gradients that need nothing but the reverse scan's per-step factors -- dU = hs^T dpre, dWc = ctx^T dpre,
+        // dW = emb^T dpre over all (t*m) rows, and the two initial-state ones (K = m) -- come FIRST, as one grouped TN launch: their
+        // arrays [decoder_W .. decoder_Wc] open the decoder region of the flat buffer, so a data-parallel rank starts summing those
+        // 42 MB while ctxgrad, the attention weight gradients and the input-gradient GEMMs (~1.5 ms) still run (VERDICT r04 item 9:
+        // the whole 76 MB region used to be handed over behind all of them)
+        static const char* nogroup0 = getenv("STATTN_GEMM_NOGROUP");
+        GemmArgs ga[5];
+        auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int Kd) {
+            gemm_defaults(q); q.split = h->opt.precision != 0;
+            q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = Kd;
+        };
+        int na = 0;
+        tn(ga[na++], hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R);
+        tn(ga[na++], ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R);
+        tn(ga[na++], emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R);
+        tn(ga[na++], mean, D, dph0, D, G_("ff_state_W"), D, D, D, m);
+        tn(ga[na++], mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m);
+        if (nogroup0) {
+            for (int i = 0; i < na; ++i) HIPCHK(h, gemm(true, false, ga[i].A, ga[i].lda, ga[i].B, ga[i].ldb, ga[i].C, ga[i].ldc, ga[i].M, ga[i].N, ga[i].K, 0));
+        } else {
+            HIPCHK(h, gemm_grp(ga, na, true, false));
+        }
+        CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
+        CHK(region_done("decoder_W", "decoder_Wcg_att"));
+    }
     {
         CtxGradArgs a{};
         a.PL = PLs; a.LW = LWs; a.bf16 = bf ? 1 : 0; a.PG = PG; a.PM = PM; a.sproj = sproj; a.dcsum = dcsum; a.dplt = dplt;
@@ -432,35 +457,26 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D, bf ? 1 : 0));
         HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
     }
-    {   // Weight gradients over all (t*m) rows / all frames, K = 1664..1920 (and the two initial-state ones, K = m), as
-        // TWO grouped TN launches: [dU, dWc, dW, dff_motion_W] (3584 tiles) and the six D x D ones with ff_state / ff_memory
-        // (2048 tiles: alone the 256-tile problems needed a split-K pass each).  Each launch used to ramp up and drain on its own.
-        GemmArgs ga[4], gq[8];
+    {   // the weight gradients that wait for the deferred context gradients: the six D x D ones over all frames / all (t*m) rows
+        // and -- fp32 path -- dff_motion_W, ONE grouped TN launch (alone the 256-tile problems needed a split-K pass each)
+        GemmArgs gq[8];
         auto tn = [&](GemmArgs& q, const float* A, int lda, const float* B, int ldb, float* C, int ldc, int M_, int N_, int Kd) {
             gemm_defaults(q); q.split = h->opt.precision != 0;
             q.A = A; q.lda = lda; q.B = B; q.ldb = ldb; q.C = C; q.ldc = ldc; q.M = M_; q.N = N_; q.K = Kd;
         };
-        int na = 0, nq = 0;
-        tn(ga[na++], hs, D, dpre, 4 * D, G_("decoder_U"), 4 * D, D, 4 * D, (int)R);
-        tn(ga[na++], ctx, D, dpre, 4 * D, G_("decoder_Wc"), 4 * D, D, 4 * D, (int)R);
-        tn(ga[na++], emb, E, dpre, 4 * D, G_("decoder_W"), 4 * D, E, 4 * D, (int)R);
-        if (ntgroup) tn(ga[na++], rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT);
+        int nq = 0;
         tn(gq[nq++], Gc, D, dPG, D, G_("decoder_Wcg_att"), D, D, D, (int)MT);
         tn(gq[nq++], Mo, D, dPM, D, G_("decoder_Wcm_att"), D, D, D, (int)MT);
         const char* names[4] = {"decoder_Wdl_att", "decoder_Wdg_att", "decoder_Wdm_att", "decoder_Wdlt_att"};
         for (int i = 0; i < 4; ++i) tn(gq[nq++], hs, D, dsproj + (size_t)i * D, 4 * D, G_(names[i]), D, D, D, (int)R);
-        tn(gq[nq++], mean, D, dph0, D, G_("ff_state_W"), D, D, D, m);
-        tn(gq[nq++], mean, D, dpc0, D, G_("ff_memory_W"), D, D, D, m);
+        if (ntgroup) tn(gq[nq++], rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT);
         if (nogroup) {
-            for (int i = 0; i < na; ++i) HIPCHK(h, gemm(true, false, ga[i].A, ga[i].lda, ga[i].B, ga[i].ldb, ga[i].C, ga[i].ldc, ga[i].M, ga[i].N, ga[i].K, 0));
             for (int i = 0; i < nq; ++i) HIPCHK(h, gemm(true, false, gq[i].A, gq[i].lda, gq[i].B, gq[i].ldb, gq[i].C, gq[i].ldc, gq[i].M, gq[i].N, gq[i].K, 0));
         } else {
-            HIPCHK(h, gemm_grp(ga, na, true, false));
             HIPCHK(h, gemm_grp(gq, nq, true, false));
         }
     }
-    CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
-    CHK(region_done("decoder_W", "ff_logit_lstm_W"));
+    CHK(region_done("decoder_Wcg_att", "ff_logit_lstm_W"));
     // -- region ff_*: initial state (:657-660), then back through tanh(ff_local), tanh(ff_motion) (:664-667)
     CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
     CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);

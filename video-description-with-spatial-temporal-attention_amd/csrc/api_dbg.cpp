@@ -216,6 +216,7 @@ long stattn_dbg_counter(const stattn_handle* h, int which) {
     if (which == 4) return h->path_bwd_panel;
     if (which == 5) return h->path_upd_rider;
     if (which == 6) return h->path_upd_rowwg;
+    if (which == 7) return h->path_vocab_stats;
     return -1;
 }
 

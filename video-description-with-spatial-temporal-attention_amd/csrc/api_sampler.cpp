@@ -370,16 +370,23 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // panel.hip's kernel, beyond 64 rows the wide kernel (panelw.hip); in between (one row group of 16-column tiles, but more
     // rows than a statistics pass per wave pays for) the logits are stored and the softmax + top-k launches run.
     bool vocab_stats = small;
+    // Beams of 17 .. 64 rows send their vocabulary launch to the wide kernel as well (PnArgs::wide_from = 17; every other launch of
+    // such a word stays on the 16-column kernel): no logits store, no softmax launch, no top-k launches, the update reads the records
+    // (`--mode beam --config c1 --beam 5`, 20 rows: 205-207 k -> 212 k row-steps/s).  Round 4 tried this by other means and one
+    // parity case died with a memory access fault that was never reproduced: with THIS switch the whole GPU suite and 300 random beams
+    // (fuzz_parity: 17 .. 64-row grids among them) run clean; STATTN_WIDE_STATS_FROM=65 restores the stored logits.
+    static const char* wsf = getenv("STATTN_WIDE_STATS_FROM");
+    const int wide_stats_from = wsf ? atoi(wsf) : 17;
     if (panels && !vocab_stats && !stochastic && h->opt.precision != 1) {
         PnArgs probe{};
-        probe.M = M; probe.nseg = 1;
+        probe.M = M; probe.nseg = 1; probe.wide_from = wide_stats_from;
         pn_seg_defaults(probe.seg[0]);
         probe.seg[0].npairs = 1; probe.seg[0].p[0] = PnPair{a1_pk, E, pn.Wo, E, 1}; probe.seg[0].N = Vp;
         vocab_stats = panel_wide_supported(probe);
     }
     if (vocab_stats) {
         // the logits launch (same arguments for every word)
-        lgargs.M = M; lgargs.nseg = 1;
+        lgargs.M = M; lgargs.nseg = 1; lgargs.wide_from = small ? 0 : wide_stats_from;
         // Small-batch decode re-reads the same ~45 MB of weights every word; per XCD that is 5.5 MB through a 4 MB L2, so nothing
         // survives from word to word.  The vocabulary matrix is more than half of it: loaded with the non-temporal policy it no
         // longer displaces the rest, which then hits L2 in the other launches of the next word (configs[0]: 48.0 -> 45.5 us per
@@ -707,6 +714,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     h->path_upd_rider = ride ? steps_run : 0;      // (replayed graphs included)
     // (a riding update falls back to one workgroup per video when its attention launch is the shared-slab kernel: count what ran)
     h->path_upd_rowwg = rw_cost && (!ride || h->upd_rowwg_last) ? steps_run : 0;
+    h->path_vocab_stats = vocab_stats ? steps_run : 0;
     // results: finished hypotheses in order of death, then the remaining live ones (:987-992)
     {
         const int fb = steps_run & 1;     // buffers written by the last executed step

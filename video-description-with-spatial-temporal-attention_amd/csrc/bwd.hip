@@ -13,6 +13,7 @@
 // dMo, the U*_att vectors and all weight matrices) is deferred: the per-step factors (del, deg, dem,
 // dplt, dcsum, dpre, dsproj) are stored -- HBM is 288 GB -- and ctxgrad_kernel / batched MFMA GEMMs
 // consume them once after the loop, instead of a read-modify-write of 54 MB tensors in every step.
+#include <cstdlib>
 #include "kernels.h"
 #include "devmath.h"
 #include "panel_inl.h"
@@ -352,6 +353,190 @@ __global__ __launch_bounds__(256, KR <= 8 ? 4 : 3) void spatial_bwd_kernel(const
 #pragma unroll 8
         for (int k = 0; k < K; ++k) fma4(acc, s_da[k], one_minus_sq(tanh4s(ldPL((size_t)k * D + 4 * d4), sl)));
         st4(a.dslp + (size_t)bt * D + 4 * d4, mul4(acc, ld4(a.Ul + 4 * d4)));
+    }
+}
+
+// ---- bf16 handles, K <= 16: the same item (row b, frame t) with 128 threads and EIGHT columns per lane, so that the bf16 slabs
+// are read with 16-byte loads (the 4-column form above reads them 8 bytes at a time: 3.2 TB/s of its bytes at configs[3]).  The LW
+// rows of a lane stay in registers as packed bf16 (4 VGPRs per region) between their two uses.  Same arithmetic, fp32 throughout.
+struct F8 { float v[8]; };
+__device__ __forceinline__ F8 ld8f(const float* p) {
+    const float4 a = ld4(p), b = ld4(p + 4);
+    return F8{{a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w}};
+}
+__device__ __forceinline__ void st8f(float* p, const F8& x) {
+    st4(p, make_float4(x.v[0], x.v[1], x.v[2], x.v[3])); st4(p + 4, make_float4(x.v[4], x.v[5], x.v[6], x.v[7]));
+}
+__device__ __forceinline__ F8 widen8(const uint4 u) {
+    return F8{{__uint_as_float(u.x << 16), __uint_as_float(u.x & 0xffff0000u), __uint_as_float(u.y << 16), __uint_as_float(u.y & 0xffff0000u),
+               __uint_as_float(u.z << 16), __uint_as_float(u.z & 0xffff0000u), __uint_as_float(u.w << 16), __uint_as_float(u.w & 0xffff0000u)}};
+}
+__device__ __forceinline__ uint4 ld16b(const float* base, size_t off) {        // 8 bf16 of a region tensor stored behind a float pointer
+    return *reinterpret_cast<const uint4*>(reinterpret_cast<const uint16_t*>(base) + off);
+}
+__device__ __forceinline__ float dot8(const F8& a, const F8& b) {
+    float r = 0.f;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) r += a.v[i] * b.v[i];
+    return r;
+}
+
+template <int KR>
+__global__ __launch_bounds__(128, KR <= 8 ? 4 : 3) void spatial_bwd_bf16_kernel(const SpatialBwdArgs a) {
+    constexpr int NT = 128, NW = 2;
+    __shared__ float s_red[NW * (KR > 8 ? KR : 8)];
+    __shared__ float s_al[KMAX], s_da[KMAX];
+    if ((int)blockIdx.x < a.rider.nblocks) {
+        __shared__ __attribute__((aligned(16))) float s_rider[NW * 64 * 16];
+        rider_tile<NW>(a.rider, (int)blockIdx.x, s_rider);
+        return;
+    }
+    const int T = a.T, K = a.K, D = a.D;
+    const int bt = xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T), b = bt / T, tid = threadIdx.x;
+    const size_t slab = (size_t)bt * K * D;
+    const float* __restrict__ sp = a.sproj + (size_t)b * a.ldsp;
+    const int nd8 = D >> 3;
+    __shared__ float s_de[3];
+    if (tid < K) s_al[tid] = a.alphal[(size_t)bt * K + tid];
+    const int tf = bt - b * T;
+    const size_t MD = (size_t)a.M * D;
+    const float sel = a.has_sel ? a.sel[b] : 1.f;
+    auto form_dcs = [&](int d8) {          // dctx[b, 8 d8 ..] = readout term + partials of dpre.Wc^T
+        const size_t ob = (size_t)b * D + 8 * d8;
+        F8 dc = a.dctx_r ? ld8f(a.dctx_r + ob) : F8{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 4
+        for (int q = 0; q < a.nP; ++q) {
+            const F8 pq = ld8f(a.dctxP + (size_t)q * MD + ob);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dc.v[i] += pq.v[i];
+        }
+        return dc;
+    };
+    constexpr int DCS_LDS = 2048;
+    __shared__ __attribute__((aligned(16))) float s_dcs[DCS_LDS];
+    const bool dcs_lds = D <= DCS_LDS;
+    {   // ---- temporal part (see spatial_bwd_kernel)
+        float q[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) q[i] = 0.f;
+        for (int d8 = tid; d8 < nd8; d8 += NT) {
+            const size_t ob = (size_t)b * D + 8 * d8, o = (size_t)bt * D + 8 * d8;
+            const F8 xc = ld8f(a.csum + ob), xg = ld8f(a.G + o), xm = ld8f(a.Mo + o), xl = ld8f(a.CL + o);
+            const F8 x0 = ld8f(a.cparts + ob), x1 = ld8f(a.cparts + MD + ob), x2 = ld8f(a.cparts + 2 * MD + ob);
+            const F8 dc = form_dcs(d8);
+            q[6] += dot8(dc, xc);
+            F8 dcs;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dcs.v[i] = dc.v[i] * sel;
+            if (dcs_lds) st8f(&s_dcs[8 * d8], dcs);
+            if (tf == 0) st8f(a.dcsum + ob, dcs);
+            q[0] += dot8(dcs, xg); q[1] += dot8(dcs, xm); q[2] += dot8(dcs, xl);
+            q[3] += dot8(dcs, x0); q[4] += dot8(dcs, x1); q[5] += dot8(dcs, x2);
+        }
+        block_sum<8>(q, s_red, tid, NW);
+        const int lane = tid & 63;
+        for (int w = tid >> 6; w < 3; w += NW) {       // softmax backward of the three temporal attentions, one wave each
+            const float* al = (w == 0 ? a.ag : (w == 1 ? a.am : a.alt)) + (size_t)b * T;
+            const float* r = w == 0 ? a.rg : (w == 1 ? a.rm : a.rlt);
+            float dotr = 0.f;
+            if (r) {
+                for (int t = lane; t < T; t += 64) dotr += al[t] * r[(size_t)b * T + t];
+                dotr = wave_sum(dotr);
+            }
+            if (lane == 0) {
+                const float da = q[w] + (r ? r[bt] : 0.f);
+                const float de = al[tf] * (da - (q[3 + w] + dotr));
+                s_de[w] = de;
+                (w == 0 ? a.deg : (w == 1 ? a.dem : a.delt))[bt] = de;
+            }
+        }
+        if (tid == 0 && tf == 0) a.dselpre[b] = a.has_sel ? q[6] * sel * (1.f - sel) : 0.f;
+    }
+    __syncthreads();
+    const float alt = a.alt[bt], delt = s_de[2], deg = s_de[0], dem = s_de[1];
+    auto dcs_of = [&](int d8) {
+        if (dcs_lds) return ld8f(&s_dcs[8 * d8]);
+        F8 dc = form_dcs(d8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dc.v[i] *= sel;
+        return dc;
+    };
+    // per-frame dsg / dsm
+    for (int d8 = tid; d8 < nd8; d8 += NT) {
+        const size_t fo = (size_t)bt * D + 8 * d8;
+        const F8 pg = ld8f(a.PG + fo), pm = ld8f(a.PM + fo), sg = ld8f(sp + D + 8 * d8), sm = ld8f(sp + 2 * D + 8 * d8);
+        const F8 ug = ld8f(a.Ug + 8 * d8), um = ld8f(a.Um + 8 * d8);
+        F8 og, om;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float tg = fast_tanh(pg.v[i] + sg.v[i]), tm = fast_tanh(pm.v[i] + sm.v[i]);
+            og.v[i] = ug.v[i] * (1.f - tg * tg) * deg; om.v[i] = um.v[i] * (1.f - tm * tm) * dem;
+        }
+        st8f(a.dsgp + fo, og); st8f(a.dsmp + fo, om);
+    }
+    // plt recomputed, dplt, d alpha_k = <alt dcsum, L_k> + <dplt, LW_k> + r_k; the lane's LW rows stay packed in registers
+    {
+        float p[KR];
+#pragma unroll
+        for (int i = 0; i < KR; ++i) p[i] = 0.f;
+        for (int d8 = tid; d8 < nd8; d8 += NT) {
+            uint4 lw[KR];
+#pragma unroll
+            for (int kk = 0; kk < KR; ++kk) lw[kk] = ld16b(a.LW, slab + (size_t)min(kk, K - 1) * D + 8 * d8);
+            F8 pl = ld8f(a.blt + 8 * d8);
+#pragma unroll
+            for (int kk = 0; kk < KR; ++kk) if (kk < K) {
+                const F8 x = widen8(lw[kk]);
+                const float al = s_al[kk];
+#pragma unroll
+                for (int i = 0; i < 8; ++i) pl.v[i] += al * x.v[i];
+            }
+            const F8 slt = ld8f(sp + 3 * D + 8 * d8), ult = ld8f(a.Ult + 8 * d8);
+            F8 dpl;
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float th = fast_tanh(pl.v[i] + slt.v[i]); dpl.v[i] = ult.v[i] * (1.f - th * th) * delt; }
+            st8f(a.dplt + (size_t)bt * D + 8 * d8, dpl);
+            F8 dcl = dcs_of(d8);
+#pragma unroll
+            for (int i = 0; i < 8; ++i) dcl.v[i] *= alt;
+            // (four L rows in flight at a time: all KR at once spill next to the KR packed LW rows)
+#pragma unroll
+            for (int k4 = 0; k4 < KR; k4 += 4) {
+                uint4 lr[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) lr[j] = ld16b(a.L, slab + (size_t)min(k4 + j, K - 1) * D + 8 * d8);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) p[k4 + j] += dot8(dcl, widen8(lr[j])) + dot8(dpl, widen8(lw[k4 + j]));
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        block_sum<KR>(p, s_red, tid, NW);
+        if (tid < KR && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
+        __syncthreads();
+    }
+    float dotp = 0.f;
+    for (int k = 0; k < K; ++k) dotp += s_al[k] * s_da[k];
+    __syncthreads();
+    if (tid < K) {
+        const float de = s_al[tid] * (s_da[tid] - dotp);
+        s_da[tid] = de;
+        a.del[(size_t)bt * K + tid] = de;
+    }
+    __syncthreads();
+    // dsl (this frame) = Ul sum_k del_k (1 - tanh^2(PL_k + sl))
+    for (int d8 = tid; d8 < nd8; d8 += NT) {
+        const F8 sl = ld8f(sp + 8 * d8), ul = ld8f(a.Ul + 8 * d8);
+        F8 acc{{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}};
+#pragma unroll 8
+        for (int k = 0; k < K; ++k) {
+            const F8 x = widen8(ld16b(a.PL, slab + (size_t)k * D + 8 * d8));
+            const float de = s_da[k];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) { const float th = fast_tanh(x.v[i] + sl.v[i]); acc.v[i] += de * (1.f - th * th); }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc.v[i] *= ul.v[i];
+        st8f(a.dslp + (size_t)bt * D + 8 * d8, acc);
     }
 }
 
@@ -829,7 +1014,11 @@ hipError_t launch_spatial_bwd(hipStream_t s, const SpatialBwdArgs& a) {
     const dim3 grid(a.M * a.T + a.rider.nblocks);
     if (a.bf16) {
         if (a.D % 4) return hipErrorInvalidValue;
-        if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL((spatial_bwd_kernel<16, true>), grid, dim3(256), 0, s, a);
+        static const char* no8 = getenv("STATTN_BWD_BF16_4COL");          // A/B switch for tools: the 4-column form for every shape
+        if (a.K <= 16 && a.D % 8 == 0 && !no8) {     // eight columns per lane, 16-byte slab loads, 128 threads
+            if (a.K > 8) hipLaunchKernelGGL(spatial_bwd_bf16_kernel<16>, grid, dim3(128), 0, s, a);
+            else hipLaunchKernelGGL(spatial_bwd_bf16_kernel<8>, grid, dim3(128), 0, s, a);
+        } else if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL((spatial_bwd_kernel<16, true>), grid, dim3(256), 0, s, a);
         else hipLaunchKernelGGL((spatial_bwd_kernel<8, true>), grid, dim3(256), 0, s, a);
     } else if (a.K > 8 && a.K <= 16) hipLaunchKernelGGL((spatial_bwd_kernel<16, false>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((spatial_bwd_kernel<8, false>), grid, dim3(256), 0, s, a);

@@ -93,7 +93,7 @@ namespace stattn_detail {
 int comm_reduce_range(stattn_handle* h, size_t off, size_t n) {
     // (comm_overlap == 2: also with a single rank -- how the event / side-stream path is exercised on a one-GPU box)
     if (!h->comm || !h->comm_overlap || n == 0 || (h->comm_nranks < 2 && h->comm_overlap != 2)) return STATTN_OK;
-    hipEvent_t ready = h->comm_ready[h->comm_regions & 3];         // an event of its own per region of a pass
+    hipEvent_t ready = h->comm_ready[h->comm_regions & 7];         // an event of its own per region of a pass (five per pass)
     ++h->comm_regions;
     HIPCHK(h, hipEventRecord(ready, h->stream));
     HIPCHK(h, hipStreamWaitEvent(h->comm_stream, ready, 0));

@@ -122,6 +122,7 @@ struct stattn_handle {
     long path_fwd_rider = 0, path_fwd_panel = 0, path_bwd_rider = 0, path_bwd_panel = 0;
     long path_upd_rider = 0;        // words of the last beam / sample search whose update rode in the next word's attention launch
     bool upd_rowwg_last = false;    // the last riding update launch ran row workgroups (set by run_step)
+    long path_vocab_stats = 0;      // words of the last beam search whose vocabulary launch ended in the statistics epilogue (no logits stored)
     long path_upd_rowwg = 0;        // ... whose update ran as k workgroups per video (row workgroups, beam_inl.h)
     bool ck_valid = false;
     // f_next staging: one pinned block for {h, c, x} in and {h, c, probs} out per call (a pageable copy costs
@@ -151,7 +152,7 @@ struct stattn_handle {
     int comm_rank = 0, comm_nranks = 1;
     int comm_overlap = 1;                 // reduce buckets on comm_stream while backward still computes
     hipStream_t comm_stream = nullptr;
-    hipEvent_t comm_ready[4] = {nullptr, nullptr, nullptr, nullptr};   // main stream: "this region's gradients are final" (one per region)
+    hipEvent_t comm_ready[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};   // main stream: "this region's gradients are final" (one per region)
     int comm_regions = 0;                 // regions handed over in the current backward pass
     hipEvent_t comm_done = nullptr;       // comm stream: "every bucket issued so far has been reduced"
     hipEvent_t comm_t0 = nullptr, comm_t1 = nullptr;   // compute stream, timed: around the wait inside stattn_allreduce_grads

@@ -206,6 +206,7 @@ struct PnArgs {
     PnSeg seg[6]; int nseg; int M;
     int kz; size_t part_stride;        // K split over gridDim.y: raw partial tiles to C + z * part_stride, no epilogue
     int stream_b;                      // weights loaded with the non-temporal policy (a matrix that should not displace the others in L2)
+    int wide_from;                     // rows from which the launch takes the wide kernel (panelw.hip); 0 = its default, 65
     int plain_order;                   // wide kernel: column blocks in launch order (segments of different K: the XCD-contiguous order would give whole XCDs the long blocks)
 };
 void pn_seg_defaults(PnSeg& s);

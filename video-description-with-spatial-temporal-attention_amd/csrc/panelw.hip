@@ -403,7 +403,7 @@ bool panel_wide_enabled() {
 
 // the wide kernel takes a launch when it has more than 64 rows, no K split over blocks, and every segment is a multiple of 32 columns
 bool panel_wide_supported(const PnArgs& a) {
-    if (!panel_wide_enabled() || a.M <= 64 || a.M > 256 * 8 || a.kz > 1) return false;
+    if (!panel_wide_enabled() || a.M < (a.wide_from > 0 ? a.wide_from : 65) || a.M > 256 * 8 || a.kz > 1) return false;
     for (int i = 0; i < a.nseg; ++i) {
         if (a.seg[i].N % WCB != 0 || a.seg[i].ldc % 4 != 0 || (a.seg[i].add && a.seg[i].ldadd % 4 != 0) || (a.seg[i].mul && a.seg[i].ldmul % 4 != 0)) return false;
         for (int p = 0; p < a.seg[i].npairs; ++p)

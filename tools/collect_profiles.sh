@@ -21,10 +21,20 @@ python bench.py --mode beam --config c1 --beam 1 --steps 50 --warmup 3 > $o/${r}
 python bench.py --mode beam --config c1 --beam 5 --steps 50 --warmup 3 > $o/${r}_bench_c1_beam5.json 2>> $o/${r}_bench.err
 python bench.py --mode decode --config c1 --steps 5 --warmup 1 > $o/${r}_bench_c1_decode.json 2>> $o/${r}_bench.err
 python bench.py --mode decode --config c1 --beam 5 --steps 5 --warmup 1 --no-cpu-baseline > $o/${r}_bench_c1_decode_beam5.json 2>> $o/${r}_bench.err
+# the reference's evaluation workload on its own (the same leg rides in the default line), and the bf16 LDS tile sweep of configs[3]
+python bench.py --mode eval > $o/${r}_bench_eval_msvd.json 2>> $o/${r}_bench.err
+python tools/gemm_bf16_sweep.py > $o/${r}_bf16_gemm_tile_sweep.txt 2>> $o/${r}_bench.err
+python tools/gemm_8ph_probe.py > $o/${r}_bf16_gemm_8ph_time_model.txt 2>> $o/${r}_bench.err
+# the N > 1 path, functionally: 2 and 8 RCCL ranks time-sharing the one GPU of the box (NOT a scaling number)
+python bench.py --gpus 2 --share-gpu --steps 10 --warmup 2 --no-cpu-baseline > $o/${r}_bench_c2_train_2ranks_shared_gpu.json 2>> $o/${r}_bench.err
+python bench.py --gpus 8 --share-gpu --steps 3 --warmup 1 --no-cpu-baseline > $o/${r}_bench_c2_train_8ranks_shared_gpu.json 2>> $o/${r}_bench.err
 tools/prof_trace.sh ${r}_trace_c2_train --steps 5 --warmup 1 --no-cpu-baseline --no-split --no-legs
 tools/prof_trace.sh ${r}_trace_c5_beam --mode beam --config c5 --steps 3 --warmup 1
 tools/prof_trace.sh ${r}_trace_c1_beam1 --mode beam --config c1 --beam 1 --steps 20 --warmup 2
 tools/prof_trace.sh ${r}_trace_c1_decode --mode decode --config c1 --steps 5 --warmup 1 --no-cpu-baseline
+tools/prof_trace.sh ${r}_trace_c4_train_bf16 --config c4 --precision bf16 --steps 5 --warmup 1 --no-cpu-baseline --no-live-pmc
+tools/prof_trace.sh ${r}_trace_eval_msvd --mode eval --eval-videos 128 --no-cpu-baseline
+tools/prof_pmc.sh ${r}_pmc_c4_bf16 MfmaUtil python bench.py --config c4 --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-live-pmc
 for c in FETCH_SIZE WRITE_SIZE MfmaUtil; do
     tools/prof_pmc.sh ${r}_pmc_train $c python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-split --no-legs --no-live-pmc
 done

@@ -1,6 +1,6 @@
 #!/bin/bash
-# usage: tools/build_gemm_var.sh <name> <extra hipcc flags...>  -> tools/_var/libstattn_<name>.so ($SRC.hip (default gemm) rebuilt with the flags)
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# usage: tools/probes/build_gemm_var.sh <name> <extra hipcc flags...>  -> tools/_var/libstattn_<name>.so ($SRC.hip (default gemm) rebuilt with the flags)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 C=$ROOT/video-description-with-spatial-temporal-attention_amd/csrc
 n=$1; shift
 SRC=${SRC:-gemm}

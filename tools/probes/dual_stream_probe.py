@@ -2,7 +2,7 @@
 """Would running the two halves of a batch as independent scans on two streams overlap the latency chains of the
 per-step kernels?  Emulation with two handles (32 rows each, own streams) against one handle with 64 rows."""
 import os, sys, time
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import stattn, bench
 

@@ -1,4 +1,4 @@
-import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os, sys, time; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, stattn, bench
 c = bench.CONFIGS['c1']; opt = bench.make_options(c)
 dec = stattn.Decoder(opt); P = bench.fast_params(dec.param_shapes(), 1); dec.set_params(P)

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Times a fixed list of GEMM shapes on the LDS-tiled fp32 kernel (one process per tile setting because the
-STATTN_GEMM_TILE switch is read once).  usage: gemm_ab.py [iters]  -- driven by tools/gemm_ab.sh over tools/_var/*.so"""
+STATTN_GEMM_TILE switch is read once).  usage: gemm_ab.py [iters]  -- driven by tools/probes/gemm_ab.sh over tools/_var/*.so"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 opt = dict(dim=128, dim_word=64, n_words=50, ctxg_dim=128, ctxl_dim=64, ctxm_dim=64, selector=True,
            use_dropout=True, prev2out=True, ctx2out=True)

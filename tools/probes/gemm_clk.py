@@ -1,8 +1,8 @@
 #!/usr/bin/env python
-"""Isolated GEMM launches under the clock-probe build (make PROBES=1 / tools/build_gemm_var.sh probe -DSTATTN_PROBES, STATTN_GEMM_CLK=1):
+"""Isolated GEMM launches under the clock-probe build (make PROBES=1 / tools/probes/build_gemm_var.sh probe -DSTATTN_PROBES, STATTN_GEMM_CLK=1):
 block-0 duration and shader clock per launch, next to the launch time by events.  usage: gemm_clk.py M N K tA tB [M N K tA tB ...]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 opt = dict(dim=128, dim_word=64, n_words=50, ctxg_dim=128, ctxl_dim=64, ctxm_dim=64, selector=True,
            use_dropout=True, prev2out=True, ctx2out=True)

@@ -2,7 +2,7 @@
 """128 x 128 tiles per CU against the rate: 256 / 512 / 768 / 1024 / 1536 / 2048 tiles of K = 4096 (one, two, ... workgroups per CU and round).
 usage: STATTN_GEMM_TILE=22 gemm_fill.py"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 opt = dict(dim=128, dim_word=64, n_words=50, ctxg_dim=128, ctxl_dim=64, ctxm_dim=64, selector=True,
            use_dropout=True, prev2out=True, ctx2out=True)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """One GEMM shape on the LDS-tiled kernel: the target of rocprofv3 --pmc passes.  usage: gemm_one.py M N K [transA transB]"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 opt = dict(dim=128, dim_word=64, n_words=50, ctxg_dim=128, ctxl_dim=64, ctxm_dim=64, selector=True,
            use_dropout=True, prev2out=True, ctx2out=True)

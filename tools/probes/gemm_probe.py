@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Time the LDS-tiled fp32 MFMA GEMM on the shapes the decoder uses (C2 config) -- TFLOP/s per shape."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 
 SHAPES = [  # (name, M, N, K, transA, transB)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """fp32-MFMA GEMM against the split (three-term bf16) GEMM on the decoder's C2 shapes: ms, TFLOP/s of fp32 work."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 from gemm_probe import SHAPES
 

@@ -2,7 +2,7 @@
 """Sweep M (rows) at fixed N, K for the LDS-tiled GEMM: shows how the rate depends on how many output tiles there are
 per resident workgroup.  usage: gemm_sweep.py N K M1 M2 ...   (env STATTN_GEMM_TILE / _NOSK / _SK select variants)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 opt = dict(dim=128, dim_word=64, n_words=50, ctxg_dim=128, ctxl_dim=64, ctxm_dim=64, selector=True,
            use_dropout=True, prev2out=True, ctx2out=True)

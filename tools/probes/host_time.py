@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Host-side enqueue time of forward_train / backward / update at configs[1] (no synchronisation inside the calls):
-how far ahead of the GPU the launching thread runs.  usage (GPU box): python tools/host_time.py"""
+how far ahead of the GPU the launching thread runs.  usage (GPU box): python tools/probes/host_time.py"""
 import sys, time, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench as B
 import stattn

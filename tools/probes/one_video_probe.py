@@ -1,5 +1,5 @@
 import sys, numpy as np
-import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import bench, stattn
 c = bench.CONFIGS["c1"]; opt = bench.make_options(c)
 dec = stattn.Decoder(opt); dec.set_params(bench.fast_params(dec.param_shapes(), 1234))

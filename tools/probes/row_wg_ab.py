@@ -3,7 +3,7 @@
 search with STATTN_NO_ROW_WG=1 (one workgroup per video): tokens, scores and final states must be BIT-equal (the arithmetic is the
 same value for value).  Shapes: configs[0] dimensions with a small vocabulary and the full one, k = 2 .. 8, 1 .. 3 videos, <eos> likely."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 from oracle import stattn_oracle as O
 bad = 0

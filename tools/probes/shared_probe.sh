@@ -1,9 +1,9 @@
 #!/bin/bash
 # A/B builds of spatial_shared_kernel (configs[4] beam search): usage
-#   tools/shared_probe.sh build name1:"-DFOO=1" name2:"-DBAR=2" ...   (here: variants of attn.o linked into tools/_var/libstattn_<name>.so)
-#   tools/shared_probe.sh run                                           (on the GPU box: leg_probe c5 under every variant; restores the product library)
+#   tools/probes/shared_probe.sh build name1:"-DFOO=1" name2:"-DBAR=2" ...   (here: variants of attn.o linked into tools/_var/libstattn_<name>.so)
+#   tools/probes/shared_probe.sh run                                           (on the GPU box: leg_probe c5 under every variant; restores the product library)
 set -e
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 PKG=$ROOT/video-description-with-spatial-temporal-attention_amd
 CS=$PKG/csrc
 VAR=$ROOT/tools/_var
@@ -23,7 +23,7 @@ else
     for so in $VAR/libstattn_*.so; do
         n=$(basename $so .so); n=${n#libstattn_}
         cp $so $PKG/libstattn.so
-        echo "== $n: $(python $ROOT/tools/leg_probe.py c5 2>/dev/null | grep -E 'value|spatial' | tr '\n' ' ')"
+        echo "== $n: $(python $ROOT/tools/probes/leg_probe.py c5 2>/dev/null | grep -E 'value|spatial' | tr '\n' ' ')"
     done
     cp $VAR/_product.so $PKG/libstattn.so
 fi

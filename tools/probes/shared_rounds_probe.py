@@ -3,7 +3,7 @@
 resident workgroups (3 per CU = 768) -- is the 3.33-round grid of 32 videos paying for its last, third-full round?
 usage: shared_rounds_probe.py [nvid ...]   (F is reduced to 512: the projections are not what is measured)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 import bench, stattn
 

@@ -1,8 +1,8 @@
 #!/usr/bin/env python
 """Launch time of the register-streaming 64-column skinny GEMM (the <= 16-row sampler path) per shape.
-(The ablations of round 1 lived in the kernel; the row-panel kernels' are in tools/panel_probe.hip.)"""
+(The ablations of round 1 lived in the kernel; the row-panel kernels' are in tools/probes/panel_probe.hip.)"""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 
 def main():

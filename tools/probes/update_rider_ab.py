@@ -3,7 +3,7 @@
 STATTN_NO_UPDATE_RIDER=1 (update as a launch of its own, attention after the re-ordering): tokens must be equal; prints the rows whose
 final states differ at all (a few ulps: children whose parent sat in another hypothesis slot of the shared-slab attention kernel)."""
 import os, sys, numpy as np
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import stattn
 from oracle import stattn_oracle as O
 dims = dict(dim=1024, dim_word=512, n_words=2000, ctxg_dim=1024, ctxl_dim=512, ctxm_dim=512, ctxglm_dim=1024)

@@ -1,7 +1,7 @@
 #!/bin/bash
 # A/B of whole-library builds on one box: every tools/_var/libstattn_<name>.so is swapped in in turn under <command> (its last lines are shown)
-# usage: tools/var_ab.sh <rounds> <tail lines> <command...>
-ROOT=$(cd "$(dirname "$0")/.." && pwd)
+# usage: tools/probes/var_ab.sh <rounds> <tail lines> <command...>
+ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 PKG=$ROOT/video-description-with-spatial-temporal-attention_amd
 VAR=$ROOT/tools/_var
 rounds=$1; lines=$2; shift 2

@@ -1033,8 +1033,8 @@ def main():
                                                            kind, " + ".join("%dx%dx%d" % x_ for x_ in shapes)),
                                              sum(2.0 * m_ * n_ * k_ for m_, n_, k_ in shapes), ms)
         # the reverse-scan chain (one launch of each per decoder step) and the deferred context-gradient kernel
-        kernels["bwd_spatial"] = hbm("spatial_bwd_kernel (+ temporal backward%s)" % (", + riding dhU = dpre.U^T GEMM" if bwd_rider else ""),
-                                     B * T * D * (4.0 * 3 * K + 4.0 * 9) + (4.0 * 4 * D * D if bwd_rider else 0.0),
+        kernels["bwd_spatial"] = hbm(("spatial_bwd_bf16_kernel" if bf16 and K <= 16 else "spatial_bwd_kernel") + " (+ temporal backward%s)" % (", + riding dhU = dpre.U^T GEMM" if bwd_rider else ""),
+                                     B * T * D * (slab_bytes * 3 * K + 4.0 * 9) + (4.0 * 4 * D * D if bwd_rider else 0.0),
                                      bkms["spatial_bwd"][0], "spatial_bwd")
         if bwd_rider:
             kernels["bwd_panel_dctx"] = mfma("dpre.Wc^T (panel_kernel, K-split; dpre.U^T rides in spatial_bwd)", 2.0 * B * 4 * D * D, bkms["panel_dctx_dhU"][0], 4.0 * D * D * 4)
@@ -1044,7 +1044,7 @@ def main():
         for nm in ("lstm_bwd", "temporal_bwd", "reduce_T"):
             if bkms[nm][1]:                           # (temporal_bwd: fused into spatial_bwd, no launches of its own)
                 kernels["bwd_" + nm] = dict(kernel=nm, bound="latency", ms_per_launch=bkms[nm][0])
-        kernels["bwd_ctxgrad"] = hbm("ctxgrad_kernel", 4.0 * (B * T * K * D * 5.0 + c["t"] * B * T * D * 2.0), bkms["ctxgrad"][0], "ctxgrad")
+        kernels["bwd_ctxgrad"] = hbm("ctxgrad_kernel", B * T * K * D * (2.0 * slab_bytes + 3.0 * 4.0) + 4.0 * c["t"] * B * T * D * 2.0, bkms["ctxgrad"][0], "ctxgrad")
         bwd_step_ms = sum(bkms[k_][0] for k_ in ("lstm_bwd", "panel_dctx_dhU", "temporal_bwd", "spatial_bwd", "reduce_T", "panel_dhW"))
     if args.kernel_breakdown and rank == 0:
         print("kernel classes (avg ms, launches):", dict(kms), file=sys.stderr)

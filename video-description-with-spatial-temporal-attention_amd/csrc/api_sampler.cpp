@@ -402,6 +402,11 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         CHK(getbuf_t(h, "bs_vstats", (size_t)M * vtile * PN_STATS_REC, &vstats));
         so.stats = vstats;
     }
+    // Beams of more than 64 rows: logits on the LDS-tiled GEMM + launch_vocab_stats instead of the wide row-panel kernel with the
+    // statistics epilogue (tools/probes/gemm_small_m.py: 160 x 12 032 x 512 31.5 us, 160 x 20 096 x 512 41 us against ~45 / ~70);
+    // STATTN_TILED_LOGITS=0 restores the epilogue (A/B)
+    static const char* tlg = getenv("STATTN_TILED_LOGITS");
+    const bool tiled_logits = vocab_stats && !small && M > 64 && !stochastic && vtile * 32 == Vp && E % 4 == 0 && !(tlg && tlg[0] == '0');
     if (small) {
         CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
         CHK(getbuf_t(h, "bs_ho_pk", packed_rows_floats(M, D), &ho_pk));
@@ -557,7 +562,14 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
             if (h->opt.prev2out) { sg.add = emb; sg.ldadd = E; }
             sg.act = 1; sg.scale = 0.5f; sg.C = a1; sg.ldc = E; sg.N = E;
             HIPCHK(h, launch_panel(s, a));
-            if (vocab_stats) {
+            if (vocab_stats && tiled_logits && !merge_pg) {
+                // more than 64 rows: the logits on the LDS-tiled GEMM (stored), the statistics records by a kernel of their own
+                GemmArgs g;
+                gemm_defaults(g); g.split = h->opt.precision != 0;
+                g.A = a1; g.lda = E; g.B = w.Wo; g.ldb = Vp; g.C = lg; g.ldc = Vp; g.M = M; g.N = Vp; g.K = E; g.bias = w.bo;
+                HIPCHK(h, launch_gemm(s, g, false, false));
+                HIPCHK(h, launch_vocab_stats(s, lg, Vp, M, V, vtile, k, suppress_eos ? 1 : 0, vstats));
+            } else if (vocab_stats) {
                 HIPCHK(h, launch_panel(s, (merge_pg && !last) ? lgargs_pg : lgargs));
             } else {
                 PnArgs b{};

@@ -150,6 +150,59 @@ hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, 
     hipLaunchKernelGGL(beam_topk_part_kernel, dim3(a.nvid, ns), dim3(256), 0, s, a, ns, part_cost, part_idx);
     return hipGetLastError();
 }
+// Vocabulary statistics from STORED logits (round 5): the records the row-panel kernels' statistics epilogue leaves -- per (row, tile of
+// 32 columns): max, sum exp(v - max), the kb best values and their columns -- for launches whose logits come from the LDS-tiled GEMM
+// (beams of more than 64 rows: 160 x 20 096 x 512 runs 41 us there against ~70 in the wide row-panel kernel, whose 628 workgroups
+// each re-read the 327 KB activation panel from L2).  One lane per (row, tile): a wave covers 64 consecutive tiles of one row.
+__global__ __launch_bounds__(64) void vocab_stats_kernel(const float* __restrict__ lg, int ldl, int M, int V, int ntile, int kb, int skip0,
+                                                         float* __restrict__ stats) {
+    const int row = blockIdx.y, tile = blockIdx.x * 64 + threadIdx.x;
+    if (tile >= ntile) return;
+    const int n0 = tile * 32;
+    const float* p = lg + (size_t)row * ldl + n0;
+    float fv[32];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float4 v = ld4(p + 4 * j);
+        fv[4 * j] = v.x; fv[4 * j + 1] = v.y; fv[4 * j + 2] = v.z; fv[4 * j + 3] = v.w;
+    }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) if (n0 + c >= V || (skip0 && n0 + c == 0)) fv[c] = -INFINITY;
+    float mx = -INFINITY;
+#pragma unroll
+    for (int c = 0; c < 32; ++c) mx = fmaxf(mx, fv[c]);
+    float se = 0.f;
+    float lv[PN_STATS_KB]; int lc[PN_STATS_KB];
+#pragma unroll
+    for (int i = 0; i < PN_STATS_KB; ++i) { lv[i] = -INFINITY; lc[i] = n0; }
+#pragma unroll
+    for (int c = 0; c < 32; ++c) {
+        const float v = fv[c];
+        se += v > -INFINITY ? __expf(v - mx) : 0.f;
+        // branch-free sorted insert, strict >: ties keep the lower column ahead (the order of panelw.hip's epilogue)
+        float cv = v; int cc = n0 + c;
+#pragma unroll
+        for (int i = PN_STATS_KB - 1; i >= 0; --i) {
+            const bool sw = cv > lv[i];
+            if (i < PN_STATS_KB - 1) { lv[i + 1] = sw ? lv[i] : cv; lc[i + 1] = sw ? lc[i] : cc; }
+            cv = sw ? cv : lv[i]; cc = sw ? cc : lc[i];
+            if (i == 0) { lv[0] = cv; lc[0] = cc; }
+        }
+    }
+    float* rec = stats + ((size_t)row * ntile + tile) * PN_STATS_REC;
+    rec[0] = mx; rec[1] = se;
+#pragma unroll
+    for (int i = 0; i < PN_STATS_KB; ++i)
+        if (i < kb) { rec[2 + i] = lv[i]; reinterpret_cast<int*>(rec)[2 + PN_STATS_KB + i] = lc[i]; }
+}
+
+hipError_t launch_vocab_stats(hipStream_t s, const float* lg, int ldl, int M, int V, int ntile, int kb, int skip0, float* stats) {
+    if (M <= 0 || ntile <= 0) return hipSuccess;
+    if (kb < 1 || kb > PN_STATS_KB || ldl % 4 || ntile * 32 > ldl) return hipErrorInvalidValue;
+    hipLaunchKernelGGL(vocab_stats_kernel, dim3((ntile + 63) / 64, M), dim3(64), 0, s, lg, ldl, M, V, ntile, kb, skip0, stats);
+    return hipGetLastError();
+}
+
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx) {
     if (!a.ticket) return hipErrorInvalidValue;
     if (a.stats && (a.ntile < 1 || a.k > PN_STATS_KB || (a.stochastic && (a.k != 1 || a.tile_cols < 1)))) return hipErrorInvalidValue;

@@ -494,6 +494,8 @@ struct BeamArgs {
 int beam_topk_splits(int nvid);
 // part_cost / part_idx: nvid * beam_topk_splits(nvid) * 8 entries of scratch
 hipError_t launch_beam_topk(hipStream_t s, const BeamArgs& a, float* part_cost, int* part_idx);
+// the statistics records of PnSeg::stats (32-column tiles) from stored logits [M][ldl]
+hipError_t launch_vocab_stats(hipStream_t s, const float* lg, int ldl, int M, int V, int ntile, int kb, int skip0, float* stats);
 hipError_t launch_beam_update(hipStream_t s, const BeamArgs& a, const float* part_cost, const int* part_idx);   // also advances *a.step (last workgroup, ticket)
 
 }  // namespace stattn

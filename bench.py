@@ -294,7 +294,7 @@ def leg_decode_c1(args, local):
     return out
 
 
-def leg_eval_msvd(args, local, nvid=None, chunk=32):
+def leg_eval_msvd(args, local, nvid=None, chunk=51):
     """The reference's evaluation workload (metrics.py:121-135: every test video through gen_sample(beam = 5, maxlen = 50); 670 MSVD
     test videos, config.py shapes) on `gen_sample_batch`'s device path: host features handed over in chunks of `chunk` videos
     (staged, F -> D projected and decoded by ONE stattn_beam_search call per chunk), <eos> suppressed so the step count is fixed.
@@ -708,8 +708,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--mode", default="train", choices=["train", "forward", "decode", "beam", "eval"])
     ap.add_argument("--eval-videos", type=int, default=None, help="eval mode: videos of the pass (default: the 670 MSVD test videos)")
-    ap.add_argument("--eval-chunk", type=int, default=32, help="eval mode: videos per stattn_beam_search call (32 = 160 rows: 2074 videos/s "
-                    "against 1447 / 1800 / 2043 / 1986 at 16 / 64 / 96 / 128, round 5)")
+    ap.add_argument("--eval-chunk", type=int, default=51, help="eval mode: videos per stattn_beam_search call (51 = 255 rows, the most the "
+                    "one-row-group wide panel kernels take: 2597 videos/s against 2100 / 2280 / 2183 / 2331 / 2472 at 32 / 36 / 40 / 44 / 48 and "
+                    "1609 at 52, round 5)")
     ap.add_argument("--beam", type=int, default=None, help="beam width k of gen_sample (decode mode default 1 = greedy, beam mode default 5)")
     ap.add_argument("--h2d", default="none", choices=["none", "sync", "prefetch"],
                     help="train mode only: also move the minibatch host->device every step (never the headline value): "

@@ -591,15 +591,15 @@ def test_mid_size_beams_take_the_vocabulary_statistics_path(stattn_mod, O, nvid,
 def test_msvd_eval_shape_batched_beam_search(stattn_mod, O):
     """The reference's evaluation workload at its real shape (metrics.py:121-135 with config.py's options: T = 28 frames, 8
     regions, feat 4096, hidden 1024, E = 512, vocabulary 20 000, beam 5) on the path `bench.py`'s eval_msvd leg measures:
-    gen_sample_batch over a chunk of 32 videos = 160 rows (896 (video, frame) items: the shared-slab attention kernel by the
-    K <= 8 rule of 800 items, the update riding in it, the 160-row wide row-panel GEMMs with the vocabulary statistics).
-    Videos 0 and 1 against the oracle's gen_sample, the others against the product's host-driven loop."""
+    gen_sample_batch over a chunk of 51 videos = 255 rows, the chunk the leg uses (1428 (video, frame) items: the shared-slab attention
+    kernel by the K <= 8 rule of 800 items, the update riding in it, the wide row-panel GEMMs, the logits on the LDS-tiled GEMM with the
+    statistics kernel).  Videos 0 and 1 against the oracle's gen_sample, six more against the product's host-driven loop."""
     dims = dict(dim=1024, dim_word=512, n_words=20000, ctxg_dim=1024, ctxl_dim=4096, ctxm_dim=4096, ctxglm_dim=1024)
     opt = O.default_options(**dims)
     P = O.random_params(opt, seed=29, dtype=np.float32)
     P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 2.0        # some hypotheses end early
     P64 = O.cast_params(P, np.float64)
-    nvid, T, K, k, maxlen = 32, 28, 8, 5, 7
+    nvid, T, K, k, maxlen = 51, 28, 8, 5, 7
     b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=63)
     model = stattn_mod.Attention()
     tparams = model.init_tparams(P)

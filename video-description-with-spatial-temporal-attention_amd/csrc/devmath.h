@@ -26,15 +26,46 @@ __device__ __forceinline__ float fast_tanh(float x) {
 
 __device__ __forceinline__ float fast_sigmoid(float x) { return fast_rcp(1.0f + __expf(-x)); }
 
+// Wave-wide sum / max, result in every lane.  __shfl_xor compiles to ds_bpermute_b32 + s_waitcnt lgkmcnt(0): six DEPENDENT LDS round
+// trips per value, and hipcc does not interleave the chains of independent values (spatial2_kernel: 66 serial bpermutes per item,
+// spatial_bwd_kernel: 144).  STATTN_DPP_REDUCE=1 builds the same reductions from six DPP lane moves on the VALU (quad swaps, half-row
+// and row mirrors, row_bcast 15 / 31: the total forms in lane 63) and one v_readlane -- no LDS, no waits.
+#ifndef STATTN_DPP_REDUCE
+#define STATTN_DPP_REDUCE 0
+#endif
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float dpp_move(float old, float v) {
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(__builtin_bit_cast(int, old), __builtin_bit_cast(int, v), CTRL, ROW_MASK, 0xF, false));
+}
 __device__ __forceinline__ float wave_sum(float v) {
+#if STATTN_DPP_REDUCE
+    v += dpp_move<0xB1, 0xF>(v, v);            // quad_perm:[1,0,3,2]
+    v += dpp_move<0x4E, 0xF>(v, v);            // quad_perm:[2,3,0,1]   every lane: the sum of its quad
+    v += dpp_move<0x141, 0xF>(v, v);           // row_half_mirror       ... of its 8 lanes
+    v += dpp_move<0x140, 0xF>(v, v);           // row_mirror            ... of its row of 16
+    v += dpp_move<0x142, 0xA>(0.f, v);         // row_bcast:15          rows 1, 3 += the row before
+    v += dpp_move<0x143, 0xC>(0.f, v);         // row_bcast:31          rows 2, 3 += lane 31: lane 63 holds all 64
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
+#endif
 }
 __device__ __forceinline__ float wave_max(float v) {
+#if STATTN_DPP_REDUCE
+    v = fmaxf(v, dpp_move<0xB1, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x4E, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x141, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x140, 0xF>(v, v));
+    v = fmaxf(v, dpp_move<0x142, 0xA>(v, v));  // (rows 0, 2 keep their own value)
+    v = fmaxf(v, dpp_move<0x143, 0xC>(v, v));
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), 63));
+#else
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
     return v;
+#endif
 }
 
 // Workgroup -> XCD placement.  Block n of a launch runs on XCD n % 8 (observed dispatch order; each XCD has its own 4 MiB

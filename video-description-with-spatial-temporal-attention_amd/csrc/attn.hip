@@ -1005,9 +1005,9 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
 #define STATTN_COLS_UPD(HH) case HH: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_update_kernel<HH, true>), grid, block, 0, s, a, *upd); \
                                      else hipLaunchKernelGGL((spatial_shared_cols_update_kernel<HH, false>), grid, block, 0, s, a, *upd); break;
                 switch (a.group) {
-                    STATTN_COLS_UPD(2) STATTN_COLS_UPD(3) STATTN_COLS_UPD(4) STATTN_COLS_UPD(5) STATTN_COLS_UPD(6) STATTN_COLS_UPD(7)
-                    default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_update_kernel<8, true>), grid, block, 0, s, a, *upd);
-                             else hipLaunchKernelGGL((spatial_shared_cols_update_kernel<8, false>), grid, block, 0, s, a, *upd); break;
+                    STATTN_COLS_UPD(2) STATTN_COLS_UPD(3) STATTN_COLS_UPD(4) STATTN_COLS_UPD(5)
+                    default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_update_kernel<6, true>), grid, block, 0, s, a, *upd);       // (group <= 6: spatial_shared_cols)
+                             else hipLaunchKernelGGL((spatial_shared_cols_update_kernel<6, false>), grid, block, 0, s, a, *upd); break;
                 }
 #undef STATTN_COLS_UPD
                 return hipGetLastError();
@@ -1045,9 +1045,9 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
 #define STATTN_COLS(HH) case HH: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_kernel<HH, true>), grid, block, 0, s, a); \
                                  else hipLaunchKernelGGL((spatial_shared_cols_kernel<HH, false>), grid, block, 0, s, a); break;
             switch (a.group) {
-                STATTN_COLS(2) STATTN_COLS(3) STATTN_COLS(4) STATTN_COLS(5) STATTN_COLS(6) STATTN_COLS(7)
-                default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_kernel<8, true>), grid, block, 0, s, a);
-                         else hipLaunchKernelGGL((spatial_shared_cols_kernel<8, false>), grid, block, 0, s, a); break;
+                STATTN_COLS(2) STATTN_COLS(3) STATTN_COLS(4) STATTN_COLS(5)
+                default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_kernel<6, true>), grid, block, 0, s, a);       // (group <= 6: spatial_shared_cols)
+                         else hipLaunchKernelGGL((spatial_shared_cols_kernel<6, false>), grid, block, 0, s, a); break;
             }
 #undef STATTN_COLS
             return hipGetLastError();

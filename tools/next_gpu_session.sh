@@ -1,0 +1,60 @@
+#!/bin/bash
+# The A/B runs that were prepared while the GPU pool was closed (round 5), in one gpurun call:
+#   tools/build_variant.sh dpp "-DSTATTN_DPP_REDUCE=1"      (here, before the call: tools/_var travels with the snapshot)
+#   gpurun --timeout 3000 -- tools/next_gpu_session.sh      -> gpurun_out/next_session_report.txt
+# Decides: (1) DPP wave reductions as the default build, (2) spatial_bwd2_kernel (STATTN_BWD2=1|2) as the default reverse attention
+# kernel of configs[1], (3) spatial_shared_cols_kernel (STATTN_SHARED_COLS=1) for K <= 8 beams.  DESIGN.md section 11.
+root=${GRAFT_REPO_ROOT:-/root/repo}
+cd $root
+o=gpurun_out; mkdir -p $o
+rep=$o/next_session_report.txt; : > $rep
+say() { echo "$@" | tee -a $rep; }
+line() { python - "$1" <<'PY' 2>/dev/null
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+except Exception as e:
+    print("  (no bench line: %s)" % e); sys.exit(0)
+k = d.get("kernels", {})
+def ms(n): return "%.1f" % (k[n]["ms_per_launch"] * 1e3) if n in k else "-"
+print("  %.3f ms/step  %.1f k row-steps/s | spatial %s us  bwd_spatial %s us  temporal %s us  ctxgrad %s us | eval videos/s %s  us/word %s" % (
+    d.get("ms_per_step", 0), d.get("value", 0) / 1e3, ms("spatial"), ms("bwd_spatial"), ms("temporal"), ms("bwd_ctxgrad"), d.get("videos_per_s"), d.get("us_per_word")))
+PY
+}
+bench() { tag=$1; shift; "$@" > $o/ns_$tag.json 2> $o/ns_$tag.err; say "$tag:"; line $o/ns_$tag.json | tee -a $rep; }
+T="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split --no-legs --no-live-pmc"
+
+say "== 0. wave_sum / wave_max against a host loop"
+tools/bin/dpp_check0 2>&1 | tail -1 | tee -a $rep
+tools/bin/dpp_check1 2>&1 | tail -1 | tee -a $rep
+
+say "== 1. configs[1] train step: product build, then the DPP build, then spatial_bwd2 under both"
+bench c2_product $T
+bench c2_dpp tools/with_variant.sh dpp $T
+STATTN_BWD2=1 bench c2_bwd2_4wg $T
+STATTN_BWD2=2 bench c2_bwd2_3wg $T
+STATTN_BWD2=1 bench c2_dpp_bwd2_4wg tools/with_variant.sh dpp $T
+STATTN_BWD2=2 bench c2_dpp_bwd2_3wg tools/with_variant.sh dpp $T
+
+say "== 2. parity under the DPP build (whole GPU suite), and of spatial_bwd2 (backward tests, both register budgets)"
+tools/with_variant.sh dpp timeout 2400 python -m pytest tests -m gpu -x -q > $o/ns_tests_dpp.log 2>&1; tail -2 $o/ns_tests_dpp.log | tee -a $rep
+for v in 1 2; do
+    STATTN_BWD2=$v timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_properties.py -m gpu -x -q > $o/ns_tests_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v: $(tail -1 $o/ns_tests_bwd2_$v.log)"
+    STATTN_BWD2=$v tools/with_variant.sh dpp timeout 1200 python -m pytest tests/test_gpu_backward.py -m gpu -x -q > $o/ns_tests_dpp_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v + DPP: $(tail -1 $o/ns_tests_dpp_bwd2_$v.log)"
+done
+
+say "== 3. other configurations under the DPP build"
+bench c4_bf16_product python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
+bench c4_bf16_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
+bench c5_product python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
+bench c5_dpp tools/with_variant.sh dpp python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
+bench eval_product python bench.py --mode eval --no-cpu-baseline
+bench eval_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
+
+say "== 4. column-per-lane shared attention (K <= 8 beams): parity, then the evaluation workload"
+STATTN_SHARED_COLS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q > $o/ns_tests_cols.log 2>&1; say "STATTN_SHARED_COLS=1: $(tail -1 $o/ns_tests_cols.log)"
+STATTN_SHARED_COLS=1 tools/with_variant.sh dpp timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $o/ns_tests_cols_dpp.log 2>&1; say "STATTN_SHARED_COLS=1 + DPP: $(tail -1 $o/ns_tests_cols_dpp.log)"
+STATTN_SHARED_COLS=1 bench eval_cols python bench.py --mode eval --no-cpu-baseline
+STATTN_SHARED_COLS=1 bench eval_cols_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
+STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
+say "== done"

@@ -7,7 +7,9 @@
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out; mkdir -p $o
-rep=$o/next_session_report.txt; : > $rep
+STAGES=${STAGES:-"0 1 2 3 4"}
+rep=$o/next_session_report.txt; : >> $rep
+stage() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 say() { echo "$@" | tee -a $rep; }
 line() { python - "$1" <<'PY' 2>/dev/null
 import json, sys
@@ -24,10 +26,12 @@ PY
 bench() { tag=$1; shift; "$@" > $o/ns_$tag.json 2> $o/ns_$tag.err; say "$tag:"; line $o/ns_$tag.json | tee -a $rep; }
 T="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split --no-legs --no-live-pmc"
 
+if stage 0; then
 say "== 0. wave_sum / wave_max against a host loop"
 tools/bin/dpp_check0 2>&1 | tail -1 | tee -a $rep
 tools/bin/dpp_check1 2>&1 | tail -1 | tee -a $rep
-
+fi
+if stage 1; then
 say "== 1. configs[1] train step: product build, then the DPP build, then spatial_bwd2 under both"
 bench c2_product $T
 bench c2_dpp tools/with_variant.sh dpp $T
@@ -35,14 +39,18 @@ STATTN_BWD2=1 bench c2_bwd2_4wg $T
 STATTN_BWD2=2 bench c2_bwd2_3wg $T
 STATTN_BWD2=1 bench c2_dpp_bwd2_4wg tools/with_variant.sh dpp $T
 STATTN_BWD2=2 bench c2_dpp_bwd2_3wg tools/with_variant.sh dpp $T
-
+bench c2_epi tools/with_variant.sh epi $T
+bench c2_product_again $T
+fi
+if stage 2; then
 say "== 2. parity under the DPP build (whole GPU suite), and of spatial_bwd2 (backward tests, both register budgets)"
 tools/with_variant.sh dpp timeout 2400 python -m pytest tests -m gpu -x -q > $o/ns_tests_dpp.log 2>&1; tail -2 $o/ns_tests_dpp.log | tee -a $rep
 for v in 1 2; do
     STATTN_BWD2=$v timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_properties.py -m gpu -x -q > $o/ns_tests_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v: $(tail -1 $o/ns_tests_bwd2_$v.log)"
     STATTN_BWD2=$v tools/with_variant.sh dpp timeout 1200 python -m pytest tests/test_gpu_backward.py -m gpu -x -q > $o/ns_tests_dpp_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v + DPP: $(tail -1 $o/ns_tests_dpp_bwd2_$v.log)"
 done
-
+fi
+if stage 3; then
 say "== 3. other configurations under the DPP build"
 bench c4_bf16_product python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 bench c4_bf16_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
@@ -50,11 +58,13 @@ bench c5_product python bench.py --mode beam --config c5 --steps 5 --warmup 1 --
 bench c5_dpp tools/with_variant.sh dpp python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
 bench eval_product python bench.py --mode eval --no-cpu-baseline
 bench eval_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-
+fi
+if stage 4; then
 say "== 4. column-per-lane shared attention (K <= 8 beams): parity, then the evaluation workload"
 STATTN_SHARED_COLS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q > $o/ns_tests_cols.log 2>&1; say "STATTN_SHARED_COLS=1: $(tail -1 $o/ns_tests_cols.log)"
 STATTN_SHARED_COLS=1 tools/with_variant.sh dpp timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $o/ns_tests_cols_dpp.log 2>&1; say "STATTN_SHARED_COLS=1 + DPP: $(tail -1 $o/ns_tests_cols_dpp.log)"
 STATTN_SHARED_COLS=1 bench eval_cols python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 bench eval_cols_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-say "== done"
+STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baselinefi
+fi
+say "== done ($STAGES)"

@@ -7,7 +7,7 @@
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out; mkdir -p $o
-STAGES=${STAGES:-"0 1 2 3 4"}
+STAGES=${STAGES:-"0 1 2 3 4 5"}
 rep=$o/next_session_report.txt; : >> $rep
 stage() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 say() { echo "$@" | tee -a $rep; }
@@ -66,5 +66,9 @@ STATTN_SHARED_COLS=1 tools/with_variant.sh dpp timeout 1500 python -m pytest tes
 STATTN_SHARED_COLS=1 bench eval_cols python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 bench eval_cols_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baselinefi
+fi
+if stage 5; then
+say "== 5. trained-like weights (peaked attention, saturating gates, logits of +-10): fp32 / split / bf16 handles against the float64 oracle"
+timeout 1500 python tools/fuzz_parity.py trained 18 777 > $o/ns_fuzz_trained.log 2>&1; tail -1 $o/ns_fuzz_trained.log | tee -a $rep
 fi
 say "== done ($STAGES)"

@@ -23,7 +23,7 @@ print("  %.3f ms/step  %.1f k row-steps/s | spatial %s us  bwd_spatial %s us  te
     d.get("ms_per_step", 0), d.get("value", 0) / 1e3, ms("spatial"), ms("bwd_spatial"), ms("temporal"), ms("bwd_ctxgrad"), d.get("videos_per_s"), d.get("us_per_word")))
 PY
 }
-bench() { tag=$1; shift; "$@" > $o/ns_$tag.json 2> $o/ns_$tag.err; say "$tag:"; line $o/ns_$tag.json | tee -a $rep; }
+bench() { tag=$1; shift; timeout 400 "$@" > $o/ns_$tag.json 2> $o/ns_$tag.err; say "$tag:"; line $o/ns_$tag.json | tee -a $rep; }
 T="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split --no-legs --no-live-pmc"
 
 if stage 0; then

@@ -408,11 +408,10 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
     const size_t MD = (size_t)a.M * D;
     const float sel = a.has_sel ? a.sel[b] : 1.f;
     const size_t ob = (size_t)b * D, o = (size_t)bt * D;        // (uniform; the lane offset is added at the use)
-    float4 dcs, gterm, mterm;
+    const float4 blt4 = ld4u(a.blt, lob), s3 = ld4u(sp + 3 * D, lob), ult = ld4u(a.Ult, lob);
+    float4 dcs;
     float q[8];
     {
-        const float4 pg = ld4u(a.PG + o, lob), pm = ld4u(a.PM + o, lob), s1 = ld4u(sp + D, lob), s2 = ld4u(sp + 2 * D, lob);
-        const float4 ug = ld4u(a.Ug, lob), um = ld4u(a.Um, lob);
         const float4 xc = ld4u(a.csum + ob, lob), xg = ld4u(a.G + o, lob), xm = ld4u(a.Mo + o, lob), xl = ld4u(a.CL + o, lob);
         const float4 x0 = ld4u(a.cparts + ob, lob), x1 = ld4u(a.cparts + MD + ob, lob), x2 = ld4u(a.cparts + 2 * MD + ob, lob);
         // dcsum[b, column] = sel * (readout term + partials of dpre.Wc^T): the first four partials in flight together
@@ -434,9 +433,20 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
 #pragma unroll
             for (int i = 0; i < 8; ++i) q[i] = 0.f;
         }
-        // the de-independent factor of the per-frame dsg / dsm (scaled by de once the reduction has produced it)
-        gterm = mul4(ug, one_minus_sq(tanh4s(pg, s1)));
-        mterm = mul4(um, one_minus_sq(tanh4s(pm, s2)));
+        // (everything of this phase is FINISHED here: left to itself, LLVM sinks each dot product down to the wave reduction that consumes
+        //  it -- behind the requests of the next phase, whose rows then arrive next to operands that are still alive: spills)
+#pragma unroll
+        for (int i = 0; i < 7; ++i) asm volatile("" : "+v"(q[i]));
+    }
+    // plt recomputed (it needs the forward weights and the LW rows only): dplt = dplb * delt once the reduction has produced delt
+    __syncthreads();                                    // s_al
+    float4 dplb;
+    {
+        float4 pl = blt4;
+#pragma unroll
+        for (int kk = 0; kk < KR; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
+        dplb = mul4(ult, one_minus_sq(tanh4s(pl, s3)));
+        asm volatile("" : "+v"(dplb.x), "+v"(dplb.y), "+v"(dplb.z), "+v"(dplb.w));
     }
     // what the spatial part reads, requested before the reduction of the temporal part (and not earlier: with the temporal operands
     // still live the 16 slab rows do not fit the 128-VGPR budget)
@@ -444,7 +454,7 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
     float4 lr[KR];
 #pragma unroll
     for (int kk = 0; kk < KR; ++kk) lr[kk] = ld4u(a.L + slab, ro[kk]);
-    const float4 blt4 = ld4u(a.blt, lob), s3 = ld4u(sp + 3 * D, lob), ult = ld4u(a.Ult, lob);
+    __builtin_amdgcn_sched_barrier(0);
     block_sum<8>(q, s_red, tid, 4);
     if (tid < 192) {
         const int w = tid >> 6, lane = tid & 63;
@@ -465,25 +475,19 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
         a.dselpre[b] = a.has_sel ? q[6] * sel * (1.f - sel) : 0.f;
     }
     __syncthreads();
-    const float alt = a.alt[bt], delt = s_de[2];
-    // per-frame dsg / dsm
-    if (act) {
-        st4u(a.dsgp + o, lob, scale4(gterm, s_de[0]));
-        st4u(a.dsmp + o, lob, scale4(mterm, s_de[1]));
-    }
-    // plt, dplt, d alpha_k
+    __builtin_amdgcn_sched_barrier(0);      // (nothing that consumes the rows in flight may be scheduled above the reduction: it would wait for them there)
+    const float alt = a.alt[bt], delt = s_de[2], deg = s_de[0], dem = s_de[1];
+    // dplt, d alpha_k
     float p[KR];
     float4 dpl;
     {
-        float4 pl = blt4;
-#pragma unroll
-        for (int kk = 0; kk < KR; ++kk) if (kk < K) fma4(pl, s_al[kk], lw[kk]);
-        const float4 th = tanh4s(pl, s3);
-        dpl = scale4(mul4(ult, one_minus_sq(th)), delt);
+        dpl = scale4(dplb, delt);
         if (act) st4u(a.dplt + o, lob, dpl);
         const float4 dcl = scale4(dcs, alt);
 #pragma unroll
         for (int kk = 0; kk < KR; ++kk) p[kk] = act ? dot4(dcl, lr[kk]) + dot4(dpl, lw[kk]) : 0.f;
+#pragma unroll
+        for (int kk = 0; kk < KR; ++kk) asm volatile("" : "+v"(p[kk]));
     }
     // the rows of the last pass, requested before the reduction of this one
     __builtin_amdgcn_sched_barrier(0);
@@ -491,6 +495,10 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
 #pragma unroll
     for (int kk = 0; kk < KR; ++kk) plr[kk] = ld4u(a.PL + slab, ro[kk]);
     const float4 sl = ld4u(sp, lob), ul = ld4u(a.Ul, lob);
+    // ... and the frame scorers' rows (their part, dsg / dsm, comes last: it needs nothing but de of the temporal part)
+    const float4 pg = ld4u(a.PG + o, lob), pm = ld4u(a.PM + o, lob), s1 = ld4u(sp + D, lob), s2 = ld4u(sp + 2 * D, lob);
+    const float4 ug = ld4u(a.Ug, lob), um = ld4u(a.Um, lob);
+    __builtin_amdgcn_sched_barrier(0);
     block_sum<KR>(p, s_red, tid, 4);
     if (tid < KR && tid < K) s_da[tid] = p[tid] + (a.rl ? a.rl[(size_t)bt * K + tid] : 0.f);
     __syncthreads();
@@ -510,6 +518,11 @@ __global__ __launch_bounds__(256, WPS) void spatial_bwd2_kernel(const SpatialBwd
 #pragma unroll
         for (int kk = 0; kk < KR; ++kk) if (kk < K) fma4(acc, s_da[kk], one_minus_sq(tanh4s(plr[kk], sl)));
         if (act) st4u(a.dslp + o, lob, mul4(acc, ul));
+    }
+    // per-frame dsg / dsm
+    if (act) {
+        st4u(a.dsgp + o, lob, scale4(mul4(ug, one_minus_sq(tanh4s(pg, s1))), deg));
+        st4u(a.dsmp + o, lob, scale4(mul4(um, one_minus_sq(tanh4s(pm, s2))), dem));
     }
 }
 

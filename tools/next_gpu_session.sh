@@ -1,7 +1,7 @@
 #!/bin/bash
 # The A/B runs that were prepared while the GPU pool was closed (round 5), in one gpurun call:
 #   tools/build_variant.sh dpp "-DSTATTN_DPP_REDUCE=1"; tools/build_variant.sh epi "-DSTATTN_PN_EPI_ORDER=1" panel.hip;
-#   tools/build_variant.sh wps2 "-DSTATTN_BWD_BF16_WPS16=2" bwd.hip      (here, before the call: tools/_var travels with the snapshot)
+#   tools/build_variant.sh wps2 "-DSTATTN_BWD_BF16_WPS16=2" bwd.hip; tools/build_variant.sh fwdsched "-DSTATTN_BF16_FWD_SCHED=1" attn.hip      (here, before the call: tools/_var travels with the snapshot)
 #   gpurun --timeout 3000 -- tools/next_gpu_session.sh      -> gpurun_out/next_session_report.txt
 # Decides: (1) DPP wave reductions as the default build, (2) spatial_bwd2_kernel (STATTN_BWD2=1|2) as the default reverse attention
 # kernel of configs[1], (3) spatial_shared_cols_kernel (STATTN_SHARED_COLS=1) for K <= 8 beams.  DESIGN.md section 11.
@@ -56,6 +56,7 @@ say "== 3. other configurations under the DPP build"
 bench c4_bf16_product python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 bench c4_bf16_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 bench c4_bf16_wps2 tools/with_variant.sh wps2 python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
+bench c4_bf16_fwdsched tools/with_variant.sh fwdsched python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 STATTN_BF16_V2=1 bench c4_bf16_v2 python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 STATTN_BF16_V2=1 bench c4_bf16_v2_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
 STATTN_BF16_V2=1 timeout 900 python -m pytest tests/test_gpu_bf16.py -m gpu -x -q > $o/ns_tests_bf16v2.log 2>&1; say "STATTN_BF16_V2=1 test_gpu_bf16: $(tail -1 $o/ns_tests_bf16v2.log)"

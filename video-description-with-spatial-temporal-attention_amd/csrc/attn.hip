@@ -369,6 +369,9 @@ __global__ __launch_bounds__(1024) void spatial_small_update_wide_kernel(const S
     spatial_small_body(a);
 }
 
+#ifndef STATTN_BF16_FWD_SCHED
+#define STATTN_BF16_FWD_SCHED 0
+#endif
 template <int NT>
 __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
     constexpr int NW = NT / 64;
@@ -402,6 +405,9 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
             for (int kk = 0; kk < 8; ++kk) x[kk] = ld16(PL + (size_t)min(k0 + kk, K - 1) * D + 8 * d8);
             const float4 s0 = ld4(sl + 8 * d8), s1 = ld4(sl + 8 * d8 + 4);
             const float4 u0 = ld4(a.Ul + 8 * d8), u1 = ld4(a.Ul + 8 * d8 + 4);
+#if STATTN_BF16_FWD_SCHED
+            __builtin_amdgcn_sched_barrier(0);      // (probe build `fwdsched`: every row of the group requested before the first use -- see spatial_bf16v2_kernel)
+#endif
 #pragma unroll
             for (int kk = 0; kk < 8; ++kk) {
                 float f[8];

@@ -40,7 +40,6 @@ STATTN_BWD2=1 bench c2_bwd2_4wg $T
 STATTN_BWD2=2 bench c2_bwd2_3wg $T
 STATTN_BWD2=1 bench c2_dpp_bwd2_4wg tools/with_variant.sh dpp $T
 STATTN_BWD2=2 bench c2_dpp_bwd2_3wg tools/with_variant.sh dpp $T
-bench c2_epi tools/with_variant.sh epi $T
 bench c2_product_again $T
 fi
 if stage 2; then
@@ -72,7 +71,7 @@ STATTN_SHARED_COLS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py test
 STATTN_SHARED_COLS=1 tools/with_variant.sh dpp timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $o/ns_tests_cols_dpp.log 2>&1; say "STATTN_SHARED_COLS=1 + DPP: $(tail -1 $o/ns_tests_cols_dpp.log)"
 STATTN_SHARED_COLS=1 bench eval_cols python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 bench eval_cols_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baselinefi
+STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
 fi
 if stage 5; then
 say "== 5. trained-like weights (peaked attention, saturating gates, logits of +-10): fp32 / split / bf16 handles against the float64 oracle"

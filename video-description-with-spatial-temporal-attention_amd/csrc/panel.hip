@@ -42,9 +42,6 @@ namespace {
 // a load inside `if (bias)` keeps its branch and hipcc puts a full s_waitcnt behind it -- every optional operand was a dependent
 // L2 round trip of its own, in the tail (or, for the LSTM kernel's "early" requests, in front) of a 5 - 12 us launch.
 __device__ const float pn_zero = 0.f, pn_one = 1.f;
-#ifndef STATTN_PN_EPI_ORDER
-#define STATTN_PN_EPI_ORDER 0           // probe builds (tools/build_variant.sh): see lstm_panel_kernel
-#endif
 
 // ---- general grouped GEMM with fused epilogue ------------------------------------------------------------
 template <int MT, int NT, int MAXT, int R, bool ONESHOT>
@@ -231,43 +228,26 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
         e.d1 = pd1[((size_t)row * a.ldd1 + d) * sd1];
         return e;
     };
-#if !STATTN_PN_EPI_ORDER
     const EpiIn e0 = epi_load(min(tid, RB * 4 - 1));
-#endif
     f32x4 acc[MT][1];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
-    struct Bases { const float* Ap[MT]; const float* Bp; int astep, nsteps; size_t tile_floats; };
-    auto bases = [&](int p) {
+    for (int p = 0; p < a.npairs; ++p) {
         const PnPair& pr = a.p[p];
-        Bases q;
+        const float* Ap[MT];
 #pragma unroll
         for (int i = 0; i < MT; ++i) {
             const int row = min((mg * MT + i) * 16 + j, a.M - 1);
             // packed activations (pn_pack_offset): one coalesced 1 KiB run per m-tile and k-step, like the weights
             // (a row group may reach past the last m-tile: clamped like the rows, those accumulators are never stored)
-            q.Ap[i] = pr.apk ? pr.A + ((size_t)min(mg * MT + i, (a.M - 1) >> 4) * (pr.K >> 4)) * 256 + 4 * lane
-                             : pr.A + (size_t)row * pr.lda + 4 * g;
+            Ap[i] = pr.apk ? pr.A + ((size_t)min(mg * MT + i, (a.M - 1) >> 4) * (pr.K >> 4)) * 256 + 4 * lane
+                           : pr.A + (size_t)row * pr.lda + 4 * g;
         }
-        q.astep = pr.apk ? 256 : 16;
-        q.nsteps = pr.K >> 4;
-        q.tile_floats = (size_t)q.nsteps * 256;
-        q.Bp = pr.P + (size_t)c * q.tile_floats + 4 * lane;
-        return q;
-    };
-#if STATTN_PN_EPI_ORDER
-    // probe build: the operand addresses of the first pair are formed BEFORE the early epilogue requests -- formed after them, their
-    // temporaries re-use registers that pending loads still target and hipcc puts s_waitcnt vmcnt(0) in front of the main loop's own
-    // first loads (ISA, round 5: the early requests were an exposed round trip, not a hidden one)
-    const Bases q0 = bases(0);
-    const EpiIn e0 = epi_load(min(tid, RB * 4 - 1));
-    pn_accumulate<MT, 1, R, ONESHOT>(acc, q0.Ap, q0.astep, q0.Bp, q0.tile_floats, q0.nsteps, ks, KS, pn_rotation(c, q0.nsteps));
-    for (int p = 1; p < a.npairs; ++p) {
-#else
-    for (int p = 0; p < a.npairs; ++p) {
-#endif
-        const Bases q = bases(p);
-        pn_accumulate<MT, 1, R, ONESHOT>(acc, q.Ap, q.astep, q.Bp, q.tile_floats, q.nsteps, ks, KS, pn_rotation(c, q.nsteps));
+        const int astep = pr.apk ? 256 : 16;
+        const int nsteps = pr.K >> 4;
+        const size_t tile_floats = (size_t)nsteps * 256;
+        pn_accumulate<MT, 1, R, ONESHOT>(acc, Ap, astep, pr.P + (size_t)c * tile_floats + 4 * lane, tile_floats, nsteps, ks, KS,
+                                         pn_rotation(c, nsteps));
     }
     PN_STAMP(1);
     pn_spill<MT, 1>(red, RB, ks, mg, acc, j, g);

@@ -147,7 +147,7 @@ int stattn_dbg_time_gemm(stattn_handle* h, int transA, int transB, int M, int N,
     hipEvent_t a, b;
     HIPCHK(h, hipEventCreate(&a)); HIPCHK(h, hipEventCreate(&b));
     float ms = 0.f;
-    static const char* cold = getenv("STATTN_DBG_COLD");   // tools: every timed launch behind a 1 GB fill (operands out of L2 and the Infinity Cache, dirty lines in both)
+    static const char* cold = sw_tool("STATTN_DBG_COLD");   // tools: every timed launch behind a 1 GB fill (operands out of L2 and the Infinity Cache, dirty lines in both)
     if (cold) {
         float* scr;
         CHK(getbuf_t(h, "dbg_cold", (size_t)256 << 20, &scr));

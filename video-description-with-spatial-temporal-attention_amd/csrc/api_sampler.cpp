@@ -353,7 +353,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // row-panel launch (both only need the new h; the projections are linear in h, so beam_update gathers their rows
     // with the hypotheses instead of recomputing them), logits with the vocabulary statistics in the epilogue (tile
     // max / sum-exp / best candidates: no logits or probabilities are stored, no softmax or top-k launch), update.
-    static const char* nosmall = getenv("STATTN_BEAM_NOSMALL");       // A/B switch for tools
+    static const char* nosmall = sw_tool("STATTN_BEAM_NOSMALL");       // A/B switch for tools
     const bool small = panels && M <= 16 && h->opt.precision != 1 && (!nosmall || stochastic);
     if (stochastic && !small) return fail(h, STATTN_EINVAL, "sample_search: needs the row-panel path (at most 16 rows, dim / dim_word multiples of 16)");
     unsigned long long* d_seed = nullptr;
@@ -375,7 +375,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // (`--mode beam --config c1 --beam 5`, 20 rows: 205-207 k -> 212 k row-steps/s).  Round 4 tried this by other means and one
     // parity case died with a memory access fault that was never reproduced: with THIS switch the whole GPU suite and 300 random beams
     // (fuzz_parity: 17 .. 64-row grids among them) run clean; STATTN_WIDE_STATS_FROM=65 restores the stored logits.
-    static const char* wsf = getenv("STATTN_WIDE_STATS_FROM");
+    static const char* wsf = sw_product("STATTN_WIDE_STATS_FROM");
     const int wide_stats_from = wsf ? atoi(wsf) : 17;
     if (panels && !vocab_stats && !stochastic && h->opt.precision != 1) {
         PnArgs probe{};
@@ -391,7 +391,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
         // survives from word to word.  The vocabulary matrix is more than half of it: loaded with the non-temporal policy it no
         // longer displaces the rest, which then hits L2 in the other launches of the next word (configs[0]: 48.0 -> 45.5 us per
         // word).  STATTN_LOGITS_NT=0: default policy (A/B).  (Non-temporal loads on EVERY weight stream were slower: DESIGN.md.)
-        { static const char* ntl = getenv("STATTN_LOGITS_NT"); lgargs.stream_b = (small && !(ntl && ntl[0] == '0')) ? 1 : 0; }
+        { static const char* ntl = sw_tool("STATTN_LOGITS_NT"); lgargs.stream_b = (small && !(ntl && ntl[0] == '0')) ? 1 : 0; }
         PnSeg& so = lgargs.seg[0];
         pn_seg_defaults(so);
         so.npairs = 1; so.p[0] = PnPair{a1_pk, E, pn.Wo, E, 1};
@@ -405,7 +405,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // Beams of more than 64 rows: logits on the LDS-tiled GEMM + launch_vocab_stats instead of the wide row-panel kernel with the
     // statistics epilogue (tools/probes/gemm_small_m.py: 160 x 12 032 x 512 31.5 us, 160 x 20 096 x 512 41 us against ~45 / ~70);
     // STATTN_TILED_LOGITS=0 restores the epilogue (A/B)
-    static const char* tlg = getenv("STATTN_TILED_LOGITS");
+    static const char* tlg = sw_tool("STATTN_TILED_LOGITS");
     const bool tiled_logits = vocab_stats && !small && M > 64 && !stochastic && vtile * 32 == Vp && E % 4 == 0 && !(tlg && tlg[0] == '0');
     if (small) {
         CHK(getbuf_t(h, "bs_proj", (size_t)M * 8 * D, &proj)); CHK(getbuf_t(h, "bs_proj_step", (size_t)M * 8 * D, &proj_step));
@@ -422,7 +422,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // On the small path (at most 16 rows) the readout launch already leaves the projections of the new h before the re-ordering
     // (`proj_step`): the same order of launches, the attention reading them there.
     if (panels && vocab_stats && !stochastic && k > 1) {
-        const char* noride = getenv("STATTN_NO_UPDATE_RIDER");
+        const char* noride = sw_product("STATTN_NO_UPDATE_RIDER");
         SpatialArgs probe{};
         probe.M = M; probe.T = T; probe.K = K; probe.D = D; probe.group = k;
         const bool hu_rider = !small && M <= 64 && spatial_rider_supported(probe);       // (run_step would let the attention launch carry h.U instead)
@@ -438,7 +438,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     PnArgs lgargs_pg{};
     bool merge_pg = false;
     if (pre && !small) {
-        const char* mpg = getenv("STATTN_MERGE_PG");
+        const char* mpg = sw_tool("STATTN_MERGE_PG");
         merge_pg = mpg && mpg[0] == '1';
         if (merge_pg) {
             lgargs_pg.M = M; lgargs_pg.nseg = 3; lgargs_pg.plain_order = 1;
@@ -456,7 +456,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     CHK(getbuf_t(h, "bs_ticket", (size_t)1, &d_ticket));
     // Beams of 2 .. 8 hypotheses on the small path: k update workgroups per video (beam_inl.h, "row workgroups"); STATTN_NO_ROW_WG=1: one (A/B)
     float* rw_cost = nullptr; int *rw_idx = nullptr, *rw_ticket = nullptr;
-    if (small && vocab_stats && !stochastic && k > 1 && !getenv("STATTN_NO_ROW_WG")) {
+    if (small && vocab_stats && !stochastic && k > 1 && !sw_product("STATTN_NO_ROW_WG")) {
         CHK(getbuf_t(h, "bs_rw_cost", (size_t)M * 8, &rw_cost)); CHK(getbuf_t(h, "bs_rw_idx", (size_t)M * 8, &rw_idx));
         CHK(getbuf_t(h, "bs_rw_ticket", (size_t)nvid, &rw_ticket));
         HIPCHK(h, hipMemsetAsync(rw_ticket, 0, (size_t)nvid * sizeof(int), s));
@@ -499,7 +499,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // The attention behind the last word is computed for nothing.  STATTN_NO_UPDATE_RIDER=1: the six-launch word (A/B, tests).
     bool ride = pre;
     if (direct) {
-        const char* noride = getenv("STATTN_NO_UPDATE_RIDER");        // (read on every call: tests switch it inside one process)
+        const char* noride = sw_product("STATTN_NO_UPDATE_RIDER");        // (read on every call: tests switch it inside one process)
         SpatialArgs probe{};
         probe.M = M; probe.T = T; probe.K = K; probe.D = D; probe.group = k;
         ride = !noride && spatial_update_supported(probe);
@@ -645,7 +645,7 @@ static int beam_search_impl(stattn_handle* h, int nvid, const float* ctxg, const
     // bulk and the short one the remainder; the host only comes back every 8 words to see whether every video has finished.  Falls back to eager launches if
     // the capture is refused (or STATTN_BEAM_NOGRAPH is set, for A/B runs).
     hipGraphExec_t gexec = nullptr;
-    static const char* nograph = getenv("STATTN_BEAM_NOGRAPH");
+    static const char* nograph = sw_product("STATTN_BEAM_NOGRAPH");
     h->beam_graph_replays = 0;
     // everything a captured launch bakes in: shapes, options and every buffer the word sequence touches
     std::vector<uintptr_t> sig = {(uintptr_t)nvid, (uintptr_t)k, (uintptr_t)T, (uintptr_t)K, (uintptr_t)L0, (uintptr_t)suppress_eos, (uintptr_t)stochastic, (uintptr_t)d_seed, (uintptr_t)ride, (uintptr_t)pre, (uintptr_t)merge_pg, (uintptr_t)rowmap, (uintptr_t)preh_step,

@@ -247,7 +247,7 @@ int stattn_forward_train(stattn_handle* h) {
         CHK(getbuf_t(h, "bx_ctx", R * D, &bctx));
         CHK(getbuf_t(h, "bx_a1", R * E, &ba1));
         GemmBfArgs g;
-        static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools
+        static const char* nopair = sw_product("STATTN_READOUT_NOPAIR");       // A/B switch for tools
         if (h->opt.ctx2out && bw.Wl12 && !nopair) {
             // a = tanh((h*d1).Wl1 + ctx.Wl2 + bl1 + bl2 [+ emb]) * d2 as ONE K-concatenated problem: [hd | ctx] rounded into one
             // [R][2 D] operand, [Wl1 ; Wl2] in rows of 2 D (z1 is never formed)
@@ -282,7 +282,7 @@ int stattn_forward_train(stattn_handle* h) {
     } else {
         Prof pr_(h, KC_READOUT);
         GemmArgs g;
-        static const char* nopair = getenv("STATTN_READOUT_NOPAIR");       // A/B switch for tools
+        static const char* nopair = sw_product("STATTN_READOUT_NOPAIR");       // A/B switch for tools
         const bool pair = h->opt.ctx2out && h->opt.precision == 0 && D % 32 == 0 && !nopair;
         if (pair) {
             // a = tanh((h*d1).Wl1 + ctx.Wl2 + bl1 + bl2 [+ emb]) * d2 as ONE K-concatenated GEMM (K = 2 D): the two 240-tile

@@ -467,174 +467,9 @@ __global__ __launch_bounds__(NT) void spatial_bf16_kernel(const SpatialArgs a) {
     if (tid == 0) a.elt[bt] = pe[0] + clt0;
 }
 
-// Wave sums of N per-thread values -> s_red, and the workgroup total of value `tid` in thread tid < N (the only threads that use
-// one: a register array indexed by tid is a scratch array).  Same summation order as block_sum_w.  The caller puts a barrier
-// between the last read of a total and the next use of s_red.
-template <int N, int NW>
-__device__ __forceinline__ float block_sum_keep(const float (&v)[N], float* s_red /*[NW][N]*/, int tid) {
-    const int lane = tid & 63, w = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < N; ++i) {
-        const float r = wave_sum(v[i]);
-        if (lane == 0) s_red[w * N + i] = r;
-    }
-    __syncthreads();
-    float t = 0.f;
-    if (tid < N) {
-#pragma unroll
-        for (int q = 0; q < NW; ++q) t += s_red[q * N + tid];
-    }
-    return t;
-}
-
-// ---- the same item for K <= 16 regions and D <= 1024 (BASELINE configs[3]), written against what hipcc made of spatial_bf16_kernel
-// (ISA, round 5): its score loop requests five of a group's eight rows, then the other three ONE AT A TIME behind a full wait each, the
-// frame scorers' operands behind the region scores and the weighted sums four regions at a time -- about eighteen dependent memory round
-// trips per item at K = 16, which is what its 68 us (4.1 TB/s) at configs[3] are made of.  Here a lane owns one 8-column group and
-// every phase's rows are requested together and BEFORE the reduction / softmax in front of the phase:
-//     top:                        the first eight PL rows + the region scorer's operands; behind them the frame scorers' operands
-//     before the first reduction:  the second eight PL rows (K > 8)
-//     before the last reduction:   the first eight L and LW rows
-//     after the softmax:           the second eight L and LW rows (K > 8), before the first eight are consumed
-// Four exposed round trips (two for K <= 8).  K > 8: two waves per SIMD (the two times sixteen packed rows of the weighted sums are 128
-// VGPRs; inside 168 hipcc spills them one row at a time with a full wait each), four workgroups per CU with up to 32 KB in flight each.  Same arithmetic in the same order as spatial_bf16_kernel (the weights of the regions
-// past K are zero instead of skipped).  STATTN_BF16_V2=1 selects it: written while the GPU pool was closed, unmeasured.
-template <int NT, bool TWO>         // TWO: 8 < K <= 16
-__global__ __launch_bounds__(NT, TWO ? 2 : 3) void spatial_bf16v2_kernel(const SpatialArgs a) {
-    constexpr int NW = NT / 64;
-    __shared__ float s_red[NW * 10];
-    __shared__ float s_e[16];
-    if ((int)blockIdx.x < a.rider.nblocks) {
-        __shared__ __attribute__((aligned(16))) float s_rider[NW * 64 * 16];
-        rider_tile<NW>(a.rider, (int)blockIdx.x, s_rider);
-        return;
-    }
-    const int T = a.T, K = a.K, D = a.D;
-    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt[0];
-    // (integer division runs on the VALU: without readfirstlane the uniform item index -- and every row pointer formed from it -- lives in VGPRs)
-    const int bt = __builtin_amdgcn_readfirstlane(xcd_rows((int)blockIdx.x - a.rider.nblocks, a.M, T));
-    const int b = __builtin_amdgcn_readfirstlane(bt / T), t = bt - b * T;
-    const int v = a.vid ? a.vid[b] : b;
-    const int tid = threadIdx.x;
-    const int nd8 = D >> 3, d8 = min(tid, nd8 - 1);
-    const bool on = tid < nd8;                         // (D < 8 NT: the lanes past D / 8 load a clamped column group and contribute nothing)
-    const float onf = on ? 1.f : 0.f;                  // (a factor, not a branch: `on ? f(x) : 0` became a branch with its own waits per region)
-    // every address = a workgroup-uniform row pointer (SGPR pair) + ONE 32-bit lane byte offset: a 64-bit address per lane costs two VGPRs
-    // per load in flight, and up to 32 loads are in flight here
-    const size_t slab = ((size_t)v * T + t) * K * D;
-    const uint16_t* __restrict__ PL = reinterpret_cast<const uint16_t*>(a.PL) + slab;
-    const uint16_t* __restrict__ L = reinterpret_cast<const uint16_t*>(a.L) + slab;
-    const uint16_t* __restrict__ LW = reinterpret_cast<const uint16_t*>(a.LW) + slab;
-    const unsigned lo2 = 16u * (unsigned)d8, lo4 = 32u * (unsigned)d8;     // byte offset of the lane's 8 columns in a bf16 / an fp32 row
-    const float* __restrict__ sl = a.sproj + (size_t)b * a.ldsp;
-    const size_t fo = ((size_t)v * T + t) * D;
-    auto ldr = [&](const uint16_t* base, int row) {      // the lane's 8 bf16 of row `row` (uniform) of a slab
-        return *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(base + (size_t)row * D) + lo2);
-    };
-    auto ldf = [&](const float* base, int half) {        // the lane's columns 4 half .. 4 half + 3 of an fp32 row
-        return *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(base) + lo4 + 16u * half);
-    };
-
-    uint4 x[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) x[kk] = ldr(PL, min(kk, K - 1));
-    const float4 s0 = ldf(sl, 0), s1 = ldf(sl, 1);
-    const float4 u0 = ldf(a.Ul, 0), u1 = ldf(a.Ul, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    // frame scorers (PG / PM stay fp32: they are K times smaller): in flight under the region scores
-    const float4 pg0 = ldf(a.PG + fo, 0), pg1 = ldf(a.PG + fo, 1), sg0 = ldf(sl + D, 0), sg1 = ldf(sl + D, 1);
-    const float4 ug0 = ldf(a.Ug, 0), ug1 = ldf(a.Ug, 1);
-    const float4 pm0 = ldf(a.PM + fo, 0), pm1 = ldf(a.PM + fo, 1), sm0 = ldf(sl + 2 * D, 0), sm1 = ldf(sl + 2 * D, 1);
-    const float4 um0 = ldf(a.Um, 0), um1 = ldf(a.Um, 1);
-    __builtin_amdgcn_sched_barrier(0);
-    auto score = [&](const uint4 r) {
-        float f[8];
-        bf8_to_f32(r, f);
-        return onf * (dot4_tanh(make_float4(f[0], f[1], f[2], f[3]), s0, u0) + dot4_tanh(make_float4(f[4], f[5], f[6], f[7]), s1, u1));
-    };
-    float p[10];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) p[kk] = score(x[kk]);
-    p[8] = onf * (dot4_tanh(pg0, sg0, ug0) + dot4_tanh(pg1, sg1, ug1));
-    p[9] = onf * (dot4_tanh(pm0, sm0, um0) + dot4_tanh(pm1, sm1, um1));
-    __builtin_amdgcn_sched_barrier(0);
-    // in flight under the first reduction: the second eight PL rows (TWO), or already the rows of the weighted sums
-    uint4 y[8], l0[8], lw[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        if (TWO) y[kk] = ldr(PL, min(8 + kk, K - 1));
-        else { l0[kk] = ldr(L, min(kk, K - 1)); lw[kk] = ldr(LW, min(kk, K - 1)); }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    {
-        const float tot = block_sum_keep<10, NW>(p, s_red, tid);
-        if (tid < 8 && tid < K) s_e[tid] = tot + cl0;
-        if (tid == 8) a.eg[bt] = tot + cg0;
-        if (tid == 9) a.em[bt] = tot + cm0;
-    }
-    if (TWO) {
-        float p2[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) p2[kk] = score(y[kk]);
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) { l0[kk] = ldr(L, kk); lw[kk] = ldr(LW, kk); }      // (K > 8: rows 0 .. 7 exist)
-        __builtin_amdgcn_sched_barrier(0);
-        __syncthreads();                               // every total of the first reduction has been read
-        const float tot = block_sum_keep<8, NW>(p2, s_red, tid);
-        if (tid < 8 && 8 + tid < K) s_e[8 + tid] = tot + cl0;
-    }
-    __syncthreads();
-
-    float mx = -INFINITY;
-    for (int k = 0; k < K; ++k) mx = fmaxf(mx, s_e[k]);
-    float sum = 0.f;
-    for (int k = 0; k < K; ++k) sum += __expf(s_e[k] - mx);
-    const float inv = 1.0f / sum;
-    __syncthreads();
-    if (tid < 16) {
-        const float al = tid < K ? __expf(s_e[tid] - mx) * inv : 0.f;      // (zero weights for the clamped rows past K)
-        if (tid < K) a.alphal[(size_t)bt * K + tid] = al;
-        s_e[tid] = al;
-    }
-    __syncthreads();
-
-    float c[8], w[8];
-#pragma unroll
-    for (int q = 0; q < 8; ++q) { c[q] = 0.f; w[q] = 0.f; }
-    auto wsum = [&](const uint4 lr, const uint4 qr, const float al) {
-        float f[8], q8[8];
-        bf8_to_f32(lr, f);
-        bf8_to_f32(qr, q8);
-#pragma unroll
-        for (int q = 0; q < 8; ++q) { c[q] += al * f[q]; w[q] += al * q8[q]; }
-    };
-    if (TWO) {      // the second eight rows of both tensors, requested before the first eight are consumed
-        uint4 l1[8], q1[8];
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) { l1[kk] = ldr(L, min(8 + kk, K - 1)); q1[kk] = ldr(LW, min(8 + kk, K - 1)); }
-        __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) wsum(l0[kk], lw[kk], s_e[kk]);
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) wsum(l1[kk], q1[kk], s_e[8 + kk]);
-    } else {
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) wsum(l0[kk], lw[kk], s_e[kk]);
-    }
-    // the local-temporal scorer's operands (all lanes: clamped column group, weight onf)
-    const float4 b0 = ldf(a.blt, 0), b1 = ldf(a.blt, 1);
-    if (on) {
-        float* cl = reinterpret_cast<float*>(reinterpret_cast<char*>(a.CL + (size_t)bt * D) + lo4);
-        st4(cl, make_float4(c[0], c[1], c[2], c[3]));
-        st4(cl + 4, make_float4(c[4], c[5], c[6], c[7]));
-    }
-    float pe[1];
-    pe[0] = onf * (dot4_tanh(make_float4(w[0] + b0.x, w[1] + b0.y, w[2] + b0.z, w[3] + b0.w), ldf(sl + 3 * D, 0), ldf(a.Ult, 0)) +
-                   dot4_tanh(make_float4(w[4] + b1.x, w[5] + b1.y, w[6] + b1.z, w[7] + b1.w), ldf(sl + 3 * D, 1), ldf(a.Ult, 1)));
-    const float tot = block_sum_keep<1, NW>(pe, s_red, tid);
-    if (tid == 0) a.elt[bt] = tot + clt0;
-}
+#if STATTN_EXPERIMENTAL
+#include "experimental/attn_bf16v2.inl"       // spatial_bf16v2_kernel: unmeasured, never in the product build
+#endif
 
 // ---- beam-search variant: the H hypotheses of a video (rows v*H .. v*H+H-1) attend to the SAME region tensors, so
 // one workgroup per (video, frame) streams each K x D slab ONCE and applies it to all H state projections:
@@ -839,161 +674,9 @@ __global__ __launch_bounds__(256, 3) void spatial_shared_update_kernel(const Spa
     spatial_shared_body<H>(a, (int)blockIdx.x - u.nvid);
 }
 
-// ---- the same for K <= 8 regions and D <= 1024: the reference's own evaluation shape (config.py: 8 regions, hidden 1024, beam 5).
-// There spatial_shared_body leaves three of its four waves without a region to score (a wave owns EIGHT regions) and walks a slab in
-// four dependent bursts of 8 KB: 92 us per word for 137 MB at 51 videos x 28 frames (0.25 of HBM).  Here a lane owns ONE float4 column of
-// the item and requests its 8 rows of PL, L and LW, the two frame rows and the H hypotheses' state projections before the first
-// wait -- one memory round trip per item, 104 KB in flight per workgroup, all four waves on the H x K x 4 reciprocals -- and the
-// H (K + 2) + 1 partial sums cross the workgroup in one LDS hop.  Two workgroups per CU (the 24 slab rows alone are 96 VGPRs).
-#ifndef STATTN_COLS_ABL
-#define STATTN_COLS_ABL 0     // probe builds (tools/probes/cols_probe.sh): 1 scores without transcendentals, 2 no slab loads, 3 no CL stores
+#if STATTN_EXPERIMENTAL
+#include "experimental/attn_shared_cols.inl"   // spatial_shared_cols_kernel: unmeasured, never in the product build
 #endif
-template <int H, bool HAS_LW>
-__device__ __forceinline__ void spatial_shared_cols_body(const SpatialArgs& a, const int vt) {
-    constexpr int NV = H * 8 + 2 * H + 1;            // region scores, frame scores, sum of Ul
-    __shared__ float s_red[4 * NV];
-    __shared__ float s_al[H * 8];
-    const int T = a.T, K = a.K, D = a.D;
-    const float cl0 = a.cl[0], cg0 = a.cg[0], cm0 = a.cm[0], clt0 = a.clt ? a.clt[0] : 0.f;
-    const int v = vt / T, t = vt % T;
-    const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
-    const int nd4 = D >> 2, d4 = min(tid, nd4 - 1);
-    const float on = tid < nd4 ? 1.f : 0.f;           // lanes past D / 4 load a clamped column and contribute zeros
-    const size_t slab = ((size_t)v * T + t) * K * D + 4 * d4, fo = ((size_t)v * T + t) * D + 4 * d4;
-    const int b0 = v * H;                             // first row (hypothesis) of this video
-
-    float4 x[8], l[8], q[8];
-#pragma unroll
-    for (int kk = 0; kk < 8; ++kk) {
-        const size_t o = slab + (size_t)min(kk, K - 1) * D;
-#if STATTN_COLS_ABL == 2
-        x[kk] = make_float4(1e-3f * tid, 1e-3f * kk, 0.1f, 0.2f); l[kk] = x[kk]; q[kk] = x[kk];
-#else
-        x[kk] = ld4_nt(a.PL + o);
-        l[kk] = ld4_nt(a.L + o);
-        q[kk] = HAS_LW ? ld4_nt(a.LW + o) : make_float4(0.f, 0.f, 0.f, 0.f);
-#endif
-    }
-    const float4 pg = ld4(a.PG + fo), pm = ld4(a.PM + fo);
-    float4 s0[H], s1[H], s2[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        const float* sp = a.sproj + (size_t)(b0 + h) * a.ldsp + 4 * d4;
-        s0[h] = ld4(sp); s1[h] = ld4(sp + D); s2[h] = ld4(sp + 2 * D);
-    }
-    const float4 u4 = ld4(a.Ul + 4 * d4), ug = ld4(a.Ug + 4 * d4), um = ld4(a.Um + 4 * d4);
-
-    // ---- scores (tanh split along its sum as in spatial_shared_body: one v_exp per slab element and per state projection element,
-    // one v_rcp per (hypothesis, region, column))
-    float r[NV];
-    {
-        const float4 m2u = make_float4(-2.f * on * u4.x, -2.f * on * u4.y, -2.f * on * u4.z, -2.f * on * u4.w);
-#if STATTN_COLS_ABL != 1
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) x[kk] = exp2x4(x[kk]);
-#endif
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-#if STATTN_COLS_ABL == 1
-            const float4 es = s0[h];
-#else
-            const float4 es = exp2x4(s0[h]);
-#endif
-#pragma unroll
-            for (int kk = 0; kk < 8; ++kk) {
-#if STATTN_COLS_ABL == 1
-                const float4 rc = make_float4(x[kk].x + es.x, x[kk].y + es.y, x[kk].z + es.z, x[kk].w + es.w);
-#else
-                const float4 rc = rcp1p4(x[kk], es);
-#endif
-                r[h * 8 + kk] = (m2u.x * rc.x + m2u.y * rc.y) + (m2u.z * rc.z + m2u.w * rc.w);
-            }
-            r[H * 8 + 2 * h] = on * dot4_tanh(pg, s1[h], ug);
-            r[H * 8 + 2 * h + 1] = on * dot4_tanh(pm, s2[h], um);
-        }
-        r[NV - 1] = on * ((u4.x + u4.y) + (u4.z + u4.w));
-    }
-    // what the second half needs beside the slabs: requested here, they land under the reduction
-    float4 s3[H];
-    float4 bl = make_float4(0.f, 0.f, 0.f, 0.f), ult = bl;
-    if (HAS_LW) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) s3[h] = ld4(a.sproj + (size_t)(b0 + h) * a.ldsp + 3 * D + 4 * d4);
-        bl = ld4(a.blt + 4 * d4); ult = ld4(a.Ult + 4 * d4);
-    }
-#pragma unroll
-    for (int i = 0; i < NV; ++i) {
-        const float rr = wave_sum(r[i]);
-        if (lane == 0) s_red[w * NV + i] = rr;
-    }
-    __syncthreads();
-    if (w == 0) {           // lane 8 h + k: softmax of hypothesis h over its 8-lane group
-        const int i = min(lane, H * 8 - 1), h = i >> 3, k = i & 7;
-        const float usum = s_red[NV - 1] + s_red[2 * NV - 1] + s_red[3 * NV - 1] + s_red[4 * NV - 1];
-        const float e = k < K ? s_red[i] + s_red[NV + i] + s_red[2 * NV + i] + s_red[3 * NV + i] + usum + cl0 : -INFINITY;
-        float mx = e;
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o, 64));
-        const float ex = k < K ? __expf(e - mx) : 0.f;
-        float sum = ex;
-#pragma unroll
-        for (int o = 4; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
-        const float al = ex / sum;
-        if (lane < H * 8) {
-            s_al[lane] = al;
-            if (k < K) a.alphal[((size_t)(b0 + h) * T + t) * K + k] = al;
-        }
-    } else if (w == 1 && lane < 2 * H) {
-        const int i = H * 8 + lane, h = lane >> 1;
-        const float e = s_red[i] + s_red[NV + i] + s_red[2 * NV + i] + s_red[3 * NV + i];
-        if (lane & 1) a.em[(size_t)(b0 + h) * T + t] = e + cm0;
-        else a.eg[(size_t)(b0 + h) * T + t] = e + cg0;
-    }
-    __syncthreads();
-
-    // ---- attended local feature (and the local-temporal score) per hypothesis, from the rows already in registers
-    float pe[H];
-#pragma unroll
-    for (int h = 0; h < H; ++h) {
-        float4 c4 = make_float4(0.f, 0.f, 0.f, 0.f), w4 = c4;
-#pragma unroll
-        for (int kk = 0; kk < 8; ++kk) {
-            const float al = s_al[h * 8 + kk];          // 0 for the regions past K
-            c4.x += al * l[kk].x; c4.y += al * l[kk].y; c4.z += al * l[kk].z; c4.w += al * l[kk].w;
-            if (HAS_LW) { w4.x += al * q[kk].x; w4.y += al * q[kk].y; w4.z += al * q[kk].z; w4.w += al * q[kk].w; }
-        }
-#if STATTN_COLS_ABL == 3
-        w4.x += c4.x + c4.y + c4.z + c4.w;
-#else
-        if (tid < nd4) st4(a.CL + ((size_t)(b0 + h) * T + t) * D + 4 * d4, c4);
-#endif
-        pe[h] = 0.f;
-        if (HAS_LW) {
-            w4.x += bl.x; w4.y += bl.y; w4.z += bl.z; w4.w += bl.w;
-            pe[h] = on * dot4_tanh(w4, s3[h], ult);
-        }
-    }
-    if (HAS_LW) {
-#pragma unroll
-        for (int h = 0; h < H; ++h) {
-            const float rr = wave_sum(pe[h]);
-            if (lane == 0) s_red[w * H + h] = rr;        // (every read of the first use is behind the second barrier above)
-        }
-        __syncthreads();
-        if (tid < H) a.elt[(size_t)(b0 + tid) * T + t] = s_red[tid] + s_red[H + tid] + s_red[2 * H + tid] + s_red[3 * H + tid] + clt0;
-    }
-}
-
-template <int H, bool HAS_LW>
-__global__ __launch_bounds__(256, 2) void spatial_shared_cols_kernel(const SpatialArgs a) { spatial_shared_cols_body<H, HAS_LW>(a, (int)blockIdx.x); }
-
-template <int H, bool HAS_LW>
-__global__ __launch_bounds__(256, 2) void spatial_shared_cols_update_kernel(const SpatialArgs a, const BeamArgs u) {
-    if ((int)blockIdx.x < u.nvid) { beam_update_body(u, 0, nullptr, nullptr, (int)blockIdx.x, u.nvid); return; }
-    spatial_shared_cols_body<H, HAS_LW>(a, (int)blockIdx.x - u.nvid);
-}
-
-
 
 // one wave per row: out[r] = dot(P[r,:], U) + c
 __global__ __launch_bounds__(256) void rowdot_kernel(const float* __restrict__ P, int ldp,
@@ -1130,8 +813,8 @@ __global__ __launch_bounds__(256) void temporal_kernel(const TemporalArgs a) {
 // only spatial2_kernel carries a rider (its 120-VGPR budget covers the rider's 95; spatial_kernel would drop from six to
 // four workgroups per CU, the bf16 and shared-slab kernels are not per-row)
 static bool spatial_shared_path(const SpatialArgs& a) {
-    static const char* noshare = getenv("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
-    static const char* mn = getenv("STATTN_SHARED_MIN");               // tools/shared_rounds_probe.py: smallest (video, frame) grid that takes it
+    static const char* noshare = sw_tool("STATTN_SPATIAL_NOSHARE");     // A/B switch for tools
+    static const char* mn = sw_tool("STATTN_SHARED_MIN");               // tools/shared_rounds_probe.py: smallest (video, frame) grid that takes it
     // Smallest (video, frame) grid that takes it, measured against the per-row kernels at beam 5, D = 1024 (tools/shared_rounds_probe.py, attention +
     // state-projection launches together -- up to 64 rows the per-row launch also carries h.U): K = 8, T = 26: 104 / 312 / 520 items lose (45 / 57 / 89 us
     // against 34 / 46 / 74), 832 tie, 1300 win (79 against 92); K = 16, T = 40: 160 items lose (47 against 41), 320 win (64 against 73), 1280: 92 against 188;
@@ -1139,21 +822,14 @@ static bool spatial_shared_path(const SpatialArgs& a) {
     const int min_items = mn ? atoi(mn) : (a.K <= 8 ? 800 : 320);
     return a.group > 1 && a.group <= 8 && a.M % a.group == 0 && !noshare && (a.M / a.group) * a.T >= min_items;
 }
-// K <= 8 regions, D <= 1024: one float4 column per lane, one memory round trip per item (spatial_shared_cols_body)
-static bool spatial_shared_cols(const SpatialArgs& a) {
-    // OFF unless STATTN_SHARED_COLS=1: measured once at the evaluation shape (51 videos x 28 frames, beam 5) it ran 76 us against the
-    // 77 us of spatial_shared_kernel<5> -- not yet the 30 us its bytes allow, and not yet through the parity suite
-    static const char* cols = getenv("STATTN_SHARED_COLS");
-    return cols && cols[0] == '1' && a.K <= 8 && a.D <= 1024 && a.group <= 6;        // (7 / 8 hypotheses with LW: 256 VGPRs and a spill)
-}
 bool spatial_rider_supported(const SpatialArgs& a) {
-    static const char* norider = getenv("STATTN_NO_RIDER");            // A/B switch for tools
-    static const char* v1 = getenv("STATTN_SPATIAL1");
+    static const char* norider = sw_product("STATTN_NO_RIDER");            // A/B switch for tools
+    static const char* v1 = sw_tool("STATTN_SPATIAL1");
     return !norider && (a.bf16 || !spatial_shared_path(a)) && a.D % 1024 == 0 && !v1;
 }
 
 static bool spatial_small_path(const SpatialArgs& a) {
-    static const char* nosm = getenv("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
+    static const char* nosm = sw_tool("STATTN_SPATIAL_NOSMALL");   // A/B switch for tools
     return !nosm && !a.bf16 && !spatial_shared_path(a) && !a.rider.nblocks && a.M * a.T <= 512 && a.K <= 8 && a.D <= 1024;
 }
 bool spatial_update_supported(const SpatialArgs& a) {
@@ -1176,17 +852,9 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
         }
         if (spatial_shared_path(a)) {
             const dim3 grid(a.M / a.group * a.T + upd->nvid), block(256);
-            if (spatial_shared_cols(a)) {
-#define STATTN_COLS_UPD(HH) case HH: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_update_kernel<HH, true>), grid, block, 0, s, a, *upd); \
-                                     else hipLaunchKernelGGL((spatial_shared_cols_update_kernel<HH, false>), grid, block, 0, s, a, *upd); break;
-                switch (a.group) {
-                    STATTN_COLS_UPD(2) STATTN_COLS_UPD(3) STATTN_COLS_UPD(4) STATTN_COLS_UPD(5)
-                    default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_update_kernel<6, true>), grid, block, 0, s, a, *upd);       // (group <= 6: spatial_shared_cols)
-                             else hipLaunchKernelGGL((spatial_shared_cols_update_kernel<6, false>), grid, block, 0, s, a, *upd); break;
-                }
-#undef STATTN_COLS_UPD
-                return hipGetLastError();
-            }
+#if STATTN_EXPERIMENTAL
+            if (exp_launch_shared_cols_update(s, a, *upd, grid, block)) return hipGetLastError();
+#endif
             switch (a.group) {
                 case 2: hipLaunchKernelGGL(spatial_shared_update_kernel<2>, grid, block, 0, s, a, *upd); break;
                 case 3: hipLaunchKernelGGL(spatial_shared_update_kernel<3>, grid, block, 0, s, a, *upd); break;
@@ -1208,12 +876,10 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
     if (a.rider.nblocks && (!spatial_rider_supported(a) || !rider_shape_ok(a.rider))) return hipErrorInvalidValue;
     if (a.bf16) {
         if (a.D % 8 != 0 || !a.LW) return hipErrorInvalidValue;
-        static const char* v2 = getenv("STATTN_BF16_V2");            // opt-in until measured (see spatial_bf16v2_kernel)
-        if (v2 && v2[0] == '1' && a.D <= 1024 && a.K <= 16 && a.clt) {
-            if (a.K > 8) hipLaunchKernelGGL((spatial_bf16v2_kernel<128, true>), dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
-            else hipLaunchKernelGGL((spatial_bf16v2_kernel<128, false>), dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
-        }
-        else if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
+#if STATTN_EXPERIMENTAL
+        if (exp_launch_spatial_bf16v2(s, a)) return hipGetLastError();
+#endif
+        if (a.D <= 1024) hipLaunchKernelGGL(spatial_bf16_kernel<128>, dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
         else hipLaunchKernelGGL(spatial_bf16_kernel<256>, dim3(a.M * a.T + a.rider.nblocks), dim3(256), 0, s, a);
         return hipGetLastError();
     }
@@ -1221,17 +887,9 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
     // (worth it from a few hundred (video, frame) items on: the rule and its measurements are in spatial_shared_path)
     if (spatial_shared_path(a)) {
         const dim3 grid(a.M / a.group * a.T), block(256);
-        if (spatial_shared_cols(a)) {
-#define STATTN_COLS(HH) case HH: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_kernel<HH, true>), grid, block, 0, s, a); \
-                                 else hipLaunchKernelGGL((spatial_shared_cols_kernel<HH, false>), grid, block, 0, s, a); break;
-            switch (a.group) {
-                STATTN_COLS(2) STATTN_COLS(3) STATTN_COLS(4) STATTN_COLS(5)
-                default: if (a.LW) hipLaunchKernelGGL((spatial_shared_cols_kernel<6, true>), grid, block, 0, s, a);       // (group <= 6: spatial_shared_cols)
-                         else hipLaunchKernelGGL((spatial_shared_cols_kernel<6, false>), grid, block, 0, s, a); break;
-            }
-#undef STATTN_COLS
-            return hipGetLastError();
-        }
+#if STATTN_EXPERIMENTAL
+        if (exp_launch_shared_cols(s, a, grid, block)) return hipGetLastError();
+#endif
         switch (a.group) {
             case 2: hipLaunchKernelGGL(spatial_shared_kernel<2>, grid, block, 0, s, a); break;
             case 3: hipLaunchKernelGGL(spatial_shared_kernel<3>, grid, block, 0, s, a); break;
@@ -1253,7 +911,7 @@ hipError_t launch_spatial(hipStream_t s, const SpatialArgs& a, const BeamArgs* u
     }
     // D a multiple of 1024: 128-thread workgroups with two columns per thread (all items of configs[1] resident at
     // once: 36 us instead of 41 us per launch there); otherwise the 256-thread kernel, one column per thread
-    static const char* v1 = getenv("STATTN_SPATIAL1");          // A/B switch for tools
+    static const char* v1 = sw_tool("STATTN_SPATIAL1");          // A/B switch for tools
     if (a.D % 1024 == 0 && !v1) hipLaunchKernelGGL(spatial2_kernel<128>, dim3(a.M * a.T + a.rider.nblocks), dim3(128), 0, s, a);
     else hipLaunchKernelGGL(spatial_kernel, dim3(a.M * a.T), dim3(256), 0, s, a);
     return hipGetLastError();

@@ -165,7 +165,7 @@ int stattn_comm_init(stattn_handle* h, int rank, int nranks, const void* id_byte
         return fail(h, STATTN_EHIP, "ncclCommInitRank(rank %d of %d) failed: %s", rank, nranks, r->GetErrorString(e));
     }
     h->comm = c; h->comm_rank = rank; h->comm_nranks = nranks;
-    static const char* noov = getenv("STATTN_COMM_NO_OVERLAP");
+    static const char* noov = sw_product("STATTN_COMM_NO_OVERLAP");
     h->comm_overlap = noov ? 0 : 1;
     static bool said = false;
     if (!said && rank == 0) { said = true; fprintf(stderr, "stattn: RCCL from %s, %d rank(s)\n", r->path.c_str(), nranks); }

@@ -444,7 +444,7 @@ template <int TM, int TN>
 hipError_t launch_group_cfg(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
     constexpr int BM = 64 * TM, BN = 64 * TN;
     GemmGroup G{};
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
     bool edge = false, pair = false;
     int tiles = 0;
     for (int i = 0; i < n; ++i) {
@@ -487,7 +487,7 @@ hipError_t launch_gemm_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, 
     // Tile of a grouped launch.  64 x 64 is the default (13 tiles per CU on the biggest projection: no tail).  When every
     // problem has N % 128 == 0 the 128 x 128 tile halves the L2 -> LDS traffic per flop; it is taken when the GROUP's
     // tile count fills whole rounds of the resident workgroups (the small problems are what fills the big one's tail).
-    static const char* gt = getenv("STATTN_GROUP_TILE");          // "22" / "11": force (tools)
+    static const char* gt = sw_tool("STATTN_GROUP_TILE");          // "22" / "11": force (tools)
     bool n128 = true;
     long t22 = 0;
     for (int i = 0; i < n; ++i) { n128 = n128 && gs[i].N % 128 == 0 && gs[i].M >= 128; t22 += (long)((gs[i].M + 127) / 128) * (gs[i].N / 128); }
@@ -505,7 +505,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
     g.kslices = 1;
 #ifdef STATTN_PROBES
-    static const char* clk = getenv("STATTN_GEMM_CLK");
+    static const char* clk = sw_tool("STATTN_GEMM_CLK");
     if (clk) {
         if (!g_clk_dev) {
             if (hipMalloc(&g_clk_dev, CLK_SLOTS * 4 * sizeof(long long)) != hipSuccess) g_clk_dev = nullptr;
@@ -517,7 +517,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
         }
     }
 #endif
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || (!tA && g.K % 4 != 0)) return hipErrorInvalidValue;
@@ -536,7 +536,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
         // Long-K weight gradients with many output tiles (dff_local_W = ctxl^T.dL: 4096 x 1024 x 13312): 128 x 128 tiles,
         // K cut so that two workgroups per CU are resident -- half the L2 -> LDS traffic per flop of the 64 x 64 tile at the
         // same fill (982 -> 909 us).  Shorter K or fewer tiles lose (dU 1024 x 4096 x 1920: 154 -> 163 us; da NT 221 -> 275).
-        static const char* nobig = getenv("STATTN_SPLITK_NOBIG");       // A/B switch for tools
+        static const char* nobig = sw_tool("STATTN_SPLITK_NOBIG");       // A/B switch for tools
         if (!nobig && !epi && tA && n128 && g.M % 128 == 0 && Kt >= 2048 && blocks(128, 128) >= 128) {
             const int t22 = blocks(128, 128);
             int ks = (512 + t22 - 1) / t22;
@@ -557,9 +557,9 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
             // 1024 workgroups are resident at once (four per CU): a slice count whose grid overshoots that by a fraction runs
             // a nearly empty second round (da = dlogit.Wo^T, 240 tiles: 5 slices = 1200 workgroups) -- round down when that
             // still fills the chip
-            static const char* ceil_rule = getenv("STATTN_SPLITK_CEIL");   // A/B switch for tools: the rule of rounds 1-3
+            static const char* ceil_rule = sw_tool("STATTN_SPLITK_CEIL");   // A/B switch for tools: the rule of rounds 1-3
             if (!ceil_rule && ks * t11 > 1024 && (ks - 1) >= 2 && (ks - 1) * t11 >= 832) --ks;
-            static const char* fks = getenv("STATTN_FWD_KS");            // tools: slice count of epilogue-carrying split-K launches
+            static const char* fks = sw_tool("STATTN_FWD_KS");            // tools: slice count of epilogue-carrying split-K launches
             if (epi && fks) ks = atoi(fks);
             else if (ks > Kt / 512) ks = Kt / 512;
             // (a launch with an epilogue pays for it once more in the reduction: slices of at least 1024 -- measured on the
@@ -582,7 +582,7 @@ hipError_t launch_gemm(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     // 128x64 / 64x64 tiles reach 125 / 118 / 114 TFLOP/s, but what decides the decoder's shapes (N = 1024,
     // M = 13312: 3.25 big tiles per CU) is the tail: whole tiles per CU quantise, so the big tile is only used
     // when its per-CU tile count is (nearly) integral; otherwise the 64x64 tile (4 resident blocks per CU).
-    static const char* force = getenv("STATTN_GEMM_TILE");       // probing only
+    static const char* force = sw_tool("STATTN_GEMM_TILE");       // probing only
     if (force && force[0] == '2' && force[1] == '2' && n128) return launch_cfg<2, 2>(s, g, tA, tB);
     if (force && force[0] == '2' && force[1] == '1') return launch_cfg<2, 1>(s, g, tA, tB);
     if (force && force[0] == '1') return launch_cfg<1, 1>(s, g, tA, tB);

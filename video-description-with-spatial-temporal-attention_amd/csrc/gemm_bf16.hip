@@ -374,10 +374,10 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || g.K % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0) return hipErrorInvalidValue;
     if (g.rowgroup < 1) g.rowgroup = 1;
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
     // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 84 forces one for the sweep
-    static const char* force = getenv("STATTN_BF16_TILE");
+    static const char* force = sw_tool("STATTN_BF16_TILE");
     const bool glds_ok = g.N % 128 == 0 && g.K % BKB == 0 && g.K >= 2 * BKB && bf16_epi::wide_ok(g) && g.n_split % 128 == 0;      // M edge: clamped rows
     int tile = g.tile ? g.tile : (force ? atoi(force) : 0);
     if (!g.tile && tile == 84 && !glds_ok) tile = 0;          // forced through the environment: only where it applies

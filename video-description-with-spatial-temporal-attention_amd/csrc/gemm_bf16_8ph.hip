@@ -323,7 +323,7 @@ hipError_t launch_gemm_bf16_8ph(hipStream_t s, const GemmBfArgs& gin) {
         g.kslices = (nk + kper - 1) / kper;           // no empty slice
         if (!g.ws || g.ws_floats < (size_t)g.kslices * g.M * g.N || ((size_t)g.ws & 15) || g.N % 4) return hipErrorInvalidValue;
     }
-    static const char* var = getenv("STATTN_8PH_VAR");       // ablations (tools/gemm_8ph_probe.py); the product runs variant 0
+    static const char* var = sw_tool("STATTN_8PH_VAR");       // ablations (tools/gemm_8ph_probe.py); the product runs variant 0
     const int v = var ? atoi(var) : 0;
     if (v == 1) return launch_var<1>(s, g);
     if (v == 2) return launch_var<2>(s, g);

@@ -418,7 +418,7 @@ static bool wide_tiles(long tiles256) { return tiles256 >= 256; }
 hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool tB) {
     GemmArgs g = gin;
     g.kslices = 1;
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
+    static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
     if (!gemm_split_supported(g, tA, tB)) return hipErrorInvalidValue;
     const int tiles = ((g.M + 127) / 128) * (g.N / 128);
@@ -445,7 +445,7 @@ hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool t
                 if (cost < best * 0.999) { best = cost; ks = k; wide = c != 0; }
             }
         }
-        if (const char* fk = getenv("STATTN_SPLIT_KS")) {                 // probing only: "<slices>[w]"
+        if (const char* fk = sw_tool("STATTN_SPLIT_KS")) {                 // probing only: "<slices>[w]"
             ks = atoi(fk); wide = fk[strlen(fk) - 1] == 'w';
             if (ks > kmax) ks = kmax;
         }
@@ -458,7 +458,7 @@ hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool t
             return launch_splitk_reduce(s, g.ws, g.C, g.ldc, g.M, g.N, ks, g.alpha, g.accumulate);
         }
     }
-    static const char* force = getenv("STATTN_SPLIT_TILE");      // probing only: "1" = 64 x 64, "2" = 128 x 128, "3" = 256 x 128
+    static const char* force = sw_tool("STATTN_SPLIT_TILE");      // probing only: "1" = 64 x 64, "2" = 128 x 128, "3" = 256 x 128
     const long tiles256 = (long)((g.M + 255) / 256) * (g.N / 128);
     if (force ? force[0] == '3' : wide_tiles(tiles256))
         return launch3<2, 2, 4, 2>(s, dim3((unsigned)tiles256), g, tA, tB, needs_edge(g, tA, 256, g.K));
@@ -470,8 +470,8 @@ hipError_t launch_gemm_split(hipStream_t s, const GemmArgs& gin, bool tA, bool t
 hipError_t launch_gemm_split_group(hipStream_t s, const GemmArgs* gs, int n, bool tA, bool tB) {
     if (n < 1 || n > GEMM_GROUP_MAX || (tA && tB)) return hipErrorInvalidValue;
     if (n == 1) return launch_gemm_split(s, gs[0], tA, tB);
-    static const char* noremap = getenv("STATTN_GEMM_NOREMAP");
-    static const char* force = getenv("STATTN_SPLIT_TILE");
+    static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
+    static const char* force = sw_tool("STATTN_SPLIT_TILE");
     long tiles128 = 0, tiles256 = 0;
     for (int i = 0; i < n; ++i) {
         tiles128 += (long)((gs[i].M + 127) / 128) * (gs[i].N / 128);

@@ -397,7 +397,7 @@ void pw_geom(int M, int colblocks, int& RG, int& MB) {
 }  // namespace
 
 bool panel_wide_enabled() {
-    static const char* off = getenv("STATTN_NO_PANELW");   // A/B switch for tools
+    static const char* off = sw_tool("STATTN_NO_PANELW");   // A/B switch for tools
     return !off;
 }
 
@@ -432,7 +432,7 @@ hipError_t launch_panel_wide(hipStream_t s, const PnArgs& a) {
     // waiting for operands: more waves per SIMD cover the ~2 us of loaded latency that a deeper ring cannot)
     const int KS = MB == 1 ? 16 : (MB == 2 ? 8 : 4);
     size_t lds = ((size_t)(KS / 2 > 2 ? KS / 2 : 2) * MB * 32 * WPITCH + (stats ? MB * 32 * (WCB + 1) : 0)) * sizeof(float);
-    static const char* ldspad = getenv("STATTN_PW_LDS");       // tools: force a dynamic LDS size (bytes) -> workgroups per CU
+    static const char* ldspad = sw_tool("STATTN_PW_LDS");       // tools: force a dynamic LDS size (bytes) -> workgroups per CU
     if (ldspad && (size_t)atol(ldspad) > lds) lds = (size_t)atol(ldspad);
     const dim3 grid(colblocks, RG), block(64 * KS);
 #define STATTN_PW(MB_, R_, KS_)                                                              \
@@ -443,7 +443,7 @@ hipError_t launch_panel_wide(hipStream_t s, const PnArgs& a) {
     } while (0)
     // ring depth: (waves per SIMD) x R x MB x 256 MFMA cycles of operands in flight >= ~6000 cycles (2.5 us)
 #ifdef STATTN_PROBES
-    if (const char* rr = getenv("STATTN_PW_R")) {          // tools/panelw_probe.hip: ring depth sweep
+    if (const char* rr = sw_tool("STATTN_PW_R")) {          // tools/panelw_probe.hip: ring depth sweep
         const int R_ = atoi(rr);
 #define STATTN_PW_SWEEP(MB_, KS_) \
         if (MB == MB_) { if (R_ == 3) STATTN_PW(MB_, 3, KS_); else if (R_ == 4) STATTN_PW(MB_, 4, KS_); else if (R_ == 5) STATTN_PW(MB_, 5, KS_); \
@@ -478,7 +478,7 @@ hipError_t launch_lstm_panel_wide(hipStream_t s, const LstmPnArgs& a) {
         hipLaunchKernelGGL((lstm_panelw_kernel<MB_, R_>), grid, block, lds, s, a);           \
     } while (0)
 #ifdef STATTN_PROBES
-    if (const char* rr = getenv("STATTN_PW_R")) {
+    if (const char* rr = sw_tool("STATTN_PW_R")) {
         const int R_ = atoi(rr);
 #define STATTN_LPW_SWEEP(MB_) \
         if (MB == MB_) { if (R_ == 3) STATTN_LPW(MB_, 3); else if (R_ == 4) STATTN_LPW(MB_, 4); else if (R_ == 5) STATTN_LPW(MB_, 5); \

@@ -310,7 +310,7 @@ hipError_t launch_skinny(hipStream_t s, const SkArgs& a) {
     bool packed = false;
     for (int i = 0; i < a.nseg; ++i)
         for (int p = 0; p < a.seg[i].npairs; ++p) packed = packed || a.seg[i].p[p].tile_stride != 0;
-    static const char* noshare = getenv("STATTN_SKINNY_NOSHARE");
+    static const char* noshare = sw_tool("STATTN_SKINNY_NOSHARE");
     if (mtb >= 2 && !packed && !noshare) hipLaunchKernelGGL(skinny_shared_kernel, grid, block, 0, s, a, mtb);
     else hipLaunchKernelGGL(skinny_kernel, grid, block, 0, s, a, mtb);
     return hipGetLastError();

@@ -29,7 +29,7 @@ hipError_t gemm_nn(stattn_handle* h, const GemmArgs& g) {
 
 // several independent plain GEMMs in one launch (gemm.hip launch_gemm_group); timed like one launch of the class
 int gemm_group(stattn_handle* h, const GemmArgs* gs, int n) {
-    static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");     // A/B switch for tools: one launch per problem
+    static const char* nogroup = sw_product("STATTN_GEMM_NOGROUP");     // A/B switch for tools: one launch per problem
     if (nogroup) {
         for (int i = 0; i < n; ++i) HIPCHK(h, gemm_nn(h, gs[i]));
         return STATTN_OK;
@@ -93,7 +93,7 @@ hipError_t gemm_bf(stattn_handle* h, const GemmBfArgs& g) {
 // several independent bf16 problems: ONE launch of the 256 x 256 kernel when every problem qualifies (one profiling slot, like the
 // fp32 path's grouped launches), else one launch each
 hipError_t gemm_bf_group(stattn_handle* h, const GemmBfArgs* gs, int n) {
-    static const char* nogroup = getenv("STATTN_GEMM_NOGROUP");           // A/B switch for tools
+    static const char* nogroup = sw_product("STATTN_GEMM_NOGROUP");           // A/B switch for tools
     bool ok = n > 1 && n <= GEMM_BF_GROUP_MAX && !nogroup;
     long tiles = 0;
     for (int i = 0; i < n && ok; ++i) { ok = gemm_bf16_8ph_supported(gs[i]); tiles += (long)((gs[i].M + 255) / 256) * (gs[i].N / 256); }
@@ -144,7 +144,7 @@ static int project_context_bf16(stattn_handle* h, int nv, int T, int K, const fl
     if (extra) g1[n1++] = *extra;
     HIPCHK(h, gemm_bf_group(h, g1, n1));
     // second launch: what needs L / M.  PL = L.Wcl + bl and LW = L.Wclt are one problem over N = 2 D columns with two outputs
-    static const char* nofuse = getenv("STATTN_BF16_NOFUSE");                 // A/B switch for tools
+    static const char* nofuse = sw_tool("STATTN_BF16_NOFUSE");                 // A/B switch for tools
     const bool fuse = D % 256 == 0 && !nofuse;
     // (pctxm_ is NOT grouped with them: at configs[3] PL | LW is exactly 5 rounds of 256 tiles and 40 more tiles of the same length
     // would add a sixth for everybody -- 190 against 162 + 19 us measured)
@@ -258,7 +258,7 @@ int init_state(stattn_handle* h, int nv, int T, const float* G, const float* mas
 // call and uses them for any batch (at 4 rows the 16-column panels still give 128+ workgroups where the 64-column
 // kernels give 32)
 bool use_panels(const stattn_handle* h, int M, int min_rows) {
-    static const char* off = getenv("STATTN_NO_PANELS");       // A/B switch for tools
+    static const char* off = sw_product("STATTN_NO_PANELS");       // A/B switch for tools
     // (the kernels take up to 512 rows; past 256 the 64-column kernels, which split the rows over workgroups, are as fast)
     return !off && M >= min_rows && M <= 256 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
 }

@@ -45,3 +45,13 @@ def pytest_generate_tests(metafunc):
     mod = metafunc.module.__name__.rsplit(".", 1)[-1]
     if mod in BOTH_PRECISIONS and metafunc.definition.get_closest_marker("gpu") and "STATTN_PRECISION" not in os.environ:
         metafunc.parametrize("stattn_precision", ["fp32", "split"], indirect=True)
+
+
+def pytest_sessionfinish(session, exitstatus):
+    # red-zone runs (tests/test_gpu_redzone.py starts pytest in a child with STATTN_DBG_REDZONE=1): how many scans the session made
+    if os.environ.get("STATTN_DBG_REDZONE"):
+        try:
+            from stattn import _native
+            print("\nREDZONE_SCANS=%d" % _native.REDZONE_CHECKS[0])
+        except Exception:
+            pass

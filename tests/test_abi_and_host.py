@@ -140,3 +140,47 @@ def test_one_hip_runtime_whichever_of_libstattn_and_torch_is_loaded_first():
         out = subprocess.run([sys.executable, "-c", src], capture_output=True, text=True, timeout=300)
         assert out.returncode == 0, out.stderr[-2000:]
         assert out.stdout.split()[0] == "1", (order, out.stdout)
+
+
+# ---- the product build's surface: runtime switches and kernels ---------------------------------
+CSRC = os.path.join(ROOT, "video-description-with-spatial-temporal-attention_amd", "csrc")
+
+
+def _product_switches():
+    src = open(os.path.join(CSRC, "switches.h")).read()
+    body = src[src.index("#define STATTN_PRODUCT_SWITCHES(X)"):src.index("inline bool sw_is_product")]
+    return re.findall(r"X\((STATTN_[A-Z0-9_]+)\)", body)
+
+
+def test_product_library_reads_at_most_ten_environment_switches():
+    listed = _product_switches()
+    assert 0 < len(listed) <= 10 and len(set(listed)) == len(listed), listed
+    used_product, used_tool = set(), set()
+    for f in sorted(os.listdir(CSRC)):
+        if not f.endswith((".hip", ".cpp", ".h")) or f == "switches.h":
+            continue
+        src = open(os.path.join(CSRC, f)).read()
+        code = re.sub(r"//[^\n]*", "", src)
+        # no raw getenv in product sources: every variable goes through sw_product / sw_tool (csrc/experimental/ is not compiled in)
+        assert not re.search(r"(?<![\w:])getenv\s*\(", code), "%s reads the environment directly" % f
+        used_product |= set(re.findall(r'sw_product\("(STATTN_[A-Z0-9_]+)"\)', code))
+        used_tool |= set(re.findall(r'sw_tool\("(STATTN_[A-Z0-9_]+)"\)', code))
+    assert used_product <= set(listed), used_product - set(listed)       # a name off the list would be a dead switch
+    assert set(listed) - used_product == set(), set(listed) - used_product   # and the list names nothing the library does not read
+    assert not (used_tool & set(listed))
+    # the product Makefile does not define STATTN_PROBES / STATTN_EXPERIMENTAL unless asked on the command line
+    mk = open(os.path.join(CSRC, "Makefile")).read()
+    assert "-DSTATTN_EXPERIMENTAL" not in mk and "$(if $(PROBES),-DSTATTN_PROBES)" in mk
+
+
+def test_product_library_contains_no_experimental_kernel():
+    """csrc/experimental/*.inl (kernels that have never been through the GPU parity suite) are compiled only under
+    -DSTATTN_EXPERIMENTAL=1; the shipped libstattn.so must not carry their host stubs or device symbols."""
+    names = set()
+    for f in os.listdir(os.path.join(CSRC, "experimental")):
+        names |= set(re.findall(r"__global__[^\n]*?void\s+(\w+)\s*\(", open(os.path.join(CSRC, "experimental", f)).read()))
+    assert names, "no experimental kernels found: delete csrc/experimental and this test together"
+    blob = open(_native.library_path(), "rb").read()
+    for n in names:
+        assert n.encode() not in blob, "libstattn.so contains the experimental kernel %s" % n
+    assert b"spatial2_kernel" in blob and b"lstm_panel_kernel" in blob          # (the scan does see kernel names)

@@ -93,9 +93,14 @@ _DBG_SIGNATURES = {
     "stattn_dbg_counter": (C.c_long, [_H, C.c_int]),
     "stattn_dbg_time_gemm_bf16": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_time_skinny": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "stattn_dbg_redzone_enabled": (C.c_int, []),
+    "stattn_dbg_redzone_buffers": (C.c_long, [_H]),
+    "stattn_dbg_redzone_check": (C.c_int, [_H]),
+    "stattn_dbg_redzone_poke": (C.c_int, [_H, C.c_char_p, C.c_long]),
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
+REDZONE_CHECKS = [0]        # red-zone scans run by this process (STATTN_DBG_REDZONE=1): tests/test_gpu_redzone.py reads it at session end
 DEBUG_SYMBOLS = tuple(_DBG_SIGNATURES)
 
 
@@ -258,6 +263,8 @@ class Decoder(object):
         self.D, self.E, self.V = o.dim, o.dim_word, o.n_words
         self.Fl, self.Fm = o.ctxl_dim, o.ctxm_dim
         self._shapes = OrderedDict()
+        self._redzone = bool(lib.stattn_dbg_redzone_enabled())
+        self.redzone_checks = 0
         for i in range(lib.stattn_param_count(self._h)):
             dims = (C.c_int64 * 2)()
             nd = C.c_int()
@@ -268,11 +275,28 @@ class Decoder(object):
     # -- plumbing
     def _chk(self, rc):
         if rc == 0:
+            # STATTN_DBG_REDZONE=1 (csrc/handle.h): after EVERY library call, every canary byte around every device buffer is verified
+            if getattr(self, "_redzone", False) and self._h.value:
+                self.redzone_checks += 1
+                REDZONE_CHECKS[0] += 1
+                rc = self._lib.stattn_dbg_redzone_check(self._h)
+                if rc != 0:
+                    raise NativeError("libstattn red zone: %s" % self._lib.stattn_last_error(self._h).decode())
             return
         msg = self._lib.stattn_last_error(self._h).decode()
         if rc == -1:
             raise ValueError(msg)
         raise NativeError("libstattn error %d: %s" % (rc, msg))
+
+    def redzone_buffers(self):
+        """Device buffers currently guarded by red zones (0 unless the process started with STATTN_DBG_REDZONE=1)."""
+        return int(self._lib.stattn_dbg_redzone_buffers(self._h))
+
+    def redzone_poke(self, name, offset):
+        """Test hook: damage one canary byte of the named buffer; the next library call must then raise."""
+        rc = self._lib.stattn_dbg_redzone_poke(self._h, name.encode(), int(offset))
+        if rc != 0:
+            raise NativeError(self._lib.stattn_last_error(self._h).decode())
 
     def close(self):
         if getattr(self, "_h", None) and self._h.value:

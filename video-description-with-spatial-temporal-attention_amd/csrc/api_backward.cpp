@@ -75,21 +75,28 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // conversion.  Conversions are remembered for the pass (hs^T feeds five products, dpre^T three, L^T two) and dropped
     // when a GEMM writes their source.
     const bool bf = h->opt.precision == 1;
-    struct BfOp { const void* src; bool tr; uint16_t* buf; };
+    struct BfOp { const void* src; bool tr; int ld, rows, cols; uint16_t* buf; };
     std::vector<BfOp> bfops;
+    int bfop_serial = 0;                             // buffer names never repeat inside a pass (a name taken from bfops.size() was
+                                                     // handed out again after an invalidation while the older entry was still cached)
     const void* const L_as_stored = L;               // bf16 handle: the only operand that already is bf16
+    // drop every conversion of a buffer that is about to be / has just been rewritten (GEMM outputs, and the in-place writers below)
+    auto bf_invalidate = [&](const void* X) {
+        for (size_t i = 0; i < bfops.size();) { if (bfops[i].src == X) { bfops[i] = bfops.back(); bfops.pop_back(); } else ++i; }
+    };
     auto bf_operand = [&](const float* X, int ld, int rows, int cols, bool tr, uint16_t** out) -> int {
-        for (const BfOp& o : bfops) if (o.src == X && o.tr == tr) { *out = o.buf; return STATTN_OK; }
+        for (const BfOp& o : bfops)
+            if (o.src == X && o.tr == tr && o.ld == ld && o.rows == rows && o.cols == cols) { *out = o.buf; return STATTN_OK; }
+        const bool src_bf = (X == L_as_stored);
+        if (!tr && src_bf) { *out = reinterpret_cast<uint16_t*>(const_cast<float*>(X)); return STATTN_OK; }
         char name[32];
-        snprintf(name, sizeof name, "bfop_%d", (int)bfops.size());
+        snprintf(name, sizeof name, "bfop_%d", bfop_serial++);
         uint16_t* buf;
         const int rows8 = (rows + 7) / 8 * 8;         // transposed: the k extent is padded to whole 16-byte chunks with zeros
         CHK(getbuf_t(h, name, (size_t)rows8 * cols, &buf));
-        const bool src_bf = (X == L_as_stored);
         if (tr) HIPCHK(h, launch_transpose_to_bf16(s, X, src_bf ? 1 : 0, (size_t)ld, buf, (size_t)rows8, rows, cols));     // [cols][rows8]
-        else if (src_bf) { *out = reinterpret_cast<uint16_t*>(const_cast<float*>(X)); return STATTN_OK; }
         else HIPCHK(h, launch_cvt_bf16_2d(s, X, (size_t)ld, buf, (size_t)cols, (size_t)rows, cols));
-        bfops.push_back(BfOp{X, tr, buf});
+        bfops.push_back(BfOp{X, tr, ld, rows, cols, buf});
         *out = buf;
         return STATTN_OK;
     };
@@ -119,7 +126,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
                 q.ws = bfws; q.ws_floats = bfws_floats;
             }
         }
-        for (size_t i = 0; i < bfops.size();) { if (bfops[i].src == (const void*)g.C) { bfops[i] = bfops.back(); bfops.pop_back(); } else ++i; }
+        bf_invalidate(g.C);
         HIPCHK(h, launch_gemm_bf16(s, q));
         return STATTN_OK;
     };
@@ -219,6 +226,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     HIPCHK(h, launch_dlogit(s, pr, Vp, dx, dmask, nll_scale, lg, Vp, (int)R, V, Vp));           // dlogit overwrites logits
     CSADD(lg, Vp, (int)R, Vp, G_("ff_logit_b"), 0, nullptr);
     HIPCHK(h, gemm(false, true, lg, Vp, w.Wo, Vp, da, E, (int)R, E, Vp, 0));                     // da = dlogit Wo^T
+    bf_invalidate(da);
     HIPCHK(h, launch_tanh_bwd(s, da, tz, d2, da, R * E));                                        // dz (in place)
     float* dz = da;
     CSADD(dz, E, (int)R, E, G_("ff_logit_lstm_b"), 0, nullptr);
@@ -437,6 +445,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     const bool ntgroup = h->opt.precision == 0 && D % 32 == 0 && !nopair && !nogroup;
     // demb = dpre.W^T (+ dz through prev2out: dz is copied in first and the product accumulated onto it), scattered to the
     // rows of Wemb further down (:613-617)
+    bf_invalidate(demb);
     if (h->opt.prev2out) HIPCHK(h, hipMemcpyAsync(demb, dz, R * E * sizeof(float), hipMemcpyDeviceToDevice, s));
     if (ntgroup) {
         // The three input-gradient GEMMs that are left, in ONE grouped NT launch (longest K first): demb (240 tiles,
@@ -454,7 +463,9 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         g3[2].A = dPM; g3[2].lda = D; g3[2].B = w.Wcm; g3[2].ldb = D; g3[2].C = dMo; g3[2].ldc = D;
         g3[2].M = (int)MT; g3[2].N = D; g3[2].K = D; g3[2].accumulate = 1;
         HIPCHK(h, gemm_grp(g3, 3, false, true));
+        bf_invalidate(dL);
         HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D, bf ? 1 : 0));
+        bf_invalidate(dMo);
         HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
     }
     {   // the weight gradients that wait for the deferred context gradients: the six D x D ones over all frames / all (t*m) rows
@@ -483,12 +494,14 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     if (!ntgroup) {
         HIPCHK(h, gemm(false, true, dPL, D, w.Wcl, D, dL, D, (int)MTK, D, D, 1));
         HIPCHK(h, gemm(false, true, dLW, D, w.Wclt, D, dL, D, (int)MTK, D, D, 1));
+        bf_invalidate(dL);
         HIPCHK(h, launch_tanh_bwd(s, dL, L, nullptr, dL, MTK * D, bf ? 1 : 0));
     }
     HIPCHK(h, gemm(true, false, rawl, Fl, dL, D, G_("ff_local_W"), D, Fl, D, (int)MTK, 0));
     CSADD(dL, D, (int)MTK, D, G_("ff_local_b"), 0, nullptr);
     if (!ntgroup) {
         HIPCHK(h, gemm(false, true, dPM, D, w.Wcm, D, dMo, D, (int)MT, D, D, 1));
+        bf_invalidate(dMo);
         HIPCHK(h, launch_tanh_bwd(s, dMo, Mo, nullptr, dMo, MT * D));
         HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
     }
@@ -542,8 +555,9 @@ int stattn_update(stattn_handle* h, float decay_c, float clip_c) {
     HIPCHK(h, hipSetDevice(h->device));
     hipStream_t s = h->stream;
     if (!h->d_rg2) {
-        HIPCHK(h, hipMalloc((void**)&h->d_rg2, h->nflat * sizeof(float)));
-        HIPCHK(h, hipMalloc((void**)&h->d_ru2, h->nflat * sizeof(float)));
+        HIPCHK(h, h->fb_rg2.ensure(h->nflat * sizeof(float)));
+        HIPCHK(h, h->fb_ru2.ensure(h->nflat * sizeof(float)));
+        h->d_rg2 = static_cast<float*>(h->fb_rg2.p); h->d_ru2 = static_cast<float*>(h->fb_ru2.p);
         HIPCHK(h, hipMemsetAsync(h->d_rg2, 0, h->nflat * sizeof(float), s));
         HIPCHK(h, hipMemsetAsync(h->d_ru2, 0, h->nflat * sizeof(float), s));
     }

@@ -135,8 +135,9 @@ int stattn_create(const stattn_options* o, int device, void* stream, stattn_hand
         h->own_stream = true;
     }
     build_param_table(h);
-    e = hipMalloc((void**)&h->d_params, h->nflat * sizeof(float));
-    if (e == hipSuccess) e = hipMalloc((void**)&h->d_grads, h->nflat * sizeof(float));
+    e = h->fb_params.ensure(h->nflat * sizeof(float));
+    if (e == hipSuccess) { h->d_params = static_cast<float*>(h->fb_params.p); e = h->fb_grads.ensure(h->nflat * sizeof(float)); }
+    if (e == hipSuccess) h->d_grads = static_cast<float*>(h->fb_grads.p);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_params, 0, h->nflat * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipMemsetAsync(h->d_grads, 0, h->nflat * sizeof(float), h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
@@ -167,10 +168,7 @@ void stattn_destroy(stattn_handle* h) {
     if (h->pin_plan[0]) (void)hipHostFree(h->pin_plan[0]);
     if (h->pin_plan[1]) (void)hipHostFree(h->pin_plan[1]);
     for (hipEvent_t e : h->plan_ev) if (e) (void)hipEventDestroy(e);
-    if (h->d_params) (void)hipFree(h->d_params);
-    if (h->d_grads) (void)hipFree(h->d_grads);
-    if (h->d_rg2) (void)hipFree(h->d_rg2);
-    if (h->d_ru2) (void)hipFree(h->d_ru2);
+    h->fb_params.release(); h->fb_grads.release(); h->fb_rg2.release(); h->fb_ru2.release();
     if (h->copy_stream) (void)hipStreamDestroy(h->copy_stream);
     if (h->staged_ev) (void)hipEventDestroy(h->staged_ev);
     if (h->free_ev[0]) (void)hipEventDestroy(h->free_ev[0]);

@@ -254,3 +254,75 @@ int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int 
 }
 
 }  // extern "C"
+
+// ---- red zones (STATTN_DBG_REDZONE=1; handle.h DevBuf) -------------------------------------------------------------------
+namespace {
+struct RzEntry { std::string name; int tail; size_t tail_from; };     // tail: 0 = the zone in front of the buffer, 1 = behind it
+void rz_collect(const std::string& name, const stattn_detail::DevBuf& b, std::vector<stattn::RedzoneRegion>& regs, std::vector<RzEntry>& who) {
+    const size_t rz = stattn_detail::redzone_bytes();
+    if (!b.base || !rz) return;
+    regs.push_back(stattn::RedzoneRegion{static_cast<const unsigned char*>(b.base), rz});
+    who.push_back(RzEntry{name, 0, 0});
+    regs.push_back(stattn::RedzoneRegion{static_cast<const unsigned char*>(b.p) + b.used, b.cap - b.used + rz});
+    who.push_back(RzEntry{name, 1, b.used});
+}
+}  // namespace
+
+int stattn_dbg_redzone_enabled(void) { return stattn_detail::redzone_bytes() ? 1 : 0; }
+
+long stattn_dbg_redzone_buffers(const stattn_handle* h) {
+    if (!h || !stattn_detail::redzone_bytes()) return 0;
+    long n = 0;
+    for (auto& kv : h->bufs) if (kv.second.base) ++n;
+    for (const stattn_detail::DevBuf* b : {&h->fb_params, &h->fb_grads, &h->fb_rg2, &h->fb_ru2}) if (b->base) ++n;
+    return n;
+}
+
+int stattn_dbg_redzone_check(stattn_handle* h) {
+    if (!h) return STATTN_EINVAL;
+    if (!stattn_detail::redzone_bytes()) return STATTN_OK;
+    HIPCHK(h, hipSetDevice(h->device));
+    HIPCHK(h, hipDeviceSynchronize());            // everything in flight on any stream has written what it will write
+    std::vector<stattn::RedzoneRegion> regs;
+    std::vector<RzEntry> who;
+    for (auto& kv : h->bufs) rz_collect(kv.first, kv.second, regs, who);
+    rz_collect("(parameters)", h->fb_params, regs, who); rz_collect("(gradients)", h->fb_grads, regs, who);
+    rz_collect("(adadelta rg2)", h->fb_rg2, regs, who); rz_collect("(adadelta ru2)", h->fb_ru2, regs, who);
+    if (regs.empty()) return STATTN_OK;
+    // scratch of the check itself: plain allocations (not DevBuf: the list being scanned must not change under the scan)
+    stattn::RedzoneRegion* dregs = nullptr;
+    unsigned long long* dbad = nullptr;
+    unsigned long long bad = ~0ull;
+    hipError_t e = hipMalloc((void**)&dregs, regs.size() * sizeof(stattn::RedzoneRegion));
+    if (e == hipSuccess) e = hipMalloc((void**)&dbad, sizeof bad);
+    if (e == hipSuccess) e = hipMemcpy(dregs, regs.data(), regs.size() * sizeof(stattn::RedzoneRegion), hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(dbad, &bad, sizeof bad, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = stattn::launch_redzone_scan(nullptr, dregs, (int)regs.size(), stattn_detail::REDZONE_BYTE, dbad);
+    if (e == hipSuccess) e = hipMemcpy(&bad, dbad, sizeof bad, hipMemcpyDeviceToHost);
+    if (dregs) (void)hipFree(dregs);
+    if (dbad) (void)hipFree(dbad);
+    if (e != hipSuccess) return fail(h, STATTN_EHIP, "red-zone scan: %s", hipGetErrorString(e));
+    if (bad == ~0ull) return STATTN_OK;
+    const size_t ri = (size_t)(bad >> 40), off = (size_t)((bad >> 8) & 0xffffffffull);
+    const RzEntry& w = who[ri < who.size() ? ri : 0];
+    if (w.tail)
+        return fail(h, STATTN_ESTATE, "red zone damaged: buffer '%s' (%zu bytes requested): byte %zu past its end was overwritten (found 0x%02x)",
+                    w.name.c_str(), w.tail_from, off, (unsigned)(bad & 0xff));
+    return fail(h, STATTN_ESTATE, "red zone damaged: buffer '%s': byte %zu before its start was overwritten (found 0x%02x)",
+                w.name.c_str(), stattn_detail::redzone_bytes() - off, (unsigned)(bad & 0xff));
+}
+
+// test hook: write one byte `offset` bytes past the requested end (offset >= 0) or before the start (offset < 0) of a named buffer
+int stattn_dbg_redzone_poke(stattn_handle* h, const char* name, long offset) {
+    if (!h || !name) return STATTN_EINVAL;
+    if (!stattn_detail::redzone_bytes()) return fail(h, STATTN_ESTATE, "redzone_poke: STATTN_DBG_REDZONE is not set");
+    auto it = h->bufs.find(name);
+    if (it == h->bufs.end() || !it->second.base) return fail(h, STATTN_ENOTFOUND, "redzone_poke: no buffer '%s'", name);
+    const stattn_detail::DevBuf& b = it->second;
+    if (offset >= (long)(b.cap - b.used + stattn_detail::redzone_bytes()) || -offset > (long)stattn_detail::redzone_bytes())
+        return fail(h, STATTN_EINVAL, "redzone_poke: offset outside the red zones");
+    unsigned char* p = offset >= 0 ? static_cast<unsigned char*>(b.p) + b.used + offset : static_cast<unsigned char*>(b.p) + offset;
+    HIPCHK(h, hipDeviceSynchronize());
+    HIPCHK(h, hipMemset(p, 0x5A, 1));
+    return STATTN_OK;
+}

@@ -374,6 +374,11 @@ hipError_t launch_gemm_bf16(hipStream_t s, const GemmBfArgs& gin) {
     if (g.M <= 0 || g.N <= 0 || g.K <= 0) return hipSuccess;
     if (g.N % 64 != 0 || g.K % 8 != 0 || g.lda % 8 != 0 || g.ldb % 8 != 0) return hipErrorInvalidValue;
     if (g.rowgroup < 1) g.rowgroup = 1;
+    // a two-output problem hands the epilogue a column rebased to its output (gemm_bf16_epi.h select_out): only bias / bias2 follow it,
+    // every other per-column or per-element operand would be read at the first output's column -- refused, not silently wrong
+    if (g.n_split > 0 && (g.add || g.rowadd || g.mul || g.bias_b)) return hipErrorInvalidValue;
+    // split-K exists in the 256 x 256 kernel only: on another tile the request would be dropped without a word
+    if (g.kslices > 1 && g.tile != 88) return hipErrorInvalidValue;
     static const char* noremap = sw_tool("STATTN_GEMM_NOREMAP");
     g.xcd_remap = noremap ? 0 : 1;
     // tile choice (tools/gemm_bf16_sweep.py): STATTN_BF16_TILE = 11 | 21 | 22 | 84 forces one for the sweep

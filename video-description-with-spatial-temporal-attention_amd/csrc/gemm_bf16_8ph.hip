@@ -343,6 +343,7 @@ hipError_t launch_gemm_bf16_8ph_group(hipStream_t s, const GemmBfArgs* gs, int n
     int maxper = 0;
     for (int p = 0; p < n; ++p) {
         if (!gemm_bf16_8ph_supported(gs[p]) || gs[p].kslices > 1 || gs[p].M <= 0) return hipErrorInvalidValue;
+        if (gs[p].n_split > 0 && (gs[p].add || gs[p].rowadd || gs[p].mul || gs[p].bias_b)) return hipErrorInvalidValue;     // (see launch_gemm_bf16)
         G.g[p] = gs[p];
         if (G.g[p].rowgroup < 1) G.g[p].rowgroup = 1;
         const int tiles = ((gs[p].M + 255) / 256) * (gs[p].N / 256);

@@ -29,18 +29,40 @@ struct ParamInfo {
     size_t count;   // logical element count
 };
 
+// Red zones (STATTN_DBG_REDZONE=1, a product switch: csrc/switches.h).  Every device buffer of the library -- all of them come from
+// DevBuf -- is then allocated with REDZONE_BYTES of canary bytes in front of it and behind the largest size ever requested for it
+// (the allocation's 256-byte rounding slack is canary as well), and stattn_dbg_redzone_check() scans all of them: a kernel that wrote
+// outside any buffer of the library is named with the buffer and the byte offset.  HIP AddressSanitizer does not run on this pool
+// (no XNACK); this is the bounds check that does.  Off (the default), DevBuf is a plain hipMalloc.
+constexpr size_t REDZONE_BYTES = 4096;
+constexpr int REDZONE_BYTE = 0xCB;
+inline size_t redzone_bytes() {
+    static const char* rz = stattn::sw_product("STATTN_DBG_REDZONE");
+    return (rz && rz[0] && rz[0] != '0') ? REDZONE_BYTES : 0;
+}
+
 struct DevBuf {
-    void* p = nullptr;
-    size_t cap = 0;
+    void* p = nullptr;          // what the library uses
+    size_t cap = 0;             // usable bytes at p
+    void* base = nullptr;       // the allocation (== p without red zones)
+    size_t used = 0;            // largest request so far: the tail canary starts at p + used
     hipError_t ensure(size_t bytes) {
-        if (bytes <= cap) return hipSuccess;
-        if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; cap = 0; }
+        if (bytes <= cap) { if (bytes > used) used = bytes; return hipSuccess; }
+        if (base) { hipError_t e = hipFree(base); if (e != hipSuccess) return e; base = p = nullptr; cap = used = 0; }
+        const size_t rz = redzone_bytes();
         size_t want = (bytes + 255) & ~size_t(255);
-        hipError_t e = hipMalloc(&p, want);
-        if (e == hipSuccess) cap = want;
+        hipError_t e = hipMalloc(&base, want + 2 * rz);
+        if (e != hipSuccess) { base = nullptr; return e; }
+        p = static_cast<char*>(base) + rz; cap = want; used = bytes;
+        if (rz) {
+            // (synchronous fills: a debugging mode.  The slack between the request and the rounded size starts as canary too; a later,
+            //  larger request that still fits moves the tail's start and simply finds canary bytes where garbage would be otherwise)
+            e = hipMemset(base, REDZONE_BYTE, rz);
+            if (e == hipSuccess) e = hipMemset(static_cast<char*>(p) + bytes, REDZONE_BYTE, want - bytes + rz);
+        }
         return e;
     }
-    void release() { if (p) { (void)hipFree(p); p = nullptr; cap = 0; } }
+    void release() { if (base) { (void)hipFree(base); base = p = nullptr; cap = used = 0; } }
 };
 
 enum KClass { KC_SPATIAL = 0, KC_HPROJ, KC_LTGEMM, KC_TEMPORAL, KC_LSTM, KC_PROLOGUE, KC_READOUT, KC_GEMM_NN, KC_SELECT, KC_COUNT };
@@ -76,6 +98,7 @@ struct stattn_handle {
     float* d_grads = nullptr;
     float* d_rg2 = nullptr;      // Adadelta running averages (common.py:180-181), allocated on first update
     float* d_ru2 = nullptr;
+    DevBuf fb_params, fb_grads, fb_rg2, fb_ru2;   // their allocations (DevBuf: red zones under STATTN_DBG_REDZONE like every other buffer)
     bool have_bwd = false;
     size_t nflat = 0;
     Weights w{};

@@ -308,6 +308,9 @@ hipError_t launch_temporal(hipStream_t s, const TemporalArgs& a);
 // small kernels (misc.hip)
 // ----------------------------------------------------------------------------
 hipError_t launch_fill(hipStream_t s, float* p, float v, size_t n);
+// red-zone scan (redzone.hip): *bad must hold ~0 on entry and still does afterwards when every canary byte is intact; see handle.h DevBuf
+struct RedzoneRegion { const unsigned char* p; size_t nbytes; };
+hipError_t launch_redzone_scan(hipStream_t s, const RedzoneRegion* regs, int nregs, int canary, unsigned long long* bad);
 hipError_t launch_iota(hipStream_t s, int* p, int n, int mul);   // p[i] = i * mul
 // mean[b,:] = sum_t G[b,t,:] / sum_t mask[b,t]   (model_attention.py:618, 649 / 739, 766)
 hipError_t launch_ctx_mean(hipStream_t s, const float* G, const float* mask, float* mean, int B, int T, int D);

@@ -35,6 +35,16 @@ int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, i
 int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,
                            float* ms_per_launch);
 
+/* Red zones (environment STATTN_DBG_REDZONE=1 when the process starts; csrc/handle.h): every device buffer of the library then
+ * carries 4 KiB of canary bytes on both sides.  _enabled: 1 when the mode is on.  _buffers: buffers currently guarded.
+ * _check: synchronises the device and scans every canary byte; STATTN_OK when all are intact, otherwise STATTN_ESTATE with
+ * stattn_last_error naming the buffer and the first damaged byte.  The Python binding calls it after EVERY library call in this mode.
+ * _poke: test hook, damages one canary byte of a named buffer (offset >= 0: bytes past its end, < 0: before its start). */
+int stattn_dbg_redzone_enabled(void);
+long stattn_dbg_redzone_buffers(const stattn_handle* h);
+int stattn_dbg_redzone_check(stattn_handle* h);
+int stattn_dbg_redzone_poke(stattn_handle* h, const char* name, long offset);
+
 #ifdef __cplusplus
 }
 #endif

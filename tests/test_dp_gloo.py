@@ -120,3 +120,31 @@ def test_shard_rows_partitions_every_row_once():
             xs.append(s['x'])
         assert rows == 7
         np.testing.assert_array_equal(np.concatenate(xs, 1), b['x'])
+
+
+def test_all_reduce_regions_tile_the_gradient_buffer_for_every_option_variant():
+    """The five regions stattn_backward hands to the overlapped all-reduce (csrc/handle.h GRAD_REGIONS, summed by comm.cpp as each
+    becomes final) must cover every float of the flat gradient buffer exactly once, whatever optional parameters the configuration
+    has (selector / ctx2out / prev2out off, odd vocabulary sizes that the device layout pads) -- until round 6 only a runtime check
+    inside stattn_allreduce_grads (comm_covered != nflat) guarded this.  Host-only: the table is evaluated without a device."""
+    import itertools
+    from stattn import _native
+    from oracle import stattn_oracle as O
+    seen = set()
+    for sel, c2o, p2o, V, D, E in itertools.product((1, 0), (1, 0), (1, 0), (12000, 211, 128), (1024, 64), (512, 64)):
+        opt = dict(dim=D, dim_word=E, n_words=V, ctxg_dim=D, ctxl_dim=96, ctxm_dim=64, selector=sel, use_dropout=1, prev2out=p2o, ctx2out=c2o)
+        regions, nflat = _native.grad_regions(opt)
+        assert len(regions) == 5
+        ordered = sorted(regions)
+        assert ordered[0][0] == 0
+        for (o0, l0), (o1, _) in zip(ordered, ordered[1:]):
+            assert l0 > 0 and o0 + l0 == o1, (opt, regions)          # no gap, no overlap
+        assert ordered[-1][0] + ordered[-1][1] == nflat, (opt, regions, nflat)
+        # the buffer is at least as long as the parameters the oracle's table lists for this variant (padding only adds)
+        shapes = O.param_shapes(O.default_options(dim=D, dim_word=E, n_words=V, ctxg_dim=D, ctxl_dim=96, ctxm_dim=64, ctxglm_dim=D,
+                                                  selector=bool(sel), ctx2out=bool(c2o), prev2out=bool(p2o)))
+        assert nflat >= sum(int(np.prod(s)) if len(s) else 1 for s in shapes.values())
+        # completion order: the readout first (final before the reverse scan), the embedding last
+        assert regions[0][0] + regions[0][1] == nflat and regions[-1][0] == 0
+        seen.add(nflat)
+    assert len(seen) > 8

@@ -93,6 +93,7 @@ _DBG_SIGNATURES = {
     "stattn_dbg_counter": (C.c_long, [_H, C.c_int]),
     "stattn_dbg_time_gemm_bf16": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
     "stattn_dbg_time_skinny": (C.c_int, [_H, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _F]),
+    "stattn_dbg_grad_regions": (C.c_int, [C.POINTER(_Options), C.c_int, C.POINTER(C.c_size_t), C.POINTER(C.c_size_t), C.POINTER(C.c_int), C.POINTER(C.c_size_t)]),
     "stattn_dbg_redzone_enabled": (C.c_int, []),
     "stattn_dbg_redzone_buffers": (C.c_long, [_H]),
     "stattn_dbg_redzone_check": (C.c_int, [_H]),
@@ -220,6 +221,20 @@ OPTION_KEYS = ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim",
                "selector", "use_dropout", "prev2out", "ctx2out")
 
 KERNEL_CLASSES = ("spatial", "hproj", "lt_gemm", "temporal", "lstm", "prologue", "readout", "gemm_nn", "select")
+
+
+def grad_regions(options):
+    """(regions, nflat): the [offset, offset + length) ranges, in floats, of the flat gradient buffer that stattn_backward hands to the
+    data-parallel all-reduce, in the order it completes them (csrc/handle.h GRAD_REGIONS).  Computed on the host: needs no GPU."""
+    lib = load_library()
+    o = _Options()
+    for k in OPTION_KEYS:
+        setattr(o, k, int(options[k]))
+    off = (C.c_size_t * 8)(); ln = (C.c_size_t * 8)(); n = C.c_int(); nflat = C.c_size_t()
+    rc = lib.stattn_dbg_grad_regions(C.byref(o), 8, off, ln, C.byref(n), C.byref(nflat))
+    if rc != 0:
+        raise NativeError("stattn_dbg_grad_regions: %s" % lib.stattn_last_error(None).decode())
+    return [(int(off[i]), int(ln[i])) for i in range(n.value)], int(nflat.value)
 
 
 class Decoder(object):

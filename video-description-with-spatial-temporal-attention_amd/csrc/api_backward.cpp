@@ -163,10 +163,12 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
 
     // A region [first, before) of the flat gradient buffer is final: run its collected bias sums, then (data
     // parallel with overlap) start summing it over the ranks on the side stream -- comm.cpp
-    auto region_done = [&](const char* first, const char* before) -> int {
+    auto region_done = [&](int ri, const char* first) -> int {
+        const GradRegion& gr = GRAD_REGIONS[ri];
+        if (strcmp(gr.first, first)) return fail(h, STATTN_ESTATE, "backward: gradient region %d is '%s', not '%s'", ri, gr.first, first);
         if (csb.n) { HIPCHK(h, launch_colsum_batch(s, csb, cspart)); csb = ColsumBatch{}; }
-        const size_t lo = h->params[h->pindex[first]].off;
-        const size_t hi = before ? h->params[h->pindex[before]].off : h->nflat;
+        const size_t lo = h->params[h->pindex[gr.first]].off;
+        const size_t hi = gr.before ? h->params[h->pindex[gr.before]].off : h->nflat;
         return comm_reduce_range(h, lo, hi - lo);
     };
     CHK(comm_backward_begins(h));
@@ -256,7 +258,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, gemm_grp(gi, ni, false, true));
         }
     }
-    CHK(region_done("ff_logit_lstm_W", nullptr));     // final before the reverse scan even starts
+    CHK(region_done(0, "ff_logit_lstm_W"));     // final before the reverse scan even starts
 
     // ---- transposed recurrent weights of the reverse scan: packed panels (row-panel kernels) or plain transposed
     // copies (skinny kernels)
@@ -404,7 +406,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, gemm_grp(ga, na, true, false));
         }
         CSADD(dpre, 4 * D, (int)R, 4 * D, G_("decoder_b"), 0, nullptr);
-        CHK(region_done("decoder_W", "decoder_Wcg_att"));
+        CHK(region_done(1, "decoder_W"));
     }
     {
         CtxGradArgs a{};
@@ -487,7 +489,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
             HIPCHK(h, gemm_grp(gq, nq, true, false));
         }
     }
-    CHK(region_done("decoder_Wcg_att", "ff_logit_lstm_W"));
+    CHK(region_done(2, "decoder_Wcg_att"));
     // -- region ff_*: initial state (:657-660), then back through tanh(ff_local), tanh(ff_motion) (:664-667)
     CSADD(dph0, D, m, D, G_("ff_state_b"), 0, nullptr);
     CSADD(dpc0, D, m, D, G_("ff_memory_b"), 0, nullptr);
@@ -506,7 +508,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         HIPCHK(h, gemm(true, false, rawm, Fm, dMo, D, G_("ff_motion_W"), D, Fm, D, (int)MT, 0));
     }
     CSADD(dMo, D, (int)MT, D, G_("ff_motion_b"), 0, nullptr);
-    CHK(region_done("ff_state_W", "decoder_W"));
+    CHK(region_done(3, "ff_state_W"));
     // -- region Wemb
     // (without an `add` operand the 1920 x 512 x 4096 problem -- 240 tiles of 64 x 64 -- may be cut along K, which fills the chip)
     if (!ntgroup) HIPCHK(h, gemm(false, true, dpre, 4 * D, w.W, 4 * D, demb, E, (int)R, E, 4 * D, h->opt.prev2out ? 1 : 0));
@@ -516,7 +518,7 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
         CHK(getbuf_t(h, "b_embpart", (size_t)(pl.npieces > 0 ? pl.npieces : 1) * E, &epart));
         HIPCHK(h, launch_embed_bwd(s, pl, demb, G_("Wemb"), epart, E, m));
     }
-    CHK(region_done("Wemb", "ff_state_W"));
+    CHK(region_done(4, "Wemb"));
 #undef CSADD
     h->have_bwd = true;
     return STATTN_OK;

@@ -177,6 +177,30 @@ void stattn_destroy(stattn_handle* h) {
     delete h;
 }
 
+// test hook (csrc/stattn_dbg.h): the gradient regions of a configuration, computed on the host -- no device is touched
+int stattn_dbg_grad_regions(const stattn_options* o, int max_regions, size_t* offsets, size_t* lengths, int* n_regions, size_t* nflat) {
+    if (!o || !offsets || !lengths || !n_regions || !nflat || max_regions < N_GRAD_REGIONS)
+        return fail(nullptr, STATTN_EINVAL, "dbg_grad_regions: bad argument");
+    if (o->dim <= 0 || o->dim_word <= 0 || o->n_words <= 0 || o->ctxl_dim <= 0 || o->ctxm_dim <= 0)
+        return fail(nullptr, STATTN_EINVAL, "dbg_grad_regions: bad options");
+    stattn_handle* h = new stattn_handle();
+    h->opt = *o;
+    h->D = o->dim; h->E = o->dim_word; h->V = o->n_words; h->Vp = (int)align_up((size_t)o->n_words, 128);
+    h->Fl = o->ctxl_dim; h->Fm = o->ctxm_dim;
+    build_param_table(h);
+    int rc = STATTN_OK;
+    for (int i = 0; i < N_GRAD_REGIONS && rc == STATTN_OK; ++i) {
+        auto a = h->pindex.find(GRAD_REGIONS[i].first);
+        auto b = GRAD_REGIONS[i].before ? h->pindex.find(GRAD_REGIONS[i].before) : h->pindex.end();
+        if (a == h->pindex.end() || (GRAD_REGIONS[i].before && b == h->pindex.end())) { rc = fail(nullptr, STATTN_ENOTFOUND, "dbg_grad_regions: region %d names an absent parameter", i); break; }
+        const size_t lo = h->params[a->second].off, hi = GRAD_REGIONS[i].before ? h->params[b->second].off : h->nflat;
+        offsets[i] = lo; lengths[i] = hi - lo;
+    }
+    *n_regions = N_GRAD_REGIONS; *nflat = h->nflat;
+    delete h;
+    return rc;
+}
+
 int stattn_sync(stattn_handle* h) {
     if (!h) return STATTN_EINVAL;
     HIPCHK(h, hipStreamSynchronize(h->stream));

@@ -233,6 +233,19 @@ inline float* findbuf(stattn_handle* h, const char* name) {
     return it == h->bufs.end() ? nullptr : static_cast<float*>(it->second.p);
 }
 
+// The regions of the flat gradient buffer in the order stattn_backward completes them (api_backward.cpp region_done), each
+// [offset of `first`, offset of `before`) in parameter-table order, `before` == nullptr meaning the end of the buffer.  The data-parallel
+// all-reduce sums exactly these (comm.cpp); together they must tile [0, nflat) for every option variant: tests/test_dp_gloo.py.
+struct GradRegion { const char* first; const char* before; };
+constexpr GradRegion GRAD_REGIONS[] = {
+    {"ff_logit_lstm_W", nullptr},               // readout + vocabulary projection: final before the reverse scan starts
+    {"decoder_W", "decoder_Wcg_att"},           // W, U, b, Wc: need only the reverse scan's per-step factors
+    {"decoder_Wcg_att", "ff_logit_lstm_W"},     // the attention weights (after ctxgrad)
+    {"ff_state_W", "decoder_W"},                // the context projections and the state initialisers
+    {"Wemb", "ff_state_W"},                     // the embedding, last
+};
+constexpr int N_GRAD_REGIONS = (int)(sizeof(GRAD_REGIONS) / sizeof(GRAD_REGIONS[0]));
+
 // comm.cpp
 int comm_reduce_range(stattn_handle* h, size_t off, size_t n);
 int comm_backward_begins(stattn_handle* h);

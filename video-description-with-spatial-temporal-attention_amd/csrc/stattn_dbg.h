@@ -35,6 +35,10 @@ int stattn_dbg_time_gemm_bf16(stattn_handle* h, int M, int N, int K, int tile, i
 int stattn_dbg_time_skinny(stattn_handle* h, int M, int N, int K, int nseg, int variant, int iters,
                            float* ms_per_launch);
 
+/* The regions of the flat gradient buffer that stattn_backward hands to the data-parallel all-reduce, in completion order
+ * (csrc/handle.h GRAD_REGIONS), for a configuration: offsets / lengths in floats, *nflat = the buffer's length.  Host only. */
+int stattn_dbg_grad_regions(const stattn_options* o, int max_regions, size_t* offsets, size_t* lengths, int* n_regions, size_t* nflat);
+
 /* Red zones (environment STATTN_DBG_REDZONE=1 when the process starts; csrc/handle.h): every device buffer of the library then
  * carries 4 KiB of canary bytes on both sides.  _enabled: 1 when the mode is on.  _buffers: buffers currently guarded.
  * _check: synchronises the device and scans every canary byte; STATTN_OK when all are intact, otherwise STATTN_ESTATE with

@@ -48,7 +48,7 @@ def pytest_generate_tests(metafunc):
 
 
 def pytest_sessionfinish(session, exitstatus):
-    # red-zone runs (tests/test_gpu_redzone.py starts pytest in a child with STATTN_DBG_REDZONE=1): how many scans the session made
+    # red-zone runs (tests/test_gpu_z1_redzone.py starts pytest in a child with STATTN_DBG_REDZONE=1): how many scans the session made
     if os.environ.get("STATTN_DBG_REDZONE"):
         try:
             from stattn import _native

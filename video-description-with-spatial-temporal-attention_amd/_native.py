@@ -101,7 +101,7 @@ _DBG_SIGNATURES = {
 }
 
 EXPORTED_SYMBOLS = tuple(_SIGNATURES)
-REDZONE_CHECKS = [0]        # red-zone scans run by this process (STATTN_DBG_REDZONE=1): tests/test_gpu_redzone.py reads it at session end
+REDZONE_CHECKS = [0]        # red-zone scans run by this process (STATTN_DBG_REDZONE=1): tests/test_gpu_z1_redzone.py reads it at session end
 DEBUG_SYMBOLS = tuple(_DBG_SIGNATURES)
 
 

@@ -22,7 +22,7 @@ namespace stattn {
     X(STATTN_WIDE_STATS_FROM)  /* first beam width whose vocabulary launch uses the wide statistics path   DESIGN.md section 9 (fallback: 65) */ \
     X(STATTN_BEAM_NOGRAPH)     /* word loop of stattn_beam_search without hipGraph capture                 fallback */ \
     X(STATTN_COMM_NO_OVERLAP)  /* one all-reduce after the backward pass instead of five overlapped ones   fallback, tests/test_gpu_dp2.py */ \
-    X(STATTN_DBG_REDZONE)      /* canary zones around every device buffer, checked after every API call    tests/test_gpu_redzone.py */
+    X(STATTN_DBG_REDZONE)      /* canary zones around every device buffer, checked after every API call    tests/test_gpu_z1_redzone.py */
 
 inline bool sw_is_product(const char* name) {
 #define X(n) if (!strcmp(name, #n)) return true;

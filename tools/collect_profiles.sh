@@ -10,7 +10,10 @@ mkdir -p $o
 # HEAD the snapshot was taken from (written by the caller before gpurun: `git rev-parse HEAD > tools/.head`; .git does not travel)
 head=$(cat tools/.head 2>/dev/null || echo unknown)
 src=$(cat bench.py video-description-with-spatial-temporal-attention_amd/csrc/*.hip video-description-with-spatial-temporal-attention_amd/csrc/*.cpp video-description-with-spatial-temporal-attention_amd/csrc/*.h | sha256sum | cut -c1-16)
-echo "{\"round\": \"$r\", \"git_head\": \"$head\", \"sources_sha16\": \"$src\", \"collected\": \"$(date -u +%FT%TZ)\"}" > $o/${r}_STAMP.json
+# per-kernel ISA hashes of the sources this library was built from (written BEFORE the call, here hipcc time is GPU time: `tools/isa_stamp.py --out profiles/${r}_ISA.json`);
+# `tools/isa_stamp.py --check profiles/${r}_ISA.json` on any later tree says mechanically whether these profiles still describe its kernels
+isa=$(sha256sum profiles/${r}_ISA.json 2>/dev/null | cut -c1-16)
+echo "{\"round\": \"$r\", \"git_head\": \"$head\", \"sources_sha16\": \"$src\", \"isa_stamp\": \"profiles/${r}_ISA.json\", \"isa_stamp_sha16\": \"$isa\", \"collected\": \"$(date -u +%FT%TZ)\"}" > $o/${r}_STAMP.json
 python bench.py > $o/${r}_bench_c2_train.json 2> $o/${r}_bench_c2_train.err
 python bench.py --mode forward > $o/${r}_bench_c2_forward.json 2>> $o/${r}_bench.err
 python bench.py --config c2v20k --no-cpu-baseline > $o/${r}_bench_c2v20k_train.json 2>> $o/${r}_bench.err

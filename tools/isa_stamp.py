@@ -5,6 +5,7 @@
     tools/isa_stamp.py --out profiles/r06_ISA.json
     tools/isa_stamp.py --against <git-ref>  -> lists every kernel whose instruction stream differs from the one <git-ref>'s sources give
     tools/isa_stamp.py --check profiles/r06_ISA.json   -> exit 1 if the working tree's kernels differ from the stamped ones
+    tools/isa_stamp.py --stamp-ref dce9137 --out profiles/r05_ISA.json   -> the stamp of a commit's sources (what its profiles measured)
 
 Every .hip under csrc/ is compiled with the Makefile's flags (`--cuda-device-only -S`), the listing is cut into kernels and the
 instruction text of each (labels renumbered, comments dropped) is hashed -- the same normalisation as tools/kernel_code_diff.py.
@@ -76,7 +77,21 @@ def compare(a, b, na, nb):
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--out"); ap.add_argument("--against"); ap.add_argument("--check")
+    ap.add_argument("--stamp-ref", help="write the stamp of a git ref's sources (with --out) instead of the working tree's")
     a = ap.parse_args()
+    if a.stamp_ref:
+        d = tempfile.mkdtemp()
+        try:
+            rel = os.path.relpath(CSRC, ROOT)
+            subprocess.check_call("git -C %s archive %s %s | tar -x -C %s" % (ROOT, a.stamp_ref, rel, d), shell=True)
+            ref = subprocess.check_output(["git", "-C", ROOT, "rev-parse", a.stamp_ref]).decode().strip()
+            doc = {"head": ref, "flags": FLAGS, "extra": EXTRA, "files": stamp(os.path.join(d, rel))}
+        finally:
+            shutil.rmtree(d, ignore_errors=True)
+        s = json.dumps(doc, indent=1, sort_keys=True)
+        if a.out: open(a.out, "w").write(s + "\n")
+        else: print(s)
+        sys.exit(0)
     cur = stamp(CSRC)
     if a.against:
         d = tempfile.mkdtemp()

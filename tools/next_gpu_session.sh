@@ -1,14 +1,17 @@
 #!/bin/bash
-# The A/B runs that were prepared while the GPU pool was closed (round 5), in one gpurun call:
-#   tools/build_variant.sh dpp "-DSTATTN_DPP_REDUCE=1"; tools/build_variant.sh epi "-DSTATTN_PN_EPI_ORDER=1" panel.hip;
-#   tools/build_variant.sh wps2 "-DSTATTN_BWD_BF16_WPS16=2" bwd.hip; tools/build_variant.sh fwdsched "-DSTATTN_BF16_FWD_SCHED=1" attn.hip      (here, before the call: tools/_var travels with the snapshot)
-#   gpurun --timeout 3000 -- tools/next_gpu_session.sh      -> gpurun_out/next_session_report.txt
-# Decides: (1) DPP wave reductions as the default build, (2) spatial_bwd2_kernel (STATTN_BWD2=1|2) as the default reverse attention
-# kernel of configs[1], (3) spatial_shared_cols_kernel (STATTN_SHARED_COLS=1) for K <= 8 beams.  DESIGN.md section 11.
+# The A/B runs of the kernels under csrc/experimental/ and of the compile-time probe builds, in one gpurun call.  Before the call (here;
+# tools/_var travels with the snapshot):   tools/build_all_variants.sh
+#   gpurun --timeout 3000 -- tools/gpu_session_r06.sh ab      -> gpurun_out/next_session_report.txt
+# Decides (promote into the product sources, or delete -- VERDICT r05 item 2; bars in parentheses):
+#   dpp      -DSTATTN_DPP_REDUCE=1          wave reductions on DPP lane moves instead of ds_bpermute chains (whole suite green + no leg slower)
+#   exp      STATTN_BWD2=1|2                spatial_bwd2_kernel            (spatial_bwd_kernel<8> 48.6 us -> <= 43 us)
+#   exp      STATTN_BF16_V2=1               spatial_bf16v2 / spatial_bwd_bf16v2 (68 -> <= 55 us, 100 -> <= 80 us with no scratch)
+#   exp      STATTN_SHARED_COLS=1           spatial_shared_cols_kernel     (eval shared-slab launch 92 -> <= 70 us)
+#   wps2 / fwdsched                         one-line variants of the shipped bf16 attention kernels
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out; mkdir -p $o
-STAGES=${STAGES:-"0 1 2 3 4 5"}
+STAGES=${STAGES:-"0 1 2 3 4"}
 rep=$o/next_session_report.txt; : >> $rep
 stage() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 say() { echo "$@" | tee -a $rep; }
@@ -25,56 +28,54 @@ print("  %.3f ms/step  %.1f k row-steps/s | spatial %s us  bwd_spatial %s us  te
 PY
 }
 bench() { tag=$1; shift; timeout 400 "$@" > $o/ns_$tag.json 2> $o/ns_$tag.err; say "$tag:"; line $o/ns_$tag.json | tee -a $rep; }
+V=tools/with_variant.sh
 T="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split --no-legs --no-live-pmc"
+C4="python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc"
 
 if stage 0; then
-say "== 0. wave_sum / wave_max against a host loop"
+say "== 0. wave_sum / wave_max (shuffle and DPP forms) against a host loop"
 tools/bin/dpp_check0 2>&1 | tail -1 | tee -a $rep
 tools/bin/dpp_check1 2>&1 | tail -1 | tee -a $rep
 fi
 if stage 1; then
-say "== 1. configs[1] train step: product build, then the DPP build, then spatial_bwd2 under both"
+say "== 1. configs[1] train step: product build, the DPP build, spatial_bwd2 under both"
 bench c2_product $T
-bench c2_dpp tools/with_variant.sh dpp $T
-STATTN_BWD2=1 bench c2_bwd2_4wg $T
-STATTN_BWD2=2 bench c2_bwd2_3wg $T
-STATTN_BWD2=1 bench c2_dpp_bwd2_4wg tools/with_variant.sh dpp $T
-STATTN_BWD2=2 bench c2_dpp_bwd2_3wg tools/with_variant.sh dpp $T
+bench c2_dpp $V dpp $T
+STATTN_BWD2=1 bench c2_bwd2_4wg $V exp $T
+STATTN_BWD2=2 bench c2_bwd2_3wg $V exp $T
+STATTN_BWD2=1 bench c2_dpp_bwd2_4wg $V expdpp $T
+STATTN_BWD2=2 bench c2_dpp_bwd2_3wg $V expdpp $T
 bench c2_product_again $T
 fi
 if stage 2; then
-say "== 2. parity under the DPP build (whole GPU suite), and of spatial_bwd2 (backward tests, both register budgets)"
-tools/with_variant.sh dpp timeout 2400 python -m pytest tests -m gpu -x -q > $o/ns_tests_dpp.log 2>&1; tail -2 $o/ns_tests_dpp.log | tee -a $rep
+say "== 2. parity: whole GPU suite under the DPP build; backward + property tests under spatial_bwd2 (both register budgets, both reductions)"
+$V dpp timeout 2400 python -m pytest tests -m gpu -x -q > $o/ns_tests_dpp.log 2>&1; tail -2 $o/ns_tests_dpp.log | tee -a $rep
 for v in 1 2; do
-    STATTN_BWD2=$v timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_properties.py -m gpu -x -q > $o/ns_tests_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v: $(tail -1 $o/ns_tests_bwd2_$v.log)"
-    STATTN_BWD2=$v tools/with_variant.sh dpp timeout 1200 python -m pytest tests/test_gpu_backward.py -m gpu -x -q > $o/ns_tests_dpp_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v + DPP: $(tail -1 $o/ns_tests_dpp_bwd2_$v.log)"
+    STATTN_BWD2=$v $V exp timeout 1200 python -m pytest tests/test_gpu_backward.py tests/test_gpu_properties.py -m gpu -x -q > $o/ns_tests_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v: $(tail -1 $o/ns_tests_bwd2_$v.log)"
+    STATTN_BWD2=$v $V expdpp timeout 1200 python -m pytest tests/test_gpu_backward.py -m gpu -x -q > $o/ns_tests_dpp_bwd2_$v.log 2>&1; say "STATTN_BWD2=$v + DPP: $(tail -1 $o/ns_tests_dpp_bwd2_$v.log)"
 done
 fi
 if stage 3; then
-say "== 3. other configurations under the DPP build"
-bench c4_bf16_product python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-bench c4_bf16_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-bench c4_bf16_wps2 tools/with_variant.sh wps2 python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-bench c4_bf16_fwdsched tools/with_variant.sh fwdsched python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-STATTN_BF16_V2=1 bench c4_bf16_v2 python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-STATTN_BF16_V2=1 bench c4_bf16_v2_dpp tools/with_variant.sh dpp python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc
-STATTN_BF16_V2=1 timeout 900 python -m pytest tests/test_gpu_bf16.py -m gpu -x -q > $o/ns_tests_bf16v2.log 2>&1; say "STATTN_BF16_V2=1 test_gpu_bf16: $(tail -1 $o/ns_tests_bf16v2.log)"
-STATTN_BF16_V2=1 timeout 900 python tools/fuzz_parity.py 45 4242 > $o/ns_fuzz_bf16v2.log 2>&1; say "STATTN_BF16_V2=1 fuzz (every third case a bf16 handle): $(tail -1 $o/ns_fuzz_bf16v2.log)"
+say "== 3. configs[3] bf16 step and the other legs under the variants"
+bench c4_bf16_product $C4
+bench c4_bf16_dpp $V dpp $C4
+bench c4_bf16_wps2 $V wps2 $C4
+bench c4_bf16_fwdsched $V fwdsched $C4
+STATTN_BF16_V2=1 bench c4_bf16_v2 $V exp $C4
+STATTN_BF16_V2=1 bench c4_bf16_v2_dpp $V expdpp $C4
+STATTN_BF16_V2=1 $V exp timeout 900 python -m pytest tests/test_gpu_bf16.py -m gpu -x -q > $o/ns_tests_bf16v2.log 2>&1; say "STATTN_BF16_V2=1 test_gpu_bf16: $(tail -1 $o/ns_tests_bf16v2.log)"
+STATTN_BF16_V2=1 $V exp timeout 900 python tools/fuzz_parity.py 45 4242 > $o/ns_fuzz_bf16v2.log 2>&1; say "STATTN_BF16_V2=1 fuzz (every third case a bf16 handle): $(tail -1 $o/ns_fuzz_bf16v2.log)"
 bench c5_product python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
-bench c5_dpp tools/with_variant.sh dpp python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
+bench c5_dpp $V dpp python bench.py --mode beam --config c5 --steps 5 --warmup 1 --no-cpu-baseline
 bench eval_product python bench.py --mode eval --no-cpu-baseline
-bench eval_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
+bench eval_dpp $V dpp python bench.py --mode eval --no-cpu-baseline
 fi
 if stage 4; then
 say "== 4. column-per-lane shared attention (K <= 8 beams): parity, then the evaluation workload"
-STATTN_SHARED_COLS=1 timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q > $o/ns_tests_cols.log 2>&1; say "STATTN_SHARED_COLS=1: $(tail -1 $o/ns_tests_cols.log)"
-STATTN_SHARED_COLS=1 tools/with_variant.sh dpp timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $o/ns_tests_cols_dpp.log 2>&1; say "STATTN_SHARED_COLS=1 + DPP: $(tail -1 $o/ns_tests_cols_dpp.log)"
-STATTN_SHARED_COLS=1 bench eval_cols python bench.py --mode eval --no-cpu-baseline
-STATTN_SHARED_COLS=1 bench eval_cols_dpp tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 tools/with_variant.sh dpp python bench.py --mode eval --no-cpu-baseline
-fi
-if stage 5; then
-say "== 5. trained-like weights (peaked attention, saturating gates, logits of +-10): fp32 / split / bf16 handles against the float64 oracle"
-timeout 1500 python tools/fuzz_parity.py trained 18 777 > $o/ns_fuzz_trained.log 2>&1; tail -1 $o/ns_fuzz_trained.log | tee -a $rep
+STATTN_SHARED_COLS=1 $V exp timeout 1500 python -m pytest tests/test_gpu_parity.py tests/test_gpu_fuzz.py -m gpu -x -q > $o/ns_tests_cols.log 2>&1; say "STATTN_SHARED_COLS=1: $(tail -1 $o/ns_tests_cols.log)"
+STATTN_SHARED_COLS=1 $V expdpp timeout 1500 python -m pytest tests/test_gpu_parity.py -m gpu -x -q > $o/ns_tests_cols_dpp.log 2>&1; say "STATTN_SHARED_COLS=1 + DPP: $(tail -1 $o/ns_tests_cols_dpp.log)"
+STATTN_SHARED_COLS=1 bench eval_cols $V exp python bench.py --mode eval --no-cpu-baseline
+STATTN_SHARED_COLS=1 bench eval_cols_dpp $V expdpp python bench.py --mode eval --no-cpu-baseline
+STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 $V expdpp python bench.py --mode eval --no-cpu-baseline
 fi
 say "== done ($STAGES)"

@@ -3,8 +3,9 @@
 // A product build (the Makefile's default) reads exactly the environment variables named in STATTN_PRODUCT_SWITCHES below -- each of
 // them selects between two paths that are BOTH covered by the GPU parity suite, or is a documented fallback.  Everything else the
 // sources consult (tile forcing, ablations, ring depths, A/B of a launch rule ...) is a TOOL switch: sw_tool() reads the environment
-// only in a -DSTATTN_PROBES build (make PROBES=1, tools/build_variant.sh) and is the constant nullptr in the product library, so a
-// stray variable can not move the product off its measured paths.  (the library read 38 variables.)
+// only in a tools build (-DSTATTN_TOOL_SWITCHES: tools/build_tools_lib.sh -> tools/_var/libstattn_tools.so, same kernels, host code that
+// listens; also implied by -DSTATTN_PROBES) and is the constant nullptr in the product library, so a stray variable can not move the
+// product off its measured paths.  (the library read 38 variables.)
 #pragma once
 #include <cstdlib>
 #include <cstring>
@@ -48,8 +49,8 @@ inline const char* sw_product_name(int i) {
 // a switch of the product library (must be on the list: a typo is a null switch in every build, caught by tests/test_abi_and_host.py)
 inline const char* sw_product(const char* name) { return sw_is_product(name) ? getenv(name) : nullptr; }
 
-// a tool switch: the environment in probe builds, nothing in the product
-#ifdef STATTN_PROBES
+// a tool switch: the environment in tools / probe builds, nothing in the product
+#if defined(STATTN_TOOL_SWITCHES) || defined(STATTN_PROBES)
 inline const char* sw_tool(const char* name) { return getenv(name); }
 #else
 inline const char* sw_tool(const char*) { return nullptr; }

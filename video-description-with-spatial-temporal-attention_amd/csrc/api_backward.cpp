@@ -176,11 +176,10 @@ int stattn_backward(stattn_handle* h, float nll_scale, float alpha_c) {
     // words of this batch), so only that region is cleared (the padding between arrays was zeroed at creation)
     HIPCHK(h, hipMemsetAsync(G_("Wemb"), 0, h->params[h->pindex["ff_state_W"]].off * sizeof(float), s));
 
-    // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout
-    // only as a = tanh(z) * d2.  The backward pass is the fp32 one, evaluated at those stored activations: they are widened
-    // (exactly) into fp32 buffers, tanh(z) is recovered from a and the dropout multiplier, everything else was fp32 anyway.
-    // the attention backward kernels, the tanh backward and the GEMM operand conversions read the region tensors as they are
-    // stored (bf16 on a bf16 handle: half their stream, no widened copies); tanh(z) of the readout is recovered from a = tanh(z) d2
+    // bf16 handle (mixed precision): the forward pass kept the region tensors L / PL / LW in bf16 and tanh(z) of the readout only as
+    // a = tanh(z) * d2.  The attention backward kernels, the tanh backward and the GEMM operand conversions read the region tensors as
+    // they are stored (half their stream, no widened copies); tanh(z) is recovered from a and the dropout multiplier; every LDS-tiled
+    // GEMM of the pass rounds both operands to bf16 on the way in (gemm_bf_one above), everything else is the fp32 backward.
     const float *Ls = L, *PLs = PL, *LWs = LW;
     if (bf) {
         PL = nullptr; LW = nullptr;

@@ -599,7 +599,8 @@ def test_msvd_eval_shape_batched_beam_search(stattn_mod, O):
     P = O.random_params(opt, seed=29, dtype=np.float32)
     P['ff_logit_b'] = P['ff_logit_b'].copy(); P['ff_logit_b'][0] += 2.0        # some hypotheses end early
     P64 = O.cast_params(P, np.float64)
-    nvid, T, K, k, maxlen = 51, 28, 8, 5, 7
+    # (STATTN_EVAL_SHAPE_VIDEOS: the A/B of larger chunks under a tools build, tools/next_gpu_session.sh stage 5; 51 in the suite)
+    nvid, T, K, k, maxlen = int(os.environ.get('STATTN_EVAL_SHAPE_VIDEOS', 51)), 28, 8, 5, 7
     b = O.synthetic_batch(opt, B=nvid, T=T, K=K, t=3, seed=63)
     model = stattn_mod.Attention()
     tparams = model.init_tparams(P)

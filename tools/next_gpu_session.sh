@@ -11,7 +11,7 @@
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out; mkdir -p $o
-STAGES=${STAGES:-"0 1 2 3 4"}
+STAGES=${STAGES:-"0 1 2 3 4 5"}
 rep=$o/next_session_report.txt; : >> $rep
 stage() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 say() { echo "$@" | tee -a $rep; }
@@ -77,5 +77,13 @@ STATTN_SHARED_COLS=1 $V expdpp timeout 1500 python -m pytest tests/test_gpu_pari
 STATTN_SHARED_COLS=1 bench eval_cols $V exp python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 bench eval_cols_dpp $V expdpp python bench.py --mode eval --no-cpu-baseline
 STATTN_SHARED_COLS=1 STATTN_SHARED_MIN=100 bench eval_cols_dpp_min100 $V expdpp python bench.py --mode eval --no-cpu-baseline
+fi
+if stage 5; then
+say "== 5. evaluation chunks beyond 255 rows on the row-panel kernels (tools build, STATTN_PANEL_MAX_ROWS=512): parity of a 102-video call, then the leg"
+for ch in 51 64 80 102; do
+    bench eval_chunk${ch}_rule256 $V tools python bench.py --mode eval --eval-chunk $ch --no-cpu-baseline
+    STATTN_PANEL_MAX_ROWS=512 bench eval_chunk${ch}_rule512 $V tools python bench.py --mode eval --eval-chunk $ch --no-cpu-baseline
+done
+STATTN_PANEL_MAX_ROWS=512 STATTN_EVAL_SHAPE_VIDEOS=102 $V tools timeout 900 python -m pytest tests/test_gpu_parity.py -m gpu -x -q -k "msvd_eval_shape or batched_beam_search or c5_" > $o/ns_tests_rows512.log 2>&1; say "STATTN_PANEL_MAX_ROWS=512 beam tests (102 videos at the evaluation shape): $(tail -1 $o/ns_tests_rows512.log)"
 fi
 say "== done ($STAGES)"

@@ -259,8 +259,12 @@ int init_state(stattn_handle* h, int nv, int T, const float* G, const float* mas
 // kernels give 32)
 bool use_panels(const stattn_handle* h, int M, int min_rows) {
     static const char* off = sw_product("STATTN_NO_PANELS");       // A/B switch for tools
-    // (the kernels take up to 512 rows; past 256 the 64-column kernels, which split the rows over workgroups, are as fast)
-    return !off && M >= min_rows && M <= 256 && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
+    // (the kernels take up to 512 rows; past 256 the 64-column kernels, which split the rows over workgroups, were as fast when the rule
+    //  was set -- before the wide kernels of panelw.hip existed.  The evaluation workload says otherwise (52 videos = 260 rows: 1609
+    //  videos/s against 2597 at 255 rows), so the bound is a tool switch for the A/B: STATTN_PANEL_MAX_ROWS=512 in a tools build)
+    static const char* mx = sw_tool("STATTN_PANEL_MAX_ROWS");
+    const int max_rows = mx ? atoi(mx) : 256;
+    return !off && M >= min_rows && M <= max_rows && panel_supported(M) && h->D % 16 == 0 && h->E % 16 == 0;
 }
 
 // repacking jobs are collected per pass and run as one launch (pack_flush)

@@ -8,10 +8,13 @@
 #   exp      STATTN_BF16_V2=1               spatial_bf16v2 / spatial_bwd_bf16v2 (68 -> <= 55 us, 100 -> <= 80 us with no scratch)
 #   exp      STATTN_SHARED_COLS=1           spatial_shared_cols_kernel     (eval shared-slab launch 92 -> <= 70 us)
 #   wps2 / fwdsched                         one-line variants of the shipped bf16 attention kernels
+#   pnv2     -DSTATTN_PN_V2=1               row-panel kernels with the prologue rewritten against its ISA (panel.hip): no exposed early
+#                                           round trip, half the scalar waits (panel_kernel<4,1,512,4> 11.6 -> <= 10 us, lstm 12.5 -> <= 11 us,
+#                                           whole suite green, results bit-identical to the product's)
 root=${GRAFT_REPO_ROOT:-/root/repo}
 cd $root
 o=gpurun_out; mkdir -p $o
-STAGES=${STAGES:-"0 1 2 3 4 5"}
+STAGES=${STAGES:-"6 0 1 2 3 4 5"}
 rep=$o/next_session_report.txt; : >> $rep
 stage() { case " $STAGES " in *" $1 "*) return 0;; esac; return 1; }
 say() { echo "$@" | tee -a $rep; }
@@ -32,6 +35,17 @@ V=tools/with_variant.sh
 T="python bench.py --steps 20 --warmup 3 --no-cpu-baseline --no-split --no-legs --no-live-pmc"
 C4="python bench.py --config c4 --precision bf16 --steps 10 --warmup 2 --no-cpu-baseline --no-legs --no-live-pmc"
 
+if stage 6; then
+say "== 6. row-panel prologue V2 (variant pnv2): headline step, decode legs, then the whole GPU suite under it"
+bench c2_product_a $T
+bench c2_pnv2 $V pnv2 $T
+bench c2_product_b $T
+bench c2_pnv2_b $V pnv2 $T
+for m in "--mode decode --config c1 --steps 5 --warmup 1" "--mode beam --config c1 --beam 5 --steps 50 --warmup 3" "--mode beam --config c5 --steps 5 --warmup 1"; do
+    t=$(echo $m | tr -d ' -'); bench ${t}_product python bench.py $m --no-cpu-baseline; bench ${t}_pnv2 $V pnv2 python bench.py $m --no-cpu-baseline
+done
+$V pnv2 timeout 2400 python -m pytest tests -m gpu -x -q > $o/ns_tests_pnv2.log 2>&1; say "pnv2 whole suite: $(tail -1 $o/ns_tests_pnv2.log)"
+fi
 if stage 0; then
 say "== 0. wave_sum / wave_max (shuffle and DPP forms) against a host loop"
 tools/bin/dpp_check0 2>&1 | tail -1 | tee -a $rep

@@ -43,6 +43,29 @@ namespace {
 // L2 round trip of its own, in the tail (or, for the LSTM kernel's "early" requests, in front) of a 5 - 12 us launch.
 __device__ const float pn_zero = 0.f, pn_one = 1.f;
 
+// -DSTATTN_PN_V2=1 (variant library `pnv2`, tools/build_all_variants.sh; NOT the product build, unmeasured): the prologues of panel_kernel
+// and lstm_panel_kernel rewritten against their ISA (round 6, tools/isa_skeleton.py):
+//  (1) `p ? p : &pn_zero` makes the early epilogue requests FLAT loads (the select mixes a kernel-argument pointer with the address of
+//      a __device__ constant), and flat loads count on lgkmcnt as well as vmcnt: every `s_waitcnt lgkmcnt(0)` behind a later scalar
+//      load waited for them, and `s_waitcnt vmcnt(0)` stood in front of the ring's first operand request -- the "early" requests were
+//      a fully exposed memory round trip at the head of every launch.  V2 loads them through global (address space 1) pointers;
+//  (2) the pair loop (1 - 3 operand pairs) is a real loop: loads pending across its head make LLVM's wait-count pass drain the queue
+//      there.  V2 unrolls it (straight-line code for the common single pair): no wait between the early requests and the ring;
+//  (3) the fields of the dynamically indexed segment / pair were re-read at every use, each an s_load with its own wait: about ten
+//      dependent scalar round trips in front of the first operand request.  V2 reads them once, and finds the segment with
+//      independent loads of all segment widths instead of one dependent load per segment passed.
+// ISA of panel_kernel<4,1,512,4,false>: 20 -> 8 scalar waits before the first operand request, no vector wait there, the main
+// loop's staged vmcnt(15..12) unchanged, 156 -> 152 VGPRs.  Same arithmetic in the same order: results are bit-identical.
+#ifndef STATTN_PN_V2
+#define STATTN_PN_V2 0
+#endif
+#if STATTN_PN_V2
+typedef const __attribute__((address_space(1))) float* pn_gptr;
+#define PN_G(p) ((pn_gptr)(p))
+#else
+#define PN_G(p) (p)
+#endif
+
 // ---- general grouped GEMM with fused epilogue ------------------------------------------------------------
 template <int MT, int NT, int MAXT, int R, bool ONESHOT>
 __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int MG, const int KS) {
@@ -51,9 +74,28 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     // locate the segment of this group of NT column tiles.  Neighbouring tiles share the cache lines of the row-major
     // epilogue operands and of C (a tile's 64 / 128 bytes per row are a fraction of a line): XCD-contiguous tile ranges
     int tg = xcd_contiguous((int)blockIdx.x, (int)gridDim.x), si = 0;
+#if STATTN_PN_V2
+    {
+        int nt[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) nt[i] = a.seg[i].N / CB;        // (segments past nseg: whatever the argument block holds, never used)
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const bool adv = si == i && i + 1 < a.nseg && tg >= nt[i];
+            tg -= adv ? nt[i] : 0; si += adv ? 1 : 0;
+        }
+    }
+#else
     while (si + 1 < a.nseg && tg >= a.seg[si].N / CB) { tg -= a.seg[si].N / CB; ++si; }
+#endif
     const PnSeg& sg = a.seg[si];
+#if STATTN_PN_V2
+    // (4) the wave index as a SCALAR: as a vector value, `last = s0 + (n - 1) * stride` of pn_accumulate became a v_mad_u64_u32 whose
+    //     64-bit addend pair had a pending load's destination as its unused high half -- and the wait-count pass waited for that load
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#endif
     const int j = lane & 15, g = lane >> 4;
     const int mg = w % MG, ks = w / MG;
     const int RB = MG * MT * 16;
@@ -75,8 +117,8 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     auto epi_load = [&](int idx) {
         const int row = min(idx / CB, M - 1), n = n0 + idx % CB;
         Epi e;
-        e.b = bias[n * sbias]; e.b2 = bias2[n * sbias2];
-        e.ad = add[((size_t)row * ldadd + n) * sadd]; e.ml = mul[((size_t)row * ldmul + n) * smul];
+        e.b = PN_G(bias)[n * sbias]; e.b2 = PN_G(bias2)[n * sbias2];
+        e.ad = PN_G(add)[((size_t)row * ldadd + n) * sadd]; e.ml = PN_G(mul)[((size_t)row * ldmul + n) * smul];
         return e;
     };
     const Epi e0 = epi_load(min(tid, RB * CB - 1));
@@ -85,6 +127,25 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
     for (int i = 0; i < MT; ++i)
 #pragma unroll
         for (int n = 0; n < NT; ++n) acc[i][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if STATTN_PN_V2
+    const int npairs = sg.npairs;
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (p >= npairs) break;
+        struct { const float* A; const float* P; int K, lda, apk; } pr;      // the pair's fields, read once
+        pr.A = sg.p[p].A; pr.P = sg.p[p].P; pr.K = sg.p[p].K; pr.lda = sg.p[p].lda; pr.apk = sg.p[p].apk;
+        const float* Ap[MT];
+#pragma unroll
+        for (int i = 0; i < MT; ++i) {
+            const int row = min((mg * MT + i) * 16 + j, M - 1);
+            const size_t opk = ((size_t)min(mg * MT + i, (M - 1) >> 4) * (pr.K >> 4)) * 256 + 4 * lane;
+            Ap[i] = pr.A + (pr.apk ? opk : (size_t)row * pr.lda + 4 * g);
+        }
+        const int astep = pr.apk ? 256 : 16;
+        const int nsteps = pr.K >> 4;
+        const size_t tile_floats = (size_t)nsteps * 256;
+        const float* Bp = pr.P + (size_t)tg * NT * tile_floats + 4 * lane;
+#else
     for (int p = 0; p < sg.npairs; ++p) {
         const PnPair& pr = sg.p[p];
         const float* Ap[MT];
@@ -100,6 +161,7 @@ __global__ __launch_bounds__(MAXT) void panel_kernel(const PnArgs a, const int M
         const int nsteps = pr.K >> 4;
         const size_t tile_floats = (size_t)nsteps * 256;
         const float* Bp = pr.P + (size_t)tg * NT * tile_floats + 4 * lane;
+#endif
 #if defined(STATTN_PROBES) && PN_VARIANT == 6
         // tools/panel_probe.hip, VERDICT r03 item 3(a): what the main loop costs when the workgroup's weight slice is ALREADY in
         // LDS (a persistent kernel would keep it there across the decoder steps): the slice is copied in before the timed part
@@ -195,7 +257,13 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
     // with tile c on XCD c % 8 the four to eight tiles that share a line sat on as many XCDs and every one of them
     // fetched the line for itself (measured: 40 MB through the fabric per launch for 20 MB of distinct bytes)
     const int c = xcd_contiguous((int)blockIdx.x, (int)gridDim.x);
+#if STATTN_PN_V2
+    // (4) the wave index as a SCALAR: as a vector value, `last = s0 + (n - 1) * stride` of pn_accumulate became a v_mad_u64_u32 whose
+    //     64-bit addend pair had a pending load's destination as its unused high half -- and the wait-count pass waited for that load
+    const int tid = threadIdx.x, lane = tid & 63, w = __builtin_amdgcn_readfirstlane(tid >> 6);
+#else
     const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+#endif
     const int j = lane & 15, g = lane >> 4;
     const int mg = w % MG, ks = w / MG;
     const int RB = MG * MT * 16;
@@ -217,22 +285,28 @@ __global__ __launch_bounds__(MAXT) void lstm_panel_kernel(const LstmPnArgs a, co
         const int row = min(idx >> 2, a.M - 1), d = 4 * c + (idx & 3);
 #pragma unroll
         for (int gate = 0; gate < 4; ++gate) {
-            e.add[gate] = padd[((size_t)row * a.ldpre + gate * D + d) * sadd];
-            e.bias[gate] = pbias[(gate * D + d) * sbias];
+            e.add[gate] = PN_G(padd)[((size_t)row * a.ldpre + gate * D + d) * sadd];
+            e.bias[gate] = PN_G(pbias)[(gate * D + d) * sbias];
         }
 #pragma unroll
         for (int q = 0; q < 3; ++q) e.dp[q] = a.dp[(size_t)row * a.lddp + q * D + d];
         e.cp = a.c_prev[(size_t)row * D + d];
         e.hp = a.h_prev[(size_t)row * D + d];
-        e.m = pmask[row * smask];
-        e.d1 = pd1[((size_t)row * a.ldd1 + d) * sd1];
+        e.m = PN_G(pmask)[row * smask];
+        e.d1 = PN_G(pd1)[((size_t)row * a.ldd1 + d) * sd1];
         return e;
     };
     const EpiIn e0 = epi_load(min(tid, RB * 4 - 1));
     f32x4 acc[MT][1];
 #pragma unroll
     for (int i = 0; i < MT; ++i) acc[i][0] = f32x4{0.f, 0.f, 0.f, 0.f};
+#if STATTN_PN_V2
+#pragma unroll
+    for (int p = 0; p < 3; ++p) {
+        if (p >= a.npairs) break;
+#else
     for (int p = 0; p < a.npairs; ++p) {
+#endif
         const PnPair& pr = a.p[p];
         const float* Ap[MT];
 #pragma unroll

@@ -165,6 +165,24 @@ __device__ __forceinline__ void pw_reduce(float* red, f32x16 (&acc)[MB], int w, 
 // branch and a full wait -- add and mul were two dependent round trips per output row of a thread)
 __device__ __attribute__((aligned(16))) const float pw_zero4[4] = {0.f, 0.f, 0.f, 0.f};
 __device__ __attribute__((aligned(16))) const float pw_one4[4] = {1.f, 1.f, 1.f, 1.f};
+// -DSTATTN_PN_V2=1 (variant `pnv2`, see panel.hip; unmeasured): `p ? p : pw_zero4` mixes a kernel-argument pointer with the address of a
+// __device__ constant, so every load through it is a FLAT load -- counted on lgkmcnt like the LDS reads of the K-slice reduction
+// beside it, which then wait for a global round trip.  V2 reads these operands through global (address space 1) pointers.
+#ifndef STATTN_PN_V2
+#define STATTN_PN_V2 0
+#endif
+#if STATTN_PN_V2
+typedef const __attribute__((address_space(1))) float* pw_gptr;
+__device__ __forceinline__ float4 pw_ld4(const float* p) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    const v4f t = *reinterpret_cast<const __attribute__((address_space(1))) v4f*>((pw_gptr)p);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+#define PW_G(p) ((pw_gptr)(p))
+#else
+#define pw_ld4 ld4
+#define PW_G(p) (p)
+#endif
 
 template <int MB, int R, int KS>
 __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
@@ -209,14 +227,14 @@ __global__ __launch_bounds__(64 * KS) void panelw_kernel(const PnArgs a) {
     const int c4 = (tid & 7) * 4, n = n0 + c4;
     // every global operand of this thread's epilogue in ONE burst: both biases and add / mul of all its rows
     constexpr int NR = (RB * 8 + NTH - 1) / NTH;            // rows per thread
-    float4 b4 = ld4(bias + n * sbias);
-    const float4 b2 = ld4(bias2 + n * sbias2);
+    float4 b4 = pw_ld4(bias + n * sbias);
+    const float4 b2 = pw_ld4(bias2 + n * sbias2);
     float4 ad[NR], ml[NR];
 #pragma unroll
     for (int q = 0; q < NR; ++q) {
         const int row = min(row0 + (tid >> 3) + q * (NTH / 8), a.M - 1);
-        ad[q] = ld4(add + ((size_t)row * ldadd + n) * sadd);
-        ml[q] = ld4(mul + ((size_t)row * ldmul + n) * smul);
+        ad[q] = pw_ld4(add + ((size_t)row * ldadd + n) * sadd);
+        ml[q] = pw_ld4(mul + ((size_t)row * ldmul + n) * smul);
     }
     b4.x += b2.x; b4.y += b2.y; b4.z += b2.z; b4.w += b2.w;
     if (stats) {   // vocabulary statistics of this column block (the logits are never stored): see panel_kernel
@@ -307,18 +325,18 @@ __global__ __launch_bounds__(256) void lstm_panelw_kernel(const LstmPnArgs a) {
     const float* const pd1 = a.d1 ? a.d1 : pw_one4; const int sd1 = a.d1 ? 1 : 0;
     float gbias[4];
 #pragma unroll
-    for (int gate = 0; gate < 4; ++gate) gbias[gate] = pbias[(gate * D + 8 * cb + (tid & 7)) * sbias];
+    for (int gate = 0; gate < 4; ++gate) gbias[gate] = PW_G(pbias)[(gate * D + 8 * cb + (tid & 7)) * sbias];
     auto epi_load = [&](int idx) {
         EpiIn e;
         const int row = min(row0 + (idx >> 3), a.M - 1), d = 8 * cb + (idx & 7);
 #pragma unroll
-        for (int gate = 0; gate < 4; ++gate) e.add[gate] = padd[((size_t)row * a.ldpre + gate * D + d) * sadd];
+        for (int gate = 0; gate < 4; ++gate) e.add[gate] = PW_G(padd)[((size_t)row * a.ldpre + gate * D + d) * sadd];
 #pragma unroll
         for (int q = 0; q < 3; ++q) e.dp[q] = a.dp[(size_t)row * a.lddp + q * D + d];
         e.cp = a.c_prev[(size_t)row * D + d];
         e.hp = a.h_prev[(size_t)row * D + d];
-        e.m = pmask[row * smask];
-        e.d1 = pd1[((size_t)row * a.ldd1 + d) * sd1];
+        e.m = PW_G(pmask)[row * smask];
+        e.d1 = PW_G(pd1)[((size_t)row * a.ldd1 + d) * sd1];
         return e;
     };
     PW_STAMP(0);

@@ -126,3 +126,47 @@ def test_hip_path_meets_the_bar_on_trained_like_weights(name):
         if bf and k == "decoder_b_sel":                            # a scalar sum of signed terms: priced against the terms' scale (tools/fuzz_parity.py)
             scale = max(scale, np.abs(np.asarray(rg["grads"]["decoder_W_sel"])).max())
         assert np.abs(got[k] - rg["grads"][k]).max() <= bar_g * scale + 5e-6, (k, np.abs(got[k] - rg["grads"][k]).max(), scale)
+
+
+def test_reference_format_checkpoint_goes_through_the_reload_path(tmp_path):
+    """tools/checkpoint_parity.py on an archive written the way the reference writes model_best_so_far.npz (numpy.savez(path,
+    history_errs=..., **params), model_attention.py:1488-1490), holding the trained-like fp32 case: the options are read off the
+    array shapes, the weights go through Attention.load_params -> init_tparams (the reference's reload sequence), and the training
+    graph, f_init and a teacher-forced f_next chain meet 1e-4 against the float64 oracle.  What a user holding the real checkpoint
+    (README.md:53) would run; the CPU half (archive -> options -> oracle peakedness) is test_checkpoint_archive_round_trip."""
+    pytest.importorskip("torch")
+    import torch
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import checkpoint_parity
+    _, _, opt, P, batch, ref = make_case("fp32")
+    path = str(tmp_path / "model_best_so_far.npz")
+    np.savez(path, history_errs=np.zeros((3, 2)), **P)
+    err, peak = checkpoint_parity.run(path, videos=4, frames=9, regions=6, steps=5, verbose=False)
+    assert min(peak.values()) >= 0.6, peak
+    assert all(v < 1e-4 for v in err.values()), err
+
+
+test_reference_format_checkpoint_goes_through_the_reload_path = pytest.mark.gpu(test_reference_format_checkpoint_goes_through_the_reload_path)
+
+
+def test_checkpoint_archive_round_trip(tmp_path):
+    """CPU: an archive in the reference's format gives back the options and, through the product's load_params, the exact weights."""
+    import os, sys
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import checkpoint_parity
+    import stattn
+    _, _, opt, P, batch, ref = make_case("split")
+    path = str(tmp_path / "model_best_so_far.npz")
+    np.savez(path, history_errs=np.zeros((3, 2)), **P)
+    got = checkpoint_parity.options_from_archive(np.load(path))
+    for k in ("dim", "dim_word", "n_words", "ctxg_dim", "ctxl_dim", "ctxm_dim", "selector", "ctx2out", "prev2out"):
+        assert got[k] == opt[k], k
+    model = stattn.Attention()
+    stattn.common.reset_rngs(1234)
+    params = model.load_params(path, model.init_params(got))
+    assert list(params) == list(P)
+    for k in P:
+        np.testing.assert_array_equal(params[k], P[k])

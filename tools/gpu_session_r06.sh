@@ -1,5 +1,5 @@
 #!/bin/bash
-# usage (through gpurun): tools/gpu_session_r06.sh [first|ab|profiles]
+# usage (through gpurun): tools/gpu_session_r06.sh [first|ab|ab1|ab2|profiles]
 #   first    = the verified-tree run of round 6: whole GPU suite + smoke() + the default bench line, logs kept
 #   ab       = tools/next_gpu_session.sh (the prepared A/Bs; needs the tools/_var libraries built before the call)
 #   profiles = tools/collect_profiles.sh r06
@@ -17,5 +17,7 @@ first)
     timeout 900 python bench.py > $o/r06_bench_first.json 2> $o/r06_bench_first.err; tail -c 600 $o/r06_bench_first.json
     ;;
 ab) shift; tools/next_gpu_session.sh "$@" ;;
+ab1) STAGES="6 0 1 2" tools/next_gpu_session.sh ;;      # the A/B session in two calls of about 45 minutes each
+ab2) STAGES="3 4 5" tools/next_gpu_session.sh ;;
 profiles) tools/collect_profiles.sh r06 ;;
 esac

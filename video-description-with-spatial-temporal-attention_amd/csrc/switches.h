@@ -18,10 +18,10 @@ namespace stattn {
     X(STATTN_NO_UPDATE_RIDER)  /* beam update in its own launch instead of riding the next word's attention tests/test_gpu_parity.py */ \
     X(STATTN_NO_ROW_WG)        /* one update workgroup per video instead of one per hypothesis             tests/test_gpu_parity.py */ \
     X(STATTN_NO_PANELS)        /* recurrent GEMMs on the LDS-tiled kernels instead of the row-panel ones    tests/test_gpu_parity.py */ \
-    X(STATTN_GEMM_NOGROUP)     /* one launch per GEMM problem instead of grouped launches                  bench.py accounting, tests via bench */ \
-    X(STATTN_READOUT_NOPAIR)   /* readout as two GEMMs instead of one K-concatenated launch                bench.py accounting */ \
-    X(STATTN_WIDE_STATS_FROM)  /* first beam width whose vocabulary launch uses the wide statistics path   DESIGN.md section 9 (fallback: 65) */ \
-    X(STATTN_BEAM_NOGRAPH)     /* word loop of stattn_beam_search without hipGraph capture                 fallback */ \
+    X(STATTN_GEMM_NOGROUP)     /* one launch per GEMM problem instead of grouped launches                  tests/test_gpu_z3_switches.py, bench.py accounting */ \
+    X(STATTN_READOUT_NOPAIR)   /* readout as two GEMMs instead of one K-concatenated launch                tests/test_gpu_z3_switches.py */ \
+    X(STATTN_WIDE_STATS_FROM)  /* first beam width whose vocabulary launch uses the wide statistics path   tests/test_gpu_z3_switches.py (65 = stored logits) */ \
+    X(STATTN_BEAM_NOGRAPH)     /* word loop of stattn_beam_search without hipGraph capture                 tests/test_gpu_z3_switches.py */ \
     X(STATTN_COMM_NO_OVERLAP)  /* one all-reduce after the backward pass instead of five overlapped ones   fallback, tests/test_gpu_dp2.py */ \
     X(STATTN_DBG_REDZONE)      /* canary zones around every device buffer, checked after every API call    tests/test_gpu_z1_redzone.py */
 
